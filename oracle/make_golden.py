@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING THE REFERENCE in this container.
+
+TEST INFRASTRUCTURE ONLY.  This script imports quadbio/cellmapper from ``/root/reference``
+(read-only; never copied) with two inert stub modules for the packages that are absent
+here (``anndata`` -> our MiniAnnData container, ``scanpy`` -> empty module; both are only
+touched by out-of-scope fallback code) and drives the reference's own public API:
+
+    Neighbors(xrep, yrep).compute_neighbors(method="sklearn", ...)        knn.py:339-465
+    NeighborsResults.knn_graph_connectivities(kernel=...)                  knn.py:134-164
+    CellMapper(query, reference).map(use_rep=..., obs_keys=..., ...)       cellmapper.py:426-491
+
+The outputs (plus the inputs and library versions) are stored as small ``.npz`` fixtures
+under ``tests/golden/``.  Fixtures are data; the reference itself never ships.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.metadata
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+import scipy
+import scipy.sparse as sp
+import sklearn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SRC = "/root/reference/src/cellmapper"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from cellmapper_amd._anndata import MiniAnnData  # noqa: E402
+
+
+def load_reference():
+    """Import the reference's model modules with inert stubs for anndata / scanpy."""
+    pkg = types.ModuleType("cellmapper")
+    pkg.__path__ = [REF_SRC]
+    pkg.version = importlib.metadata.version  # needed by check.py
+    sys.modules["cellmapper"] = pkg
+    ad = types.ModuleType("anndata")
+    ad.AnnData = MiniAnnData
+    sys.modules["anndata"] = ad
+    sc = types.ModuleType("scanpy")
+    scget = types.ModuleType("scanpy.get")
+    scget._check_mask = None
+    scget._get_obs_rep = None
+    sc.get = scget
+    sys.modules["scanpy"] = sc
+    sys.modules["scanpy.get"] = scget
+    os.environ.setdefault("LOGLEVEL", "WARNING")
+    cm = importlib.import_module("cellmapper.model.cellmapper")
+    knn = importlib.import_module("cellmapper.model.knn")
+    utils = importlib.import_module("cellmapper.utils")
+    return cm, knn, utils
+
+
+VERSIONS = dict(
+    v_sklearn=sklearn.__version__, v_scipy=scipy.__version__, v_numpy=np.__version__, v_pandas=pd.__version__
+)
+KERNELS = ["gaussian", "scarches", "inverse_distance", "equal"]
+
+
+def csr_parts(prefix, m):
+    m = m.tocsr()
+    return {f"{prefix}_indptr": m.indptr, f"{prefix}_indices": m.indices, f"{prefix}_data": m.data,
+            f"{prefix}_shape": np.asarray(m.shape)}
+
+
+def label_names(codes):
+    return np.array([f"c{c:02d}" for c in codes])
+
+
+def run_mapping_case(cm_mod, name, xrep, yrep, k, metric="euclidean", seed=0, n_cat=20, G=48, only_yx=True,
+                     transfer_kernels=("gaussian",), rep_key="X_emb"):
+    """Full CellMapper.map() run through the reference; returns dict of arrays."""
+    rng = np.random.default_rng(seed + 1000)
+    n_ref, nq = xrep.shape[0], yrep.shape[0]
+    label_codes = rng.integers(0, n_cat, n_ref)
+    num_values = rng.standard_normal(n_ref)  # float64 numeric obs column
+    obsm_in = rng.standard_normal((n_ref, 2)).astype(np.float32)
+    X_dense = rng.random((n_ref, G), dtype=np.float32)
+    Xs = sp.random(n_ref, G, density=0.1, format="csr", dtype=np.float32, random_state=seed + 7)
+    Xs.data = np.exp(rng.standard_normal(Xs.nnz)).astype(np.float32)
+
+    out = dict(xrep=xrep, yrep=yrep, k=np.int64(k), metric=np.array(metric), label_codes=label_codes,
+               num_values=num_values, obsm_in=obsm_in, X_dense=X_dense, **csr_parts("X_sparse", Xs), **VERSIONS)
+
+    def make_pair(X):
+        ref = MiniAnnData(X=X,
+                          obs=pd.DataFrame({"label": pd.Categorical(label_names(label_codes)), "num": num_values},
+                                           index=[f"r{i}" for i in range(n_ref)]),
+                          obsm={rep_key: xrep, "X_umap": obsm_in})
+        qry = MiniAnnData(X=np.zeros((nq, 3), dtype=np.float32),
+                          obs=pd.DataFrame(index=[f"q{i}" for i in range(nq)]), obsm={rep_key: yrep})
+        return qry, ref
+
+    first = True
+    for kern in transfer_kernels:
+        qry, ref = make_pair(X_dense)
+        cmap = cm_mod.CellMapper(qry, ref)
+        cmap.map(obs_keys=["label", "num"], obsm_keys="X_umap", layer_key="X", n_neighbors=k, use_rep=rep_key,
+                 knn_method="sklearn", metric=metric, only_yx=only_yx, mapping_method=kern)
+        if first:
+            out["yx_dist"] = cmap.knn.yx.distances
+            out["yx_idx"] = cmap.knn.yx.indices
+            for kk in KERNELS:
+                out.update(csr_parts(f"conn_{kk}", cmap.knn.yx.knn_graph_connectivities(kernel=kk)))
+            if not only_yx:
+                for g in ("xx", "yy", "xy"):
+                    out[f"{g}_dist"] = getattr(cmap.knn, g).distances
+                    out[f"{g}_idx"] = getattr(cmap.knn, g).indices
+            first = False
+        out.update(csr_parts(f"map_{kern}", cmap.mapping_matrix))
+        cats = list(ref.obs["label"].cat.categories)
+        pred = qry.obs["label_pred"]
+        out[f"pred_code_{kern}"] = np.array([int(s[1:]) for s in pred.astype(str)], dtype=np.int64)
+        out[f"conf_{kern}"] = qry.obs["label_conf"].to_numpy()
+        out[f"num_pred_{kern}"] = qry.obs["num_pred"].to_numpy()
+        out[f"obsm_pred_{kern}"] = np.asarray(qry.obsm["X_umap_pred"])
+        out[f"layer_dense_{kern}"] = np.asarray(cmap.query_imputed.X)
+        # sparse layer
+        qry2, ref2 = make_pair(Xs)
+        cmap2 = cm_mod.CellMapper(qry2, ref2)
+        cmap2.knn = cmap.knn
+        cmap2.only_yx = only_yx
+        cmap2.compute_mapping_matrix(method=kern)
+        cmap2.map_layers("X")
+        res = cmap2.query_imputed.X
+        assert sp.issparse(res)
+        res = res.tocsr().copy()
+        res.sort_indices()
+        out.update(csr_parts(f"layer_sparse_{kern}", res))
+        out["categories"] = np.array(cats)
+    if not only_yx:
+        for meth in (("jaccard", "hnoca") if k > 1 else ("jaccard",)):
+            qry, ref = make_pair(X_dense)
+            cmap3 = cm_mod.CellMapper(qry, ref)
+            cmap3.knn = cmap.knn
+            cmap3.only_yx = False
+            cmap3.compute_mapping_matrix(method=meth)
+            mm = cmap3.mapping_matrix.copy()
+            mm.sort_indices()
+            out.update(csr_parts(f"map_{meth}", mm))
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cm_mod, knn_mod, utils_mod = load_reference()
+    saved = {}
+
+    def save(name, d):
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **d)
+        saved[name] = os.path.getsize(path)
+
+    # ---- 1. small_data fixture of the reference's tests (tests/conftest.py:23-28), k=3, full mode
+    x = np.array([[0, 0], [1, 0], [0, 1], [1, 1], [2, 2]], dtype=np.float64)
+    nb = knn_mod.Neighbors(x, x.copy())
+    nb.compute_neighbors(n_neighbors=3, method="sklearn", only_yx=False)
+    d = dict(xrep=x, yrep=x.copy(), k=np.int64(3), **VERSIONS)
+    for g in ("xx", "yy", "xy", "yx"):
+        d[f"{g}_dist"] = getattr(nb, g).distances
+        d[f"{g}_idx"] = getattr(nb, g).indices
+    for kk in KERNELS:
+        d.update(csr_parts(f"conn_{kk}", nb.yx.knn_graph_connectivities(kernel=kk)))
+    d.update(csr_parts("bool_adj", nb.yx.boolean_adjacency()))
+    d.update(csr_parts("graph_dist", nb.yx.knn_graph_distances))
+    save("small_data", d)
+
+    # ---- 2. sample_distances / sample_indices (tests/conftest.py:11-20) through every kernel + normalisation
+    sd = np.array([[0.0, 1.0], [0.0, 2.0], [0.0, 3.0]], dtype=np.float64)
+    si = np.array([[0, 1], [1, 2], [2, 0]], dtype=np.int64)
+    nr = knn_mod.NeighborsResults(distances=sd, indices=si)
+    d = dict(distances=sd, indices=si, **VERSIONS)
+    q = MiniAnnData(X=np.zeros((3, 1), np.float32))
+    for kk in KERNELS:
+        conn = nr.knn_graph_connectivities(kernel=kk)
+        d.update(csr_parts(f"conn_{kk}", conn))
+        cmap = cm_mod.CellMapper(q)
+        cmap.mapping_matrix = conn
+        d.update(csr_parts(f"map_{kk}", cmap.mapping_matrix))
+    d.update(csr_parts("conn_inverse_distance_eps", nr.knn_graph_connectivities(kernel="inverse_distance", epsilon=0.5)))
+    save("sample_graph", d)
+
+    # ---- 3. synthetic embeddings
+    def synth(seed, n_ref, nq, dd, dtype):
+        rng = np.random.default_rng(seed)
+        return rng.standard_normal((n_ref, dd)).astype(dtype), rng.standard_normal((nq, dd)).astype(dtype)
+
+    xr, yr = synth(0, 1536, 192, 50, np.float32)
+    save("synth_f32_k15", run_mapping_case(cm_mod, "synth_f32_k15", xr, yr, 15, transfer_kernels=("gaussian", "inverse_distance")))
+    save("synth_f32_k30", run_mapping_case(cm_mod, "synth_f32_k30", xr, yr, 30, transfer_kernels=("gaussian", "scarches", "equal")))
+    xr64, yr64 = synth(1, 1024, 128, 50, np.float64)
+    save("synth_f64_k30", run_mapping_case(cm_mod, "synth_f64_k30", xr64, yr64, 30))
+    save("synth_f32_cosine_k15", run_mapping_case(cm_mod, "synth_f32_cosine_k15", xr, yr, 15, metric="cosine"))
+    save("synth_f64_cosine_k15", run_mapping_case(cm_mod, "synth_f64_cosine_k15", xr64, yr64, 15, metric="cosine"))
+    # wider embedding, d not multiple of anything, k=1 (identity-style), full mode incl. jaccard / hnoca
+    xr2, yr2 = synth(2, 1024, 200, 37, np.float32)
+    save("synth_full_d37_k10", run_mapping_case(cm_mod, "synth_full_d37_k10", xr2, yr2, 10, only_yx=False))
+    # clustered (gaussian mixture) data with big offsets: stresses cancellation in the ||x||^2-2xy+||y||^2 form
+    rng = np.random.default_rng(3)
+    centers = rng.standard_normal((8, 50)) * 20.0
+    xr3 = (centers[rng.integers(0, 8, 1536)] + rng.standard_normal((1536, 50))).astype(np.float32)
+    yr3 = (centers[rng.integers(0, 8, 192)] + rng.standard_normal((192, 50))).astype(np.float32)
+    save("synth_clustered_k30", run_mapping_case(cm_mod, "synth_clustered_k30", xr3, yr3, 30))
+    # n_comps truncation: rep has 64 dims, reference uses first 50 (cellmapper.py:246-248)
+    xr4, yr4 = synth(4, 1024, 128, 64, np.float32)
+    save("synth_d64_trunc50_k15", run_mapping_case(cm_mod, "synth_d64_trunc50_k15", xr4, yr4, 15))
+
+    # ---- 4. duplicated reference rows (exact ties in distance)
+    xr5, yr5 = synth(5, 512, 64, 50, np.float32)
+    xr5[100:140] = xr5[100]  # 40 identical rows > k
+    xr5[300:305] = xr5[300]
+    yr5[0] = xr5[100]
+    yr5[1] = xr5[300]
+    save("synth_dups_k15", run_mapping_case(cm_mod, "synth_dups_k15", xr5, yr5, 15))
+
+    # ---- 5. spatial self-mapping, d=2 (sklearn picks kd_tree: neighbors/_base.py:622-655), k=90
+    rng = np.random.default_rng(6)
+    coords = rng.uniform(0, 2000, (1000, 2))
+    out = run_mapping_case(cm_mod, "spatial_self_k90", coords, coords, 90, rep_key="spatial", G=24)
+    save("spatial_self_k90", out)
+    coords32 = rng.uniform(0, 2000, (2000, 2)).astype(np.float32)
+    save("spatial32_self_k20", run_mapping_case(cm_mod, "spatial32_self_k20", coords32, coords32, 20, rep_key="spatial", G=24))
+    # d=10 (still kd_tree) two-sample
+    xr6, yr6 = synth(7, 1500, 100, 10, np.float32)
+    save("synth_d10_k15", run_mapping_case(cm_mod, "synth_d10_k15", xr6, yr6, 15))
+
+    # ---- 6. from_distances-style padded input (-1 / inf), via the reference's own ingest (knn.py:296-337)
+    n = 40
+    rng = np.random.default_rng(8)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        deg = int(rng.integers(1, 7))
+        nbrs = rng.choice(np.delete(np.arange(n), i), size=deg, replace=False)
+        for j in nbrs:
+            rows.append(i), cols.append(int(j)), vals.append(float(rng.uniform(0.1, 3.0)))
+    dm = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    d = dict(**csr_parts("dm", dm), **VERSIONS)
+    for inc, tag in ((None, "none"), (True, "true"), (False, "false")):
+        nbf = knn_mod.Neighbors.from_distances(dm, include_self=inc)
+        d[f"idx_{tag}"] = nbf.xx.indices
+        d[f"dist_{tag}"] = nbf.xx.distances
+        for kk in KERNELS:
+            conn = nbf.xx.knn_graph_connectivities(kernel=kk)
+            d.update(csr_parts(f"conn_{kk}_{tag}", conn))
+            cmap = cm_mod.CellMapper(MiniAnnData(X=np.zeros((n, 1), np.float32)))
+            cmap.mapping_matrix = conn
+            d.update(csr_parts(f"map_{kk}_{tag}", cmap.mapping_matrix))
+    save("padded_graph", d)
+
+    # ---- 7. k = 1 identity mapping (tests/model/test_query_to_reference_mapping.py:75-92 restated on synthetic data)
+    xr7, _ = synth(9, 300, 1, 20, np.float32)
+    save("identity_k1", run_mapping_case(cm_mod, "identity_k1", xr7, xr7.copy(), 1, only_yx=False, n_cat=7, G=16))
+
+    for k_, v in saved.items():
+        print(f"{k_:28s} {v/1024:8.1f} KiB")
+    print("total %.2f MiB" % (sum(saved.values()) / 2**20))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Shared parity helpers: tie-aware k-NN comparison and golden-fixture loading."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Tolerances (BASELINE.json north_star): neighbour indices bit-exact for exact brute force
+# (tie groups compared as sets), transferred floats within 1e-5 relative.
+RTOL_FLOAT = 1e-5
+RTOL_DIST = 1e-6
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_csr(g, prefix):
+    shape = tuple(int(v) for v in g[f"{prefix}_shape"])
+    return sp.csr_matrix((g[f"{prefix}_data"], g[f"{prefix}_indices"], g[f"{prefix}_indptr"]), shape=shape)
+
+
+def exact_dist(ref, qry_row, cols, metric):
+    r = ref[cols].astype(np.float64)
+    q = qry_row.astype(np.float64)
+    if metric == "cosine":
+        rn = r / np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-300)
+        qn = q / max(np.linalg.norm(q), 1e-300)
+        return np.clip(1.0 - rn @ qn, 0.0, 2.0)
+    return np.sqrt(((r - q) ** 2).sum(1))
+
+
+def assert_knn_parity(dist, idx, g_dist, g_idx, ref, qry, metric="euclidean", rtol=RTOL_DIST, atol=1e-5,
+                      tie_tol=1e-9):
+    """Indices must be identical, except inside groups of (numerically) tied distances, which are compared
+    as sets; a tie group touching the k-th position may hold any index whose true distance equals the tie value."""
+    dist = np.asarray(dist)
+    idx = np.asarray(idx)
+    assert dist.shape == g_dist.shape and idx.shape == g_idx.shape, (dist.shape, g_dist.shape)
+    if metric == "cosine":
+        # sklearn computes cosine distances in the input dtype (float32 stays float32): rounding-level noise
+        atol = max(atol, 4e-7 if g_dist.dtype == np.float32 else 1e-12)
+        tie_tol = max(tie_tol, 4e-7 if g_dist.dtype == np.float32 else 1e-12)
+    np.testing.assert_allclose(dist, g_dist, rtol=rtol, atol=atol)
+    bad_rows = np.nonzero((idx != g_idx).any(axis=1))[0]
+    k = idx.shape[1]
+    for i in bad_rows:
+        gd = g_dist[i].astype(np.float64)
+        for pos in np.nonzero(idx[i] != g_idx[i])[0]:
+            tol = tie_tol * max(1.0, abs(gd[pos])) if metric != "cosine" else tie_tol
+            grp = np.nonzero(np.abs(gd - gd[pos]) <= tol)[0]
+            ours, theirs = set(idx[i, grp].tolist()), set(g_idx[i, grp].tolist())
+            if ours == theirs:
+                continue
+            assert grp[-1] == k - 1, f"row {i}: index sets differ inside a non-boundary tie group at pos {pos}"
+            extra = np.array(sorted(ours - theirs), dtype=np.int64)
+            de = exact_dist(ref, qry[i], extra, metric)
+            assert np.all(np.abs(de - gd[pos]) <= max(tol, atol)), (
+                f"row {i}: boundary-tie indices {extra} have distances {de}, expected {gd[pos]}")
+    return len(bad_rows)
+
+
+def assert_csr_close(indptr, cols, vals, g_csr, rtol=RTOL_FLOAT, atol=0.0, tie_rows_ok=None):
+    """Compare a CSR triple with a golden scipy CSR (canonical form)."""
+    g = g_csr.tocsr().copy()
+    g.sum_duplicates()
+    g.sort_indices()
+    ours = sp.csr_matrix((np.asarray(vals), np.asarray(cols), np.asarray(indptr)), shape=g.shape)
+    ours.sort_indices()
+    if tie_rows_ok is None or len(tie_rows_ok) == 0:
+        assert np.array_equal(ours.indptr, g.indptr)
+        assert np.array_equal(ours.indices, g.indices)
+        np.testing.assert_allclose(ours.data, g.data, rtol=rtol, atol=atol)
+    else:
+        keep = np.setdiff1d(np.arange(g.shape[0]), np.asarray(tie_rows_ok))
+        a, b = ours[keep], g[keep]
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        np.testing.assert_allclose(a.data, b.data, rtol=rtol, atol=atol)
+
+
+def tie_rows(idx, g_idx):
+    return np.nonzero((np.sort(np.asarray(idx), 1) != np.sort(np.asarray(g_idx), 1)).any(axis=1))[0]
