@@ -1,0 +1,252 @@
+"""ctypes binding of ``libcellmap_hip.so`` (C ABI: ``include/cellmap.h``).
+
+This is the only place the Python layer touches native code.  There is deliberately NO CPU fallback: if the
+shared library or a GPU is missing, every entry point raises ``RuntimeError`` with a build hint, mirroring
+the reference's optional-backend gate (``check.py:39-56``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CELLMAP_HIP_LIB", os.path.join(_HERE, "libcellmap_hip.so"))
+
+BUILD_HINT = (
+    "The 'hip' backend needs libcellmap_hip.so (gfx950 / MI355X). Build it in-tree with "
+    "`make -C cellmapper_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`) on a ROCm >= 7.0 box."
+)
+
+CM_F32, CM_F64 = 0, 1
+METRICS = {"euclidean": 0, "l2": 0, "cosine": 1}
+FORMS = {"auto": 0, "gemm": 1, "direct": 2}
+KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
+CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK = 1, 2
+
+_STATUS_EXC = {1: ValueError, 2: MemoryError, 3: RuntimeError, 4: ValueError, 5: NotImplementedError, 6: RuntimeError}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+EXPORTS = [
+    "cm_version", "cm_device_count", "cm_create", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
+    "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
+    "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
+    "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
+]
+
+
+def load_library():
+    """dlopen the shared library and declare argument types (no GPU call is made here)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found. {BUILD_HINT}")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise RuntimeError(f"Could not load {LIB_PATH}: {e}. {BUILD_HINT}") from e
+        vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+        lib.cm_version.restype = C.c_int
+        lib.cm_device_count.restype = C.c_int
+        lib.cm_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.cm_destroy.argtypes = [vp]
+        lib.cm_last_error.argtypes = [vp]
+        lib.cm_last_error.restype = C.c_char_p
+        lib.cm_set_stream.argtypes = [vp, vp]
+        lib.cm_synchronize.argtypes = [vp]
+        lib.cm_knn_stats.argtypes = [vp, vp]
+        lib.cm_knn.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp]
+        lib.cm_knn_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i32, vp, vp]
+        lib.cm_knn_merge_dev.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
+        lib.cm_mapping_matrix.argtypes = [vp, vp, vp, i64, i32, i64, i32, dbl, vp, vp, vp, vp, vp, vp]
+        lib.cm_dist_moments_dev.argtypes = [vp, vp, vp, i64, vp, vp]
+        lib.cm_kernel_param_dev.argtypes = [vp, vp, i32, vp]
+        lib.cm_weights_dev.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp, dbl, vp, vp, vp, vp]
+        lib.cm_ell_to_csr_dev.argtypes = [vp, vp, vp, vp, i64, i32, vp, vp, vp]
+        lib.cm_label_vote.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, vp, vp]
+        lib.cm_label_vote_dev.argtypes = [vp, vp, vp, vp, i64, vp, i64, i32, vp, vp]
+        lib.cm_spmm_dense.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, i32, vp]
+        lib.cm_spmm_dense_dev.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, i32, vp]
+        lib.cm_spmm_csr_nnz.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp]
+        lib.cm_spmm_csr.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp]
+        lib.cm_map_labels_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, dbl, vp, i32, vp, vp, vp, vp]
+        lib.cm_csr_normalize.argtypes = [vp, vp, vp, i64, vp]
+        for name in EXPORTS:
+            fn = getattr(lib, name)
+            if name not in ("cm_version", "cm_device_count", "cm_last_error"):
+                fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))  # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class Handle:
+    """One backend context = one GPU + stream + workspace (``cm_create`` / ``cm_destroy``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.cm_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self.lib.cm_last_error(None).decode()
+            raise RuntimeError(f"Could not initialise the HIP backend on device {device}: {msg}. {BUILD_HINT}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.cm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.cm_last_error(self._h).decode()
+            raise _STATUS_EXC.get(rc, RuntimeError)(msg or f"cellmap status {rc}")
+
+    def call(self, name: str, *args):
+        self.check(getattr(self.lib, name)(self._h, *args))
+
+    def set_stream(self, stream_ptr):
+        self.call("cm_set_stream", C.c_void_p(int(stream_ptr) if stream_ptr else 0))
+
+    def synchronize(self):
+        self.call("cm_synchronize")
+
+    def knn_stats(self):
+        out = np.zeros(4, np.int64)
+        self.call("cm_knn_stats", _ptr(out))
+        return dict(fallback_queries=int(out[0]), candidates=int(out[1]), ref_splits=int(out[2]), lowd_path=int(out[3]))
+
+    # ------------------------------------------------------------------ host tier (numpy in / numpy out)
+    def knn(self, ref: np.ndarray, qry: np.ndarray, k: int, metric: str = "euclidean", form: str = "auto"):
+        if metric not in METRICS:
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
+        ref = np.ascontiguousarray(ref)
+        qry = np.ascontiguousarray(qry)
+        if ref.ndim != 2 or qry.ndim != 2 or ref.shape[1] != qry.shape[1]:
+            raise ValueError(f"Incompatible representation shapes {ref.shape} and {qry.shape}.")
+        dt = np.float32 if (ref.dtype == np.float32 and qry.dtype == np.float32) else np.float64
+        ref = ref.astype(dt, copy=False)
+        qry = qry.astype(dt, copy=False)
+        if not (np.isfinite(ref).all() and np.isfinite(qry).all()):
+            raise ValueError("Input contains NaN or infinity.")
+        n_ref, d = ref.shape
+        nq = qry.shape[0]
+        k = int(k)
+        out_dt = dt if METRICS[metric] == 1 else np.float64
+        dist = np.empty((nq, k), out_dt)
+        idx = np.empty((nq, k), np.int64)
+        self.call("cm_knn", _ptr(ref), n_ref, _ptr(qry), nq, d, CM_F64 if dt == np.float64 else CM_F32, k,
+                  METRICS[metric], FORMS[form], _ptr(dist), _ptr(idx))
+        return dist, idx
+
+    def mapping_matrix(self, dist, idx, n_ref: int, kernel: str = "gaussian", epsilon: float = 1e-8, want_conn=False):
+        """-> (indptr int64, cols int32, vals float32 normalised, conn float64 | None, param)."""
+        if kernel not in KERNELS:
+            raise ValueError(
+                f"Unknown kernel: {kernel}. Supported kernels are: 'gaussian', 'scarches', 'random', "
+                "'inverse_distance', 'equal'.")
+        dist = np.ascontiguousarray(dist, np.float64)
+        idx = np.ascontiguousarray(idx, np.int64)
+        if dist.shape != idx.shape:
+            raise ValueError("Indices and distances must have the same shape.")
+        nq, k = idx.shape
+        if idx.size and (idx.max() >= n_ref or idx.min() < -1):
+            raise ValueError("column index exceeds matrix dimensions")
+        indptr = np.empty(nq + 1, np.int64)
+        cols = np.empty(nq * k, np.int32)
+        vals = np.empty(nq * k, np.float32)
+        conn = np.empty(nq * k, np.float64) if want_conn else None
+        nnz = C.c_int64(0)
+        param = C.c_double(0.0)
+        self.call("cm_mapping_matrix", _ptr(dist), _ptr(idx), nq, k, int(n_ref), KERNELS[kernel], float(epsilon),
+                  _ptr(indptr), _ptr(cols), _ptr(vals), _ptr(conn), C.byref(nnz), C.byref(param))
+        n = nnz.value
+        return indptr, cols[:n], vals[:n], (conn[:n] if want_conn else None), param.value
+
+    def csr_normalize(self, indptr, data64):
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        data64 = np.ascontiguousarray(data64, np.float64)
+        out = np.empty(data64.shape[0], np.float32)
+        self.call("cm_csr_normalize", _ptr(indptr), _ptr(data64), len(indptr) - 1, _ptr(out))
+        return out
+
+    def label_vote(self, indptr, cols, vals, codes, n_cat: int):
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        cols = np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals, np.float32)
+        codes = np.ascontiguousarray(codes, np.int32)
+        nq = len(indptr) - 1
+        out_code = np.empty(nq, np.int32)
+        out_conf = np.empty(nq, np.float32)
+        self.call("cm_label_vote", _ptr(indptr), _ptr(cols), _ptr(vals), nq, _ptr(codes), len(codes), int(n_cat),
+                  _ptr(out_code), _ptr(out_conf))
+        return out_code, out_conf
+
+    def spmm_dense(self, indptr, cols, vals, B):
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        cols = np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals, np.float32)
+        B = np.asarray(B)
+        squeeze = B.ndim == 1
+        if squeeze:
+            B = B.reshape(-1, 1)
+        if B.dtype != np.float32:
+            B = B.astype(np.float64, copy=False)  # scipy upcast(float32, other) -> float64 for ints / float64
+        B = np.ascontiguousarray(B)
+        nq = len(indptr) - 1
+        out = np.empty((nq, B.shape[1]), B.dtype)
+        self.call("cm_spmm_dense", _ptr(indptr), _ptr(cols), _ptr(vals), nq, _ptr(B), B.shape[0], B.shape[1],
+                  CM_F64 if B.dtype == np.float64 else CM_F32, _ptr(out))
+        return out[:, 0] if squeeze else out
+
+    def spmm_csr(self, indptr, cols, vals, B_indptr, B_cols, B_vals, n_out: int):
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        cols = np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals, np.float32)
+        bi = np.ascontiguousarray(B_indptr, np.int64)
+        bc = np.ascontiguousarray(B_cols, np.int32)
+        bv = np.ascontiguousarray(B_vals, np.float32)
+        nq, n_ref = len(indptr) - 1, len(bi) - 1
+        out_indptr = np.empty(nq + 1, np.int64)
+        self.call("cm_spmm_csr_nnz", _ptr(indptr), _ptr(cols), _ptr(vals), nq, _ptr(bi), _ptr(bc), _ptr(bv), n_ref,
+                  int(n_out), _ptr(out_indptr))
+        nnz = int(out_indptr[nq])
+        out_cols = np.empty(nnz, np.int32)
+        out_vals = np.empty(nnz, np.float32)
+        self.call("cm_spmm_csr", _ptr(indptr), _ptr(cols), _ptr(vals), nq, _ptr(bi), _ptr(bc), _ptr(bv), n_ref,
+                  int(n_out), _ptr(out_indptr), _ptr(out_cols), _ptr(out_vals))
+        return out_indptr, out_cols, out_vals
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_handle() -> Handle:
+    """Process-wide handle on ``CELLMAP_DEVICE`` (default: LOCAL_RANK or 0), created on first use."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            dev = int(os.environ.get("CELLMAP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            _default = Handle(dev)
+        return _default

@@ -1,0 +1,286 @@
+"""``CellMapper``: k-NN based transfer of labels, embeddings and expression -- MI355X-native drop-in.
+
+Keeps the reference's user API (``cellmapper.py:20-637``): ``CellMapper(query, reference=None)``, ``.map(...)``,
+``compute_neighbors`` / ``compute_mapping_matrix`` / ``map_obs`` / ``map_obsm`` / ``map_layers``,
+``mapping_matrix`` (scipy CSR float32, settable), ``query_imputed``, ``load_precomputed_distances``.
+All arithmetic (k-NN, graph kernel, normalisation, label vote, SpMM / SpGEMM) runs in the HIP backend.
+Out of scope here: the ``use_rep=None`` PCA / CCA fallbacks and the evaluation mixin.
+"""
+from __future__ import annotations
+
+import gc
+from typing import Any, Literal
+
+import numpy as np
+import pandas as pd
+from scipy.sparse import csr_matrix, issparse
+
+from . import _native
+from .knn import Neighbors
+from .logging import logger
+from .utils import create_imputed_anndata, get_n_comps
+
+_KERNEL_METHODS = ("gaussian", "scarches", "inverse_distance", "random", "equal")
+
+
+class CellMapper:
+    """Mapping of labels, embeddings, and expression values between reference and query datasets."""
+
+    def __init__(self, query, reference=None) -> None:
+        self.query = query
+        self.reference = reference if reference is not None else query
+        self._is_self_mapping = reference is None
+        if self._is_self_mapping:
+            logger.info("Initialized CellMapper for self-mapping with %d cells.", query.n_obs)
+        else:
+            logger.info("Initialized CellMapper with %d query cells and %d reference cells.", query.n_obs,
+                        self.reference.n_obs)
+        self.knn: Neighbors | None = None
+        self._mapping_matrix: csr_matrix | None = None
+        self.label_transfer_metrics: dict[str, Any] | None = None
+        self.label_transfer_report: pd.DataFrame | None = None
+        self.prediction_postfix: str | None = None
+        self.confidence_postfix: str | None = None
+        self.only_yx: bool | None = None
+        self._query_imputed = None
+        self.expression_transfer_metrics: dict[str, Any] | None = None
+
+    def __repr__(self):
+        q = f"AnnData(n_obs={self.query.n_obs:,}, n_vars={self.query.n_vars:,})"
+        if self._is_self_mapping:
+            return f"CellMapper(self-mapping, data={q})"
+        r = f"AnnData(n_obs={self.reference.n_obs:,}, n_vars={self.reference.n_vars:,})"
+        return f"CellMapper(query={q}, reference={r})"
+
+    # ------------------------------------------------------------------ mapping matrix (K3) ----------
+    @property
+    def mapping_matrix(self):
+        """Row-normalised mapping matrix, scipy CSR float32 of shape ``(n_query, n_reference)``."""
+        return self._mapping_matrix
+
+    @mapping_matrix.setter
+    def mapping_matrix(self, value):
+        self._mapping_matrix = None if value is None else self._validate_and_normalize_mapping_matrix(value)
+
+    def _validate_and_normalize_mapping_matrix(self, mapping_matrix) -> csr_matrix:
+        """Shape check, float64 row normalisation on the GPU, CSR float32 (reference cellmapper.py:99-137)."""
+        expected = (self.query.n_obs, self.reference.n_obs)
+        if tuple(mapping_matrix.shape) != expected:
+            raise ValueError(f"Mapping matrix shape mismatch: expected ({expected[0]}, {expected[1]}), "
+                             f"but got {mapping_matrix.shape}.")
+        m = csr_matrix(mapping_matrix, dtype=np.float64, copy=True)
+        m.sum_duplicates()
+        m.sort_indices()
+        vals = _native.default_handle().csr_normalize(m.indptr, m.data)
+        if m.nnz and bool(np.any(np.add.reduceat(np.abs(m.data), np.minimum(m.indptr[:-1], m.nnz - 1))[np.diff(m.indptr) > 0] == 0)):
+            logger.warning("Some rows in the mapping matrix have a sum of zero. These rows will be left unchanged.")
+        out = csr_matrix((vals, m.indices, m.indptr), shape=m.shape)
+        return out
+
+    # ------------------------------------------------------------------ K0 ---------------------------
+    def compute_neighbors(
+        self,
+        n_neighbors: int = 30,
+        use_rep: str | None = None,
+        n_comps: int | None = None,
+        method: Literal["hip", "sklearn", "pynndescent", "rapids", "faiss"] = "hip",
+        metric: str = "euclidean",
+        only_yx: bool = False,
+        fallback_representation: Literal["fast_cca", "joint_pca"] = "fast_cca",
+        fallback_kwargs: dict[str, Any] | None = None,
+    ) -> None:
+        """Nearest neighbors between reference and query in ``use_rep`` (reference cellmapper.py:139-251).
+
+        ``use_rep="X"`` means ``.X`` (reserved, as upstream); otherwise ``.obsm[use_rep]``; the first
+        ``min(n_comps or 50, d)`` columns are used.  ``use_rep=None`` (automatic PCA / CCA representation) is
+        outside this backend's scope: compute a joint representation first and pass its key.
+        """
+        self.only_yx = only_yx
+        if use_rep is None:
+            raise NotImplementedError(
+                "use_rep=None (automatic joint PCA / fast-CCA representation) is not part of the MI355X backend. "
+                "Pre-compute a joint representation and pass its key via `use_rep`.")
+        if use_rep == "X":
+            xrep, yrep = self.reference.X, self.query.X
+        else:
+            xrep, yrep = self.reference.obsm[use_rep], self.query.obsm[use_rep]
+        if issparse(xrep) or issparse(yrep):
+            xrep = xrep.toarray() if issparse(xrep) else xrep
+            yrep = yrep.toarray() if issparse(yrep) else yrep
+        xrep, yrep = np.asarray(xrep), np.asarray(yrep)
+        n_comps = get_n_comps(n_comps, n_vars=xrep.shape[1])
+        xrep, yrep = xrep[:, :n_comps], yrep[:, :n_comps]
+        self.knn = Neighbors(np.ascontiguousarray(xrep), np.ascontiguousarray(yrep))
+        self.knn.compute_neighbors(n_neighbors=n_neighbors, method=method, metric=metric, only_yx=only_yx)
+
+    # ------------------------------------------------------------------ K1-K3 ------------------------
+    def compute_mapping_matrix(
+        self,
+        method: Literal["jaccard", "gaussian", "scarches", "inverse_distance", "random", "hnoca", "equal"] = "gaussian",
+    ) -> None:
+        """Mapping matrix from the query->reference graph (reference cellmapper.py:253-305)."""
+        if self.knn is None:
+            raise ValueError("Neighbors have not been computed. Call compute_neighbors() first.")
+        logger.info("Computing mapping matrix using method '%s'.", method)
+        if method in ("jaccard", "hnoca"):
+            if self.only_yx:
+                raise ValueError("Jaccard and HNOCa methods require both x and y neighbors to be computed. "
+                                 "Set only_yx=False.")
+            xx, yy, xy, yx = self.knn.get_adjacency_matrices()
+            n_neighbors = self.knn.xx.n_neighbors
+            # shared-neighbour counts; the SpGEMM of 0/1 adjacencies is a "next" row
+            jac = ((yx @ xx.T) + (yy @ xy.T)).tocsr()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if method == "jaccard":
+                    jac.data = jac.data / (4 * n_neighbors - jac.data)
+                else:
+                    jac.data = (jac.data / (2 * n_neighbors - jac.data)) ** 2
+            self.mapping_matrix = jac
+        elif method in _KERNEL_METHODS:
+            if method == "random":
+                self.mapping_matrix = self.knn.yx.knn_graph_connectivities(kernel="random")
+                return
+            yx = self.knn.yx
+            expected = (self.query.n_obs, self.reference.n_obs)
+            if yx.shape != expected:
+                raise ValueError(f"Mapping matrix shape mismatch: expected ({expected[0]}, {expected[1]}), "
+                                 f"but got {yx.shape}.")
+            self._mapping_matrix = yx.normalized_mapping_matrix(kernel=method)
+        else:
+            raise NotImplementedError(f"Method '{method}' is not implemented.")
+
+    # ------------------------------------------------------------------ A1 / A2 / A3 -----------------
+    def _require_mapping(self):
+        if self.mapping_matrix is None:
+            raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
+        m = self._mapping_matrix
+        return m.indptr.astype(np.int64, copy=False), m.indices, m.data
+
+    def map_obsm(self, key: str, prediction_postfix: str = "pred") -> None:
+        """``query.obsm[f"{key}_{postfix}"] = M @ reference.obsm[key]`` (reference cellmapper.py:307-344)."""
+        indptr, cols, vals = self._require_mapping()
+        logger.info("Mapping embeddings for key '%s'.", key)
+        emb = np.asarray(self.reference.obsm[key])
+        out_key = f"{key}_{prediction_postfix}"
+        self.query.obsm[out_key] = _native.default_handle().spmm_dense(indptr, cols, vals, emb)
+        logger.info("Embeddings mapped and stored in query.obsm['%s'].", out_key)
+
+    def map_layers(self, key: str) -> None:
+        """``query_imputed = M @ (reference.X | reference.layers[key])`` (reference cellmapper.py:346-383)."""
+        indptr, cols, vals = self._require_mapping()
+        logger.info("Mapping layer for key '%s'.", key)
+        layer = self.reference.X if key == "X" else self.reference.layers[key]
+        h = _native.default_handle()
+        if issparse(layer):
+            B = csr_matrix(layer)
+            if not B.has_canonical_format:
+                B = B.copy()
+                B.sum_duplicates()
+            oi, oc, ov = h.spmm_csr(indptr, cols, vals, B.indptr, B.indices, B.data.astype(np.float32, copy=False),
+                                    B.shape[1])
+            res = csr_matrix((ov, oc, oi), shape=(len(indptr) - 1, B.shape[1]))
+        else:
+            res = h.spmm_dense(indptr, cols, vals, np.asarray(layer))
+        self.query_imputed = res
+        msg = f"Expression for layer '{key}' mapped and stored in query_imputed.X."
+        if not self._is_self_mapping:
+            msg += (f"\nNote: The feature space matches the reference (n_vars={self.reference.n_vars}), "
+                    f"not the query (n_vars={self.query.n_vars}).")
+        logger.info(msg)
+
+    @property
+    def query_imputed(self):
+        """Imputed query data as an AnnData-like object (or None)."""
+        return self._query_imputed
+
+    @query_imputed.setter
+    def query_imputed(self, value) -> None:
+        if value is None:
+            self._query_imputed = None
+            return
+        self._query_imputed = create_imputed_anndata(expression_data=value, query_adata=self.query,
+                                                     reference_adata=self.reference)
+
+    # ------------------------------------------------------------------ orchestration ----------------
+    def map(
+        self,
+        obs_keys: str | list[str] | None = None,
+        obsm_keys: str | list[str] | None = None,
+        layer_key: str | None = None,
+        n_neighbors: int = 30,
+        use_rep: str | None = None,
+        knn_method: Literal["hip", "sklearn", "pynndescent", "rapids", "faiss"] = "hip",
+        metric: str = "euclidean",
+        only_yx: bool = False,
+        mapping_method: Literal["jaccard", "gaussian", "scarches", "inverse_distance", "random", "hnoca", "equal"] = "gaussian",
+        prediction_postfix: str = "pred",
+    ) -> "CellMapper":
+        """Neighbors -> mapping matrix -> transfer of obs / obsm / layer, in that order (reference :426-491)."""
+        self.compute_neighbors(n_neighbors=n_neighbors, use_rep=use_rep, method=knn_method, metric=metric,
+                               only_yx=only_yx)
+        self.compute_mapping_matrix(method=mapping_method)
+        if obs_keys is not None:
+            for key in ([obs_keys] if isinstance(obs_keys, str) else obs_keys):
+                self.map_obs(key=key, prediction_postfix=prediction_postfix)
+        if obsm_keys is not None:
+            for key in ([obsm_keys] if isinstance(obsm_keys, str) else obsm_keys):
+                self.map_obsm(key=key, prediction_postfix=prediction_postfix)
+        if layer_key is not None:
+            self.map_layers(key=layer_key)
+        if obs_keys is None and obsm_keys is None and layer_key is None:
+            logger.warning("Neither ``obs_keys``, ``obsm_keys`` or ``layer_key`` provided. No labels, embeddings or "
+                           "layers were transferred. Please provide at least one of ``obs_keys``, ``obsm_keys`` or "
+                           "``layer_key``.")
+        return self
+
+    def load_precomputed_distances(self, distances_key: str = "distances", include_self: bool | None = None) -> None:
+        """Use ``query.obsp[distances_key]`` instead of a search (self-mapping only; reference :493-532)."""
+        if not self._is_self_mapping:
+            raise ValueError("load_precomputed_distances is only available in self-mapping mode.")
+        dm = self.query.obsp[distances_key]
+        self.knn = Neighbors.from_distances(dm, include_self=include_self)
+        logger.info("Loaded precomputed distances from '%s' with %d cells and %d neighbors per cell.", distances_key,
+                    dm.shape[0], self.knn.xx.n_neighbors)
+
+    # ------------------------------------------------------------------ A0 / A0n ---------------------
+    def map_obs(self, key: str, prediction_postfix: str = "pred", confidence_postfix: str = "conf") -> None:
+        """Transfer ``reference.obs[key]``: weighted vote for categorical data, weighted mean for numeric
+        (reference cellmapper.py:534-637)."""
+        if self.mapping_matrix is None:
+            raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
+        if key not in self.reference.obs.columns:
+            raise KeyError(f"Key '{key}' not found in reference.obs")
+        self.prediction_postfix = prediction_postfix
+        self.confidence_postfix = confidence_postfix
+        col = self.reference.obs[key]
+        categorical = (isinstance(col.dtype, pd.CategoricalDtype) or pd.api.types.is_object_dtype(col)
+                       or pd.api.types.is_string_dtype(col))
+        if categorical:
+            logger.info("Mapping categorical data for key '%s' using one-hot encoding.", key)
+            self._map_obs_categorical(key, prediction_postfix, confidence_postfix)
+        else:
+            logger.info("Mapping numerical data for key '%s' using direct matrix multiplication.", key)
+            self._map_obs_numerical(key, prediction_postfix)
+
+    def _map_obs_categorical(self, key: str, prediction_postfix: str, confidence_postfix: str) -> None:
+        indptr, cols, vals = self._require_mapping()
+        col = self.reference.obs[key]
+        # sorted unique observed values: the category order sklearn's OneHotEncoder would produce
+        categories, codes = np.unique(np.asarray(col), return_inverse=True)
+        code, conf = _native.default_handle().label_vote(indptr, cols, vals, codes.astype(np.int32), len(categories))
+        pred = pd.Series(data=categories[code], index=self.query.obs_names, dtype=col.dtype)
+        self.query.obs[f"{key}_{prediction_postfix}"] = pred
+        self.query.obs[f"{key}_{confidence_postfix}"] = pd.Series(conf, index=self.query.obs_names)
+        if f"{key}_colors" in self.reference.uns and isinstance(col.dtype, pd.CategoricalDtype):
+            lookup = dict(zip(col.cat.categories, self.reference.uns[f"{key}_colors"], strict=True))
+            self.query.uns[f"{key}_{prediction_postfix}_colors"] = [lookup.get(c, "#383838") for c in pred.cat.categories]
+        logger.info("Categorical data mapped and stored in query.obs['%s'].", f"{key}_{prediction_postfix}")
+        del codes, code, conf
+        gc.collect()
+
+    def _map_obs_numerical(self, key: str, prediction_postfix: str) -> None:
+        indptr, cols, vals = self._require_mapping()
+        values = np.array(self.reference.obs[key]).reshape(-1, 1)
+        mapped = _native.default_handle().spmm_dense(indptr, cols, vals, values)
+        self.query.obs[f"{key}_{prediction_postfix}"] = pd.Series(data=mapped.ravel(), index=self.query.obs_names)
+        logger.info("Numerical data mapped and stored in query.obs['%s'].", f"{key}_{prediction_postfix}")

@@ -1,0 +1,424 @@
+// C ABI of libcellmap_hip.so (declared in include/cellmap.h): handle management, the device tier (thin
+// argument checks around the launchers) and the host tier (H2D, device tier, D2H).
+#include "cm_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace {
+std::mutex g_err_mu;
+std::string g_create_err;
+
+struct DevBuf {  // RAII device allocation used by the host tier
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    cm_status alloc(cm_handle_t h, size_t bytes) {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        return CM_OK;
+    }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+cm_status begin_call(cm_handle_t h, size_t ws_bytes) {
+    if (!h) return CM_E_INVALID;
+    h->err.clear();
+    CM_HIP(h, hipSetDevice(h->device));
+    h->ws_off = 0;
+    return cm_ws_reserve(h, ws_bytes);
+}
+
+cm_status h2d(cm_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return CM_OK;
+}
+cm_status d2h(cm_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    return CM_OK;
+}
+cm_status sync(cm_handle_t h) {
+    CM_HIP(h, hipStreamSynchronize(h->stream));
+    return CM_OK;
+}
+cm_status check_fallback_overflow(cm_handle_t h) {
+    h->knn_stats[0] = h->d_nflag_pinned[0];
+    if (h->d_nflag_pinned[1]) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN exact fallback overflow: more than 2048 reference rows tie within a query's k-th distance");
+    return CM_OK;
+}
+
+// param for the graph kernel from the distances (device), honouring the reference's global statistics
+cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, int kernel, double *d_m3,
+                           double *d_param) {
+    if (kernel != CM_KERNEL_GAUSSIAN && kernel != CM_KERNEL_SCARCHES) return CM_OK;
+    CM_HIP(h, hipMemsetAsync(d_m3, 0, 3 * sizeof(double), h->stream));
+    CM_TRY(cm_moments_run(h, d_dist, d_idx, n, nullptr, d_m3));
+    CM_TRY(cm_param_run(h, d_m3, CM_KERNEL_GAUSSIAN, d_param));  // = mean
+    if (kernel == CM_KERNEL_SCARCHES) {
+        double *d_mean = d_m3 + 3;
+        CM_HIP(h, hipMemcpyAsync(d_mean, d_param, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        CM_HIP(h, hipMemsetAsync(d_m3, 0, 3 * sizeof(double), h->stream));
+        CM_TRY(cm_moments_run(h, d_dist, d_idx, n, d_mean, d_m3));
+        CM_TRY(cm_param_run(h, d_m3, CM_KERNEL_SCARCHES, d_param));
+    }
+    return CM_OK;
+}
+}  // namespace
+
+// ----------------------------------------------------------------------------- workspace ------------
+cm_status cm_ws_reserve(cm_handle_t h, size_t bytes) {
+    bytes = cm_align(bytes) + 4096;
+    if (bytes <= h->ws_cap) return CM_OK;
+    if (h->ws) { CM_HIP(h, hipStreamSynchronize(h->stream)); CM_HIP(h, hipFree(h->ws)); h->ws = nullptr; h->ws_cap = 0; }
+    hipError_t e = hipMalloc((void **)&h->ws, bytes);
+    if (e != hipSuccess) CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes of workspace) failed: %s", bytes, hipGetErrorString(e));
+    h->ws_cap = bytes;
+    return CM_OK;
+}
+void *cm_ws_alloc(cm_handle_t h, size_t bytes) {
+    bytes = cm_align(bytes ? bytes : 1);
+    if (h->ws_off + bytes > h->ws_cap) return nullptr;
+    void *p = h->ws + h->ws_off;
+    h->ws_off += bytes;
+    return p;
+}
+
+extern "C" {
+
+int cm_version(void) { return 100; }
+
+int cm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+cm_status cm_create(int device, cm_handle_t *out) {
+    if (!out) return CM_E_INVALID;
+    *out = nullptr;
+    auto fail = [&](const char *what, hipError_t e) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_err = std::string(what) + ": " + hipGetErrorString(e);
+        return CM_E_HIP;
+    };
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail("no HIP device available (libcellmap_hip needs an AMD GPU; gfx950 code objects)", e);
+    if (device < 0 || device >= n) { std::lock_guard<std::mutex> g(g_err_mu); g_create_err = "device index out of range"; return CM_E_INVALID; }
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    cm_handle_s *h = new (std::nothrow) cm_handle_s();
+    if (!h) return CM_E_NOMEM;
+    h->device = device;
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete h; return fail("hipStreamCreate", e); }
+    h->stream = h->own_stream;
+    if ((e = hipHostMalloc((void **)&h->d_nflag_pinned, 64, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail("hipHostMalloc", e); }
+    memset(h->d_nflag_pinned, 0, 64);
+    *out = h;
+    return CM_OK;
+}
+
+cm_status cm_destroy(cm_handle_t h) {
+    if (!h) return CM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->d_nflag_pinned) (void)hipHostFree(h->d_nflag_pinned);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return CM_OK;
+}
+
+const char *cm_last_error(cm_handle_t h) {
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_create_err.c_str();
+}
+
+cm_status cm_set_stream(cm_handle_t h, void *hip_stream) {
+    if (!h) return CM_E_INVALID;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CM_OK;
+}
+
+cm_status cm_synchronize(cm_handle_t h) {
+    if (!h) return CM_E_INVALID;
+    CM_HIP(h, hipSetDevice(h->device));
+    CM_TRY(sync(h));
+    return check_fallback_overflow(h);
+}
+
+cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]) {
+    if (!h || !out) return CM_E_INVALID;
+    h->knn_stats[0] = h->d_nflag_pinned[0];
+    for (int i = 0; i < 4; ++i) out[i] = h->knn_stats[i];
+    return CM_OK;
+}
+
+// ------------------------------------------------------------------------------ device tier ---------
+cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                     int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
+                     void *d_out_dist, int64_t *d_out_idx) {
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype)));
+    return cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
+}
+
+cm_status cm_knn_merge_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
+                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx) {
+    CM_TRY(begin_call(h, 0));
+    return cm_knn_merge_run(h, d_dist, d_idx, nparts, nq, k, sqrt_out, d_out_dist, d_out_idx);
+}
+
+cm_status cm_dist_moments_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n,
+                              const double *d_center, double *d_out3) {
+    CM_TRY(begin_call(h, 64 * 1024));
+    return cm_moments_run(h, d_dist, d_idx, n, d_center, d_out3);
+}
+
+cm_status cm_kernel_param_dev(cm_handle_t h, const double *d_moments3, int32_t kernel, double *d_param) {
+    CM_TRY(begin_call(h, 0));
+    return cm_param_run(h, d_moments3, kernel, d_param);
+}
+
+cm_status cm_weights_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                         int64_t n_ref, int32_t kernel, const double *d_param, double epsilon, int32_t *d_cols,
+                         float *d_vals, int32_t *d_cnt, double *d_conn) {
+    CM_TRY(begin_call(h, 0));
+    return cm_weights_run(h, d_dist, d_idx, nq, k, n_ref, kernel, d_param, epsilon, d_cols, d_vals, d_cnt, d_conn);
+}
+
+cm_status cm_ell_to_csr_dev(cm_handle_t h, const int32_t *d_cols, const float *d_vals, const int32_t *d_cnt,
+                            int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols, float *d_out_vals) {
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq)));
+    return cm_ell_to_csr_run(h, d_cols, d_vals, nullptr, d_cnt, nq, k, d_indptr, d_out_cols, d_out_vals, nullptr);
+}
+
+cm_status cm_label_vote_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const int32_t *d_codes, int64_t /*n_ref*/, int32_t n_cat, int32_t *d_out_code,
+                            float *d_out_conf) {
+    CM_TRY(begin_call(h, 0));
+    if (!d_indptr) CM_FAIL(h, CM_E_INVALID, "label vote: indptr is NULL");
+    return cm_vote_run(h, d_indptr, d_cols, d_vals, nq, 0, nullptr, d_codes, n_cat, d_out_code, d_out_conf);
+}
+
+cm_status cm_spmm_dense_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const void *d_B, int64_t /*n_ref*/, int64_t n_out, int32_t b_dtype, void *d_out) {
+    CM_TRY(begin_call(h, 0));
+    return cm_spmm_dense_run(h, d_indptr, d_cols, d_vals, nq, d_B, n_out, b_dtype, d_out);
+}
+
+cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                            int32_t dtype, int32_t k, int32_t metric, int32_t kernel, double epsilon,
+                            const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code, float *d_out_conf,
+                            double *d_out_dist, int64_t *d_out_idx) {
+    size_t nk = (size_t)nq * k;
+    size_t extra = cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024;
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype) + extra));
+    if (metric == CM_METRIC_COSINE && dtype == CM_F32)
+        CM_FAIL(h, CM_E_UNSUPPORTED, "fused pipeline: cosine on float32 returns float32 distances; use the staged calls");
+    double *dist = d_out_dist ? d_out_dist : (double *)cm_ws_alloc(h, 8 * nk);
+    int64_t *idx = d_out_idx ? d_out_idx : (int64_t *)cm_ws_alloc(h, 8 * nk);
+    int32_t *cols = (int32_t *)cm_ws_alloc(h, 4 * nk);
+    float *vals = (float *)cm_ws_alloc(h, 4 * nk);
+    int32_t *cnt = (int32_t *)cm_ws_alloc(h, 4 * (size_t)nq);
+    double *m3 = (double *)cm_ws_alloc(h, 64);
+    if (!dist || !idx || !cols || !vals || !cnt || !m3) CM_FAIL(h, CM_E_NOMEM, "fused pipeline: device workspace exhausted");
+    double *param = m3 + 5;
+    CM_TRY(cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, CM_FORM_AUTO, 0, 0, dist, idx));
+    CM_TRY(kernel_param_dev(h, dist, idx, (int64_t)nk, kernel, m3, param));
+    CM_TRY(cm_weights_run(h, dist, idx, nq, k, n_ref, kernel, param, epsilon, cols, vals, cnt, nullptr));
+    return cm_vote_run(h, nullptr, cols, vals, nq, k, cnt, d_codes, n_cat, d_out_code, d_out_conf);
+}
+
+// -------------------------------------------------------------------------------- host tier ---------
+cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d,
+                 int32_t dtype, int32_t k, int32_t metric, int32_t form, void *out_dist, int64_t *out_idx) {
+    if (!h) return CM_E_INVALID;
+    if (dtype != CM_F32 && dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "k-NN: unknown dtype id %d", dtype);
+    if (n_ref < 1 || d < 1 || nq < 0) CM_FAIL(h, CM_E_INVALID, "k-NN: bad shape");
+    if (k < 1 || k > n_ref)
+        CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
+    const size_t es = dtype == CM_F64 ? 8 : 4;
+    const size_t des = (metric == CM_METRIC_COSINE) ? es : 8;  // element size of the returned distances
+    const int64_t QCH = 1 << 21;
+    const int64_t chunk = std::min<int64_t>(nq, QCH);
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, chunk, d, k, dtype)));
+    DevBuf dref, dq, dd, di;
+    CM_TRY(dref.alloc(h, es * n_ref * d));
+    CM_TRY(dq.alloc(h, es * chunk * d));
+    CM_TRY(dd.alloc(h, des * chunk * k));
+    CM_TRY(di.alloc(h, 8 * (size_t)chunk * k));
+    CM_TRY(h2d(h, dref.p, ref, es * n_ref * d));
+    int64_t nflag = 0;
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        int64_t nqc = std::min<int64_t>(chunk, nq - q0);
+        h->ws_off = 0;
+        CM_TRY(h2d(h, dq.p, (const char *)qry + es * q0 * d, es * nqc * d));
+        CM_TRY(cm_knn_run(h, dref.p, n_ref, dq.p, nqc, d, dtype, k, metric, form, 0, 0, dd.p, di.as<int64_t>()));
+        CM_TRY(d2h(h, (char *)out_dist + des * q0 * k, dd.p, des * nqc * k));
+        CM_TRY(d2h(h, out_idx + q0 * k, di.p, 8 * (size_t)nqc * k));
+        CM_TRY(sync(h));
+        CM_TRY(check_fallback_overflow(h));
+        nflag += h->knn_stats[0];
+    }
+    h->knn_stats[0] = nflag;
+    h->d_nflag_pinned[0] = (int32_t)std::min<int64_t>(nflag, 0x7fffffff);
+    return CM_OK;
+}
+
+cm_status cm_mapping_matrix(cm_handle_t h, const double *dist, const int64_t *idx, int64_t nq, int32_t k,
+                            int64_t n_ref, int32_t kernel, double epsilon, int64_t *out_indptr, int32_t *out_cols,
+                            float *out_vals, double *out_conn, int64_t *out_nnz, double *out_param) {
+    if (!h) return CM_E_INVALID;
+    if (nq < 0 || k < 1) CM_FAIL(h, CM_E_INVALID, "mapping matrix: bad shape");
+    if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
+    size_t nk = (size_t)nq * k;
+    CM_TRY(begin_call(h, 64 * 1024 + cm_scan_ws_bytes(nq)));
+    DevBuf dd, di, dcols, dvals, dconn, dcnt, dptr, ocols, ovals, oconn, dm;
+    CM_TRY(dd.alloc(h, 8 * nk)); CM_TRY(di.alloc(h, 8 * nk));
+    CM_TRY(dcols.alloc(h, 4 * nk)); CM_TRY(dvals.alloc(h, 4 * nk)); CM_TRY(dcnt.alloc(h, 4 * (size_t)nq));
+    CM_TRY(dptr.alloc(h, 8 * ((size_t)nq + 1))); CM_TRY(ocols.alloc(h, 4 * nk)); CM_TRY(ovals.alloc(h, 4 * nk));
+    CM_TRY(dm.alloc(h, 64));
+    if (out_conn) { CM_TRY(dconn.alloc(h, 8 * nk)); CM_TRY(oconn.alloc(h, 8 * nk)); }
+    CM_TRY(h2d(h, dd.p, dist, 8 * nk));
+    CM_TRY(h2d(h, di.p, idx, 8 * nk));
+    double *m3 = dm.as<double>(), *param = m3 + 5;
+    CM_HIP(h, hipMemsetAsync(m3, 0, 64, h->stream));
+    CM_TRY(cm_moments_run(h, dd.as<double>(), di.as<int64_t>(), (int64_t)nk, nullptr, m3));
+    double hm[3] = {0, 0, 0};
+    CM_TRY(d2h(h, hm, m3, 24));
+    CM_TRY(sync(h));
+    if (!(hm[2] > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
+    CM_TRY(kernel_param_dev(h, dd.as<double>(), di.as<int64_t>(), (int64_t)nk, kernel, m3, param));
+    CM_TRY(cm_weights_run(h, dd.as<double>(), di.as<int64_t>(), nq, k, n_ref, kernel, param, epsilon, dcols.as<int32_t>(),
+                          dvals.as<float>(), dcnt.as<int32_t>(), out_conn ? dconn.as<double>() : nullptr));
+    CM_TRY(cm_ell_to_csr_run(h, dcols.as<int32_t>(), dvals.as<float>(), out_conn ? dconn.as<double>() : nullptr,
+                             dcnt.as<int32_t>(), nq, k, dptr.as<int64_t>(), ocols.as<int32_t>(), ovals.as<float>(),
+                             out_conn ? oconn.as<double>() : nullptr));
+    CM_TRY(d2h(h, out_indptr, dptr.p, 8 * ((size_t)nq + 1)));
+    double hp = 0.0;
+    CM_TRY(d2h(h, &hp, param, 8));
+    CM_TRY(sync(h));
+    int64_t nnz = out_indptr[nq];
+    CM_TRY(d2h(h, out_cols, ocols.p, 4 * (size_t)nnz));
+    CM_TRY(d2h(h, out_vals, ovals.p, 4 * (size_t)nnz));
+    if (out_conn) CM_TRY(d2h(h, out_conn, oconn.p, 8 * (size_t)nnz));
+    CM_TRY(sync(h));
+    if (out_nnz) *out_nnz = nnz;
+    if (out_param) *out_param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? hp : 0.0;
+    return CM_OK;
+}
+
+cm_status cm_csr_normalize(cm_handle_t h, const int64_t *indptr, const double *data, int64_t nq, float *out_vals) {
+    if (!h) return CM_E_INVALID;
+    CM_TRY(begin_call(h, 0));
+    int64_t nnz = indptr[nq];
+    DevBuf dp, dd, dout;
+    CM_TRY(dp.alloc(h, 8 * ((size_t)nq + 1))); CM_TRY(dd.alloc(h, 8 * (size_t)nnz)); CM_TRY(dout.alloc(h, 4 * (size_t)nnz));
+    CM_TRY(h2d(h, dp.p, indptr, 8 * ((size_t)nq + 1)));
+    CM_TRY(h2d(h, dd.p, data, 8 * (size_t)nnz));
+    CM_TRY(cm_csr_normalize_run(h, dp.as<int64_t>(), dd.as<double>(), nq, dout.as<float>()));
+    CM_TRY(d2h(h, out_vals, dout.p, 4 * (size_t)nnz));
+    return sync(h);
+}
+
+static cm_status upload_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                            DevBuf &dp, DevBuf &dc, DevBuf &dv) {
+    int64_t nnz = indptr[nq];
+    CM_TRY(dp.alloc(h, 8 * ((size_t)nq + 1))); CM_TRY(dc.alloc(h, 4 * (size_t)nnz)); CM_TRY(dv.alloc(h, 4 * (size_t)nnz));
+    CM_TRY(h2d(h, dp.p, indptr, 8 * ((size_t)nq + 1)));
+    CM_TRY(h2d(h, dc.p, cols, 4 * (size_t)nnz));
+    CM_TRY(h2d(h, dv.p, vals, 4 * (size_t)nnz));
+    return CM_OK;
+}
+
+cm_status cm_label_vote(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                        const int32_t *codes, int64_t n_ref, int32_t n_cat, int32_t *out_code, float *out_conf) {
+    if (!h) return CM_E_INVALID;
+    CM_TRY(begin_call(h, 0));
+    DevBuf dp, dc, dv, dcodes, ocode, oconf;
+    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));
+    CM_TRY(dcodes.alloc(h, 4 * (size_t)n_ref)); CM_TRY(ocode.alloc(h, 4 * (size_t)nq)); CM_TRY(oconf.alloc(h, 4 * (size_t)nq));
+    CM_TRY(h2d(h, dcodes.p, codes, 4 * (size_t)n_ref));
+    CM_TRY(cm_vote_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, 0, nullptr, dcodes.as<int32_t>(), n_cat,
+                       ocode.as<int32_t>(), oconf.as<float>()));
+    CM_TRY(d2h(h, out_code, ocode.p, 4 * (size_t)nq));
+    CM_TRY(d2h(h, out_conf, oconf.p, 4 * (size_t)nq));
+    return sync(h);
+}
+
+cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                        const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
+    if (!h) return CM_E_INVALID;
+    if (b_dtype != CM_F32 && b_dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
+    if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm: payload has no columns");
+    CM_TRY(begin_call(h, 0));
+    const size_t es = b_dtype == CM_F64 ? 8 : 4;
+    DevBuf dp, dc, dv, dB, dO;
+    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));
+    // column slabs keep payload + output within a fixed HBM budget (wide .X payloads exceed it)
+    size_t free_b = 0, total_b = 0;
+    CM_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = free_b / 2;
+    int64_t cw = n_out;
+    size_t per_col = es * ((size_t)n_ref + (size_t)nq);
+    if (per_col * (size_t)n_out > budget) {
+        cw = (int64_t)(budget / per_col);
+        cw = cw / 64 * 64;
+        if (cw < 64) CM_FAIL(h, CM_E_NOMEM, "spmm: not enough device memory for a 64-column slab");
+    }
+    CM_TRY(dB.alloc(h, es * (size_t)n_ref * cw));
+    CM_TRY(dO.alloc(h, es * (size_t)nq * cw));
+    for (int64_t c0 = 0; c0 < n_out; c0 += cw) {
+        int64_t w = std::min<int64_t>(cw, n_out - c0);
+        CM_HIP(h, hipMemcpy2DAsync(dB.p, es * w, (const char *)B + es * c0, es * n_out, es * w, (size_t)n_ref, hipMemcpyHostToDevice, h->stream));
+        CM_TRY(cm_spmm_dense_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, dB.p, w, b_dtype, dO.p));
+        if (nq) CM_HIP(h, hipMemcpy2DAsync((char *)out + es * c0, es * n_out, dO.p, es * w, es * w, (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+        CM_TRY(sync(h));
+    }
+    return CM_OK;
+}
+
+static cm_status spmm_csr_common(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                                 const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                                 int64_t n_out, int64_t *out_indptr_w, const int64_t *out_indptr_r, int32_t *out_cols,
+                                 float *out_vals) {
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + 4096));
+    DevBuf dp, dc, dv, bp, bc, bv, rn, op, oc, ov;
+    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));
+    CM_TRY(upload_csr(h, b_indptr, b_cols, b_vals, n_ref, bp, bc, bv));
+    CM_TRY(op.alloc(h, 8 * ((size_t)nq + 1)));
+    if (out_indptr_w) {
+        CM_TRY(rn.alloc(h, 4 * (size_t)nq));
+        CM_TRY(cm_spmm_csr_count_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, bp.as<int64_t>(), bc.as<int32_t>(),
+                                     bv.as<float>(), n_out, rn.as<int32_t>()));
+        CM_TRY(cm_exclusive_scan_i32_to_i64(h, rn.as<int32_t>(), nq, op.as<int64_t>()));
+        CM_TRY(d2h(h, out_indptr_w, op.p, 8 * ((size_t)nq + 1)));
+        return sync(h);
+    }
+    int64_t nnz = out_indptr_r[nq];
+    CM_TRY(oc.alloc(h, 4 * (size_t)nnz)); CM_TRY(ov.alloc(h, 4 * (size_t)nnz));
+    CM_TRY(h2d(h, op.p, out_indptr_r, 8 * ((size_t)nq + 1)));
+    CM_TRY(cm_spmm_csr_fill_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, bp.as<int64_t>(), bc.as<int32_t>(),
+                                bv.as<float>(), n_out, op.as<int64_t>(), oc.as<int32_t>(), ov.as<float>()));
+    CM_TRY(d2h(h, out_cols, oc.p, 4 * (size_t)nnz));
+    CM_TRY(d2h(h, out_vals, ov.p, 4 * (size_t)nnz));
+    return sync(h);
+}
+
+cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                          const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                          int64_t n_out, int64_t *out_indptr) {
+    if (!h) return CM_E_INVALID;
+    return spmm_csr_common(h, indptr, cols, vals, nq, b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr, nullptr, nullptr, nullptr);
+}
+
+cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                      const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                      int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
+    if (!h) return CM_E_INVALID;
+    return spmm_csr_common(h, indptr, cols, vals, nq, b_indptr, b_cols, b_vals, n_ref, n_out, nullptr, out_indptr, out_cols, out_vals);
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal declarations shared by the translation units of libcellmap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "cellmap.h"
+
+struct cm_handle_s {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only device workspace, carved by a bump allocator that is reset at the start of every API call
+    char *ws = nullptr;
+    size_t ws_cap = 0;
+    size_t ws_off = 0;
+    int64_t knn_stats[4] = {0, 0, 0, 0};
+    int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
+};
+
+#define CM_FAIL(h, code, ...)                                   \
+    do {                                                        \
+        char _b[512];                                           \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+        if (h) (h)->err = _b;                                   \
+        return (code);                                          \
+    } while (0)
+
+#define CM_HIP(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) CM_FAIL(h, CM_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define CM_TRY(expr)                     \
+    do {                                 \
+        cm_status _s = (expr);           \
+        if (_s != CM_OK) return _s;      \
+    } while (0)
+
+// ---- workspace ----
+cm_status cm_ws_reserve(cm_handle_t h, size_t bytes);  // may reallocate: call BEFORE launching work that uses ws
+void *cm_ws_alloc(cm_handle_t h, size_t bytes);         // 256-B aligned carve; nullptr when exhausted
+static inline size_t cm_align(size_t b) { return (b + 255) & ~size_t(255); }
+
+// ---- k-NN (knn_kernels.hip) ----
+size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype);
+cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                     int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
+                     void *d_out_dist, int64_t *d_out_idx);
+cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
+                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx);
+
+// ---- graph kernel + transfers (graph_kernels.hip) ----
+cm_status cm_moments_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, const double *d_center,
+                         double *d_out3);
+cm_status cm_param_run(cm_handle_t h, const double *d_m3, int32_t kernel, double *d_param);
+cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                         int64_t n_ref, int32_t kernel, const double *d_param, double eps, int32_t *d_cols,
+                         float *d_vals, int32_t *d_cnt, double *d_conn);
+cm_status cm_ell_to_csr_run(cm_handle_t h, const int32_t *d_cols, const float *d_vals, const double *d_conn,
+                            const int32_t *d_cnt, int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols,
+                            float *d_out_vals, double *d_out_conn);
+size_t cm_scan_ws_bytes(int64_t n);
+cm_status cm_csr_normalize_run(cm_handle_t h, const int64_t *d_indptr, const double *d_data, int64_t nq, float *d_out);
+cm_status cm_vote_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                      int32_t ell_k, const int32_t *d_cnt, const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code,
+                      float *d_out_conf);
+cm_status cm_spmm_dense_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const void *d_B, int64_t n_out, int32_t b_dtype, void *d_out);
+cm_status cm_spmm_csr_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                int64_t n_out, int32_t *d_row_nnz);
+cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                               int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                               int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals);
+cm_status cm_exclusive_scan_i32_to_i64(cm_handle_t h, const int32_t *d_in, int64_t n, int64_t *d_out /* n+1 */);

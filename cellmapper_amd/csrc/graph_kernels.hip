@@ -1,0 +1,534 @@
+// K1-K3 (graph kernel -> canonical, row-normalised mapping matrix) and A0/A0n/A1/A2/A3 (transfers) on gfx950.
+// These stages are HBM-bound byte/gather work: coalesced row reads, wave-per-row cooperative sorting in LDS,
+// 16-byte vector loads for the wide SpMM.  No MFMA here on purpose.
+//
+// Reference interfaces replaced (under /root/reference/src/cellmapper/model/):
+//   knn.py:68-77,166-226  validity mask + kernel values        knn.py:79-111  COO -> canonical CSR
+//   cellmapper.py:99-137  row normalisation + float32 cast     cellmapper.py:589-623  one-hot vote
+//   cellmapper.py:338,373,628  mapping_matrix @ dense          cellmapper.py:373  mapping_matrix @ sparse
+#include "cm_internal.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int W_KMAX = 1024;  // max neighbours per row handled by the wave-per-row kernels
+constexpr int RED_BLOCKS = 512;
+
+// ------------------------------------------------------------------ moments of the valid distances ---
+__global__ __launch_bounds__(256) void moments_partial(const double *__restrict__ dist, const int64_t *__restrict__ idx,
+                                                        int64_t n, const double *__restrict__ center,
+                                                        double *__restrict__ partial /*[gridDim.x][3]*/) {
+    const double c = center ? *center : 0.0;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        double v = dist[t];
+        if (idx[t] != -1 && isfinite(v)) { double u = v - c; s1 += u; s2 += u * u; cnt += 1.0; }
+    }
+    __shared__ double sh[3][256];
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 3 + 0] = sh[0][0];
+        partial[blockIdx.x * 3 + 1] = sh[1][0];
+        partial[blockIdx.x * 3 + 2] = sh[2][0];
+    }
+}
+__global__ void moments_final(const double *__restrict__ partial, int nb, double *__restrict__ out3) {
+    if (threadIdx.x < 3) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partial[b * 3 + threadIdx.x];
+        out3[threadIdx.x] += s;
+    }
+}
+__global__ void param_kernel(const double *__restrict__ m, int kernel, double *__restrict__ param) {
+    if (threadIdx.x == 0) {
+        double p = 0.0;
+        if (kernel == CM_KERNEL_GAUSSIAN) p = m[0] / m[2];  // global mean distance (knn.py:196)
+        else if (kernel == CM_KERNEL_SCARCHES) { double sd = sqrt(m[1] / m[2]); double r = 2.0 / sd; p = r * r; }  // knn.py:206-207
+        if (!(m[2] > 0.0)) p = NAN;
+        *param = p;
+    }
+}
+
+// ------------------------------------------------------------------ K1-K3 fused, one wave per row ----
+__global__ __launch_bounds__(256) void weights_rows(const double *__restrict__ dist, const int64_t *__restrict__ idx,
+                                                     int64_t nq, int k, int kernel, const double *__restrict__ param_p,
+                                                     double eps, int32_t *__restrict__ cols, float *__restrict__ vals,
+                                                     int32_t *__restrict__ cntp, double *__restrict__ conn) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // per wave: wv[k] double, sw[k] double, col[k] int, scol[k] int, head[k] int
+    unsigned char *base = smem + (size_t)w * ((size_t)k * (8 + 8 + 4 + 4 + 4) + 32);
+    base = (unsigned char *)(((uintptr_t)base + 15) & ~(uintptr_t)15);
+    double *wv = (double *)base;
+    double *sw = wv + k;
+    int *col = (int *)(sw + k);
+    int *scol = col + k;
+    int *head = scol + k;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= nq) return;
+    const double param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? *param_p : 0.0;
+    const double two_s2 = 2.0 * (param * param);
+    for (int t = lane; t < k; t += 64) {
+        double dd = dist[i * k + t];
+        int64_t c = idx[i * k + t];
+        bool valid = (c != -1) && isfinite(dd);
+        double wt = 0.0;
+        if (valid) {
+            switch (kernel) {
+            case CM_KERNEL_GAUSSIAN: wt = exp(-(dd * dd) / two_s2); break;
+            case CM_KERNEL_SCARCHES: wt = exp(-dd / param); break;
+            case CM_KERNEL_INVERSE_DISTANCE: wt = 1.0 / (dd + eps); break;
+            case CM_KERNEL_IDENTITY: wt = dd; break;
+            default: wt = 1.0;
+            }
+        }
+        wv[t] = wt;
+        col[t] = valid ? (int)c : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // head = first occurrence of its column (duplicates are summed into it, like COO -> CSR does)
+    for (int t = lane; t < k; t += 64) {
+        int c = col[t];
+        int hd = c >= 0;
+        for (int j = 0; j < t && hd; ++j) hd = (col[j] != c);
+        head[t] = hd;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int myheads = 0;
+    for (int t = lane; t < k; t += 64) {
+        if (!head[t]) continue;
+        int c = col[t];
+        int rk = 0;
+        double sum = 0.0;
+        for (int j = 0; j < k; ++j) {
+            int cj = col[j];
+            rk += (head[j] && cj < c) ? 1 : 0;
+            if (cj == c) sum += wv[j];
+        }
+        scol[rk] = c;
+        sw[rk] = sum;
+        ++myheads;
+    }
+    int m = myheads;
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    __builtin_amdgcn_wave_barrier();
+    // float64 row sum in CSR order (scipy csr_matvec against ones), zero -> 1, multiply by the reciprocal
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) s = s + sw[r] * 1.0;
+    if (s == 0.0) s = 1.0;
+    const double rinv = 1.0 / s;
+    for (int r = lane; r < k; r += 64) {
+        bool on = r < m;
+        cols[i * k + r] = on ? scol[r] : 0;
+        vals[i * k + r] = on ? (float)(sw[r] * rinv) : 0.f;
+        if (conn) conn[i * k + r] = on ? sw[r] : 0.0;
+    }
+    if (lane == 0) cntp[i] = m;
+}
+
+// K3 for a caller-supplied canonical CSR: one thread per row (rows are short), float64 sequential sum.
+__global__ void csr_normalize_rows(const int64_t *__restrict__ indptr, const double *__restrict__ data, int64_t nq,
+                                   float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    double s = 0.0;
+    for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) s = s + data[p] * 1.0;
+    if (s == 0.0) s = 1.0;
+    const double r = 1.0 / s;
+    for (int64_t p = indptr[i]; p < indptr[i + 1]; ++p) out[p] = (float)(data[p] * r);
+}
+
+// ------------------------------------------------------------------ exclusive scan int32 -> int64 ----
+constexpr int SCAN_CHUNK = 1024;
+__global__ __launch_bounds__(256) void scan_block_sums(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ bsum) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    int64_t s = 0;
+    for (int t = threadIdx.x; t < SCAN_CHUNK; t += 256) { int64_t p = base + t; if (p < n) s += in[p]; }
+    __shared__ int64_t sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+__global__ void scan_of_sums(int64_t *bsum, int64_t nb) {  // single thread: nb = n/1024 is small
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t b = 0; b < nb; ++b) { int64_t v = bsum[b]; bsum[b] = run; run += v; }
+    }
+}
+__global__ __launch_bounds__(256) void scan_apply(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ bsum,
+                                                   int64_t *__restrict__ out /*n+1*/) {
+    __shared__ int64_t sh[256];
+    int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    int64_t v[4];
+    int64_t loc = 0;
+    for (int e = 0; e < 4; ++e) { int64_t p = base + threadIdx.x * 4 + e; v[e] = p < n ? in[p] : 0; loc += v[e]; }
+    sh[threadIdx.x] = loc;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        int64_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int64_t run = bsum[blockIdx.x] + sh[threadIdx.x] - loc;
+    for (int e = 0; e < 4; ++e) {
+        int64_t p = base + threadIdx.x * 4 + e;
+        if (p < n) out[p] = run;
+        run += v[e];
+        if (p == n - 1) out[n] = run;
+    }
+}
+__global__ void ell_compact(const int32_t *__restrict__ cols, const float *__restrict__ vals, const double *__restrict__ conn,
+                            const int32_t *__restrict__ cnt, const int64_t *__restrict__ indptr, int64_t nq, int k,
+                            int32_t *__restrict__ ocols, float *__restrict__ ovals, double *__restrict__ oconn) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nq * k) return;
+    int64_t i = g / k;
+    int t = (int)(g - i * k);
+    if (t < cnt[i]) {
+        int64_t o = indptr[i] + t;
+        ocols[o] = cols[g];
+        if (ovals) ovals[o] = vals[g];
+        if (oconn) oconn[o] = conn[g];
+    }
+}
+
+// ------------------------------------------------------------------ A0: label vote, one wave per row -
+// Per category float32 sums accumulated in ascending column order (scipy csr_matmat), zero sums dropped,
+// argmax ties -> lowest category code (scipy sparse argmax on sorted columns), empty -> (0, 0).
+__global__ __launch_bounds__(256) void vote_rows(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+                                                  const float *__restrict__ vals, int64_t nq, int ell_k,
+                                                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ codes,
+                                                  int32_t *__restrict__ out_code, float *__restrict__ out_conf) {
+    __shared__ int s_code[4][W_KMAX];
+    __shared__ float s_w[4][W_KMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= nq) return;
+    int64_t p0;
+    int n;
+    if (indptr) { p0 = indptr[i]; n = (int)(indptr[i + 1] - p0); }
+    else { p0 = i * ell_k; n = cnt ? cnt[i] : ell_k; }
+    float best = 0.f;
+    int bcode = 0x7fffffff;
+    if (n <= W_KMAX) {
+        for (int t = lane; t < n; t += 64) { s_code[w][t] = codes[cols[p0 + t]]; s_w[w][t] = vals[p0 + t]; }
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < n; t += 64) {
+            int c = s_code[w][t];
+            bool first = true;
+            for (int j = 0; j < t && first; ++j) first = (s_code[w][j] != c);
+            if (!first) continue;
+            float sum = 0.f;
+            for (int j = t; j < n; ++j) if (s_code[w][j] == c) sum = sum + s_w[w][j] * 1.0f;
+            if (sum != 0.f && (sum > best || (sum == best && c < bcode) || bcode == 0x7fffffff)) { best = sum; bcode = c; }
+        }
+    } else {  // long rows (user-supplied mapping matrices): same algorithm straight from global memory
+        for (int t = lane; t < n; t += 64) {
+            int c = codes[cols[p0 + t]];
+            bool first = true;
+            for (int j = 0; j < t && first; ++j) first = (codes[cols[p0 + j]] != c);
+            if (!first) continue;
+            float sum = 0.f;
+            for (int j = t; j < n; ++j) if (codes[cols[p0 + j]] == c) sum = sum + vals[p0 + j] * 1.0f;
+            if (sum != 0.f && (sum > best || (sum == best && c < bcode) || bcode == 0x7fffffff)) { best = sum; bcode = c; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o);
+        int oc = __shfl_xor(bcode, o);
+        bool take = (oc != 0x7fffffff) && (bcode == 0x7fffffff || ob > best || (ob == best && oc < bcode));
+        if (take) { best = ob; bcode = oc; }
+    }
+    if (lane == 0) {
+        bool found = bcode != 0x7fffffff && best > 0.f;
+        out_code[i] = found ? bcode : 0;
+        out_conf[i] = found ? best : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ A1/A2: CSR x dense ---------------
+// Wide rows: one workgroup per (query row, 256*VEC-column chunk); every lane owns VEC consecutive output columns,
+// reads the k gathered reference rows with 16-byte loads (row index / weight are wave-uniform scalars) and
+// accumulates in ascending column order, multiply and add rounded separately (scipy csr_matvecs order).
+template <typename T, int VEC>
+struct VecT;
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecT<float, 1> { typedef float type; };
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<double, 1> { typedef double type; };
+
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b);
+template <> __device__ __forceinline__ float mul_rn<float>(float a, float b) { return __fmul_rn(a, b); }
+template <> __device__ __forceinline__ double mul_rn<double>(double a, double b) { return __dmul_rn(a, b); }
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b);
+template <> __device__ __forceinline__ float add_rn<float>(float a, float b) { return __fadd_rn(a, b); }
+template <> __device__ __forceinline__ double add_rn<double>(double a, double b) { return __dadd_rn(a, b); }
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void spmm_wide(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+                                                  const float *__restrict__ vals, int64_t nq, const T *__restrict__ B,
+                                                  int64_t n_out, T *__restrict__ out, int64_t nchunks) {
+    typedef typename VecT<T, VEC>::type V;
+    const int64_t tiles = nq * nchunks;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row = tile / nchunks;
+        const int64_t c0 = (tile - row * nchunks) * (256 * VEC) + (int64_t)threadIdx.x * VEC;
+        if (c0 >= n_out) continue;
+        const int64_t p0 = indptr[row], p1 = indptr[row + 1];
+        T acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = (T)0;
+        int64_t p = p0;
+        for (; p + 4 <= p1; p += 4) {
+            V x[4];
+            T a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = (T)vals[p + u];
+                x[u] = *reinterpret_cast<const V *>(B + (int64_t)cols[p + u] * n_out + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T *xv = reinterpret_cast<const T *>(&x[u]);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = add_rn<T>(acc[v], mul_rn<T>(a[u], xv[v]));
+            }
+        }
+        for (; p < p1; ++p) {
+            T a = (T)vals[p];
+            V x = *reinterpret_cast<const V *>(B + (int64_t)cols[p] * n_out + c0);
+            const T *xv = reinterpret_cast<const T *>(&x);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = add_rn<T>(acc[v], mul_rn<T>(a, xv[v]));
+        }
+        V o;
+        T *ov = reinterpret_cast<T *>(&o);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov[v] = acc[v];
+        __builtin_nontemporal_store(o, reinterpret_cast<V *>(out + row * n_out + c0));
+    }
+}
+
+// Narrow payloads (obsm with a few columns, numeric obs with one): one thread per output element.
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_narrow(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+                                                    const float *__restrict__ vals, int64_t nq, const T *__restrict__ B,
+                                                    int64_t n_out, T *__restrict__ out) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nq * n_out) return;
+    int64_t row = g / n_out, c = g - row * n_out;
+    T acc = (T)0;
+    for (int64_t p = indptr[row]; p < indptr[row + 1]; ++p)
+        acc = add_rn<T>(acc, mul_rn<T>((T)vals[p], B[(int64_t)cols[p] * n_out + c]));
+    out[g] = acc;
+}
+
+// ------------------------------------------------------------------ A3: CSR x CSR --------------------
+// One workgroup per output row with a dense float32 accumulator in LDS (n_out <= 36864 columns) plus a
+// "touched" bitmap.  Neighbour rows are applied one after the other (ascending column order of the mapping
+// matrix) so every output element sees the same sequence of float32 adds as scipy's csr_matmat.
+// MODE 0: count non-zeros per row.  MODE 1: emit (column, value) pairs in ascending column order.
+template <int MODE>
+__global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+                                                    const float *__restrict__ vals, int64_t nq,
+                                                    const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
+                                                    const float *__restrict__ bvals, int n_out, int32_t *__restrict__ row_nnz,
+                                                    const int64_t *__restrict__ out_indptr, int32_t *__restrict__ ocols,
+                                                    float *__restrict__ ovals) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *acc = reinterpret_cast<float *>(smem);  // [n_out]
+    int *scan = reinterpret_cast<int *>(acc + ((n_out + 3) & ~3));  // [blockDim.x]
+    const int nt = blockDim.x, tid = threadIdx.x;
+    for (int64_t row = blockIdx.x; row < nq; row += gridDim.x) {
+        for (int c = tid; c < n_out; c += nt) acc[c] = 0.f;
+        __syncthreads();
+        for (int64_t p = indptr[row]; p < indptr[row + 1]; ++p) {
+            const float a = vals[p];
+            const int64_t j = cols[p];
+            for (int64_t t = bptr[j] + tid; t < bptr[j + 1]; t += nt) {
+                int c = bcols[t];
+                acc[c] = __fadd_rn(acc[c], __fmul_rn(a, bvals[t]));
+            }
+            __syncthreads();
+        }
+        // ordered compaction: each thread owns a contiguous column range
+        const int per = (n_out + nt - 1) / nt;
+        const int cb = tid * per, ce = (cb + per < n_out) ? cb + per : n_out;
+        int mine = 0;
+        for (int c = cb; c < ce; ++c) mine += (acc[c] != 0.f) ? 1 : 0;
+        scan[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < nt; o <<= 1) {
+            int add = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        if (MODE == 0) {
+            if (tid == nt - 1) row_nnz[row] = scan[tid];
+        } else {
+            int64_t o = out_indptr[row] + scan[tid] - mine;
+            for (int c = cb; c < ce; ++c) {
+                float v = acc[c];
+                if (v != 0.f) { ocols[o] = c; ovals[o] = v; ++o; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ======================================================================= host-side launchers ==========
+cm_status cm_moments_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, const double *d_center,
+                         double *d_out3) {
+    double *partial = (double *)cm_ws_alloc(h, sizeof(double) * 3 * RED_BLOCKS);
+    if (!partial) CM_FAIL(h, CM_E_NOMEM, "moments: device workspace exhausted");
+    hipLaunchKernelGGL(moments_partial, dim3(RED_BLOCKS), dim3(256), 0, h->stream, d_dist, d_idx, n, d_center, partial);
+    hipLaunchKernelGGL(moments_final, dim3(1), dim3(64), 0, h->stream, partial, RED_BLOCKS, d_out3);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_param_run(cm_handle_t h, const double *d_m3, int32_t kernel, double *d_param) {
+    hipLaunchKernelGGL(param_kernel, dim3(1), dim3(64), 0, h->stream, d_m3, kernel, d_param);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                         int64_t /*n_ref*/, int32_t kernel, const double *d_param, double eps, int32_t *d_cols,
+                         float *d_vals, int32_t *d_cnt, double *d_conn) {
+    if (k < 1 || k > W_KMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "mapping matrix: %d neighbours per row exceeds the supported %d", k, W_KMAX);
+    if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
+    if (nq == 0) return CM_OK;
+    size_t lds = 4 * ((size_t)k * 28 + 32) + 16;
+    hipLaunchKernelGGL(weights_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
+                       d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_csr_normalize_run(cm_handle_t h, const int64_t *d_indptr, const double *d_data, int64_t nq, float *d_out) {
+    if (nq == 0) return CM_OK;
+    hipLaunchKernelGGL(csr_normalize_rows, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, d_indptr, d_data, nq, d_out);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+size_t cm_scan_ws_bytes(int64_t n) { return cm_align(sizeof(int64_t) * ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1)); }
+
+cm_status cm_exclusive_scan_i32_to_i64(cm_handle_t h, const int32_t *d_in, int64_t n, int64_t *d_out) {
+    if (n == 0) { CM_HIP(h, hipMemsetAsync(d_out, 0, sizeof(int64_t), h->stream)); return CM_OK; }
+    int64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    int64_t *bsum = (int64_t *)cm_ws_alloc(h, sizeof(int64_t) * (nb + 1));
+    if (!bsum) CM_FAIL(h, CM_E_NOMEM, "scan: device workspace exhausted");
+    hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(256), 0, h->stream, d_in, n, bsum);
+    hipLaunchKernelGGL(scan_of_sums, dim3(1), dim3(64), 0, h->stream, bsum, nb);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(256), 0, h->stream, d_in, n, bsum, d_out);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_ell_to_csr_run(cm_handle_t h, const int32_t *d_cols, const float *d_vals, const double *d_conn,
+                            const int32_t *d_cnt, int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols,
+                            float *d_out_vals, double *d_out_conn) {
+    CM_TRY(cm_exclusive_scan_i32_to_i64(h, d_cnt, nq, d_indptr));
+    if (nq == 0) return CM_OK;
+    int64_t tot = nq * k;
+    hipLaunchKernelGGL(ell_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_cols, d_vals, d_conn, d_cnt,
+                       d_indptr, nq, k, d_out_cols, d_out_vals, d_out_conn);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_vote_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                      int32_t ell_k, const int32_t *d_cnt, const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code,
+                      float *d_out_conf) {
+    if (n_cat < 1) CM_FAIL(h, CM_E_INVALID, "label vote: n_cat must be >= 1");
+    if (nq == 0) return CM_OK;
+    hipLaunchKernelGGL(vote_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_cols, d_vals, nq, ell_k,
+                       d_cnt, d_codes, d_out_code, d_out_conf);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+template <typename T>
+static cm_status spmm_dense_t(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                              const T *B, int64_t n_out, T *out) {
+    constexpr int VEC = 16 / sizeof(T);
+    hipStream_t st = h->stream;
+    bool aligned = (n_out % VEC == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (n_out >= 64 && aligned) {
+        int64_t nchunks = (n_out + 256 * VEC - 1) / (256 * VEC);
+        int64_t tiles = nq * nchunks;
+        unsigned grid = (unsigned)(tiles < 256 * 32 ? tiles : 256 * 32);
+        hipLaunchKernelGGL((spmm_wide<T, VEC>), dim3(grid), dim3(256), 0, st, d_indptr, d_cols, d_vals, nq, B, n_out, out, nchunks);
+    } else if (n_out >= 256) {
+        int64_t nchunks = (n_out + 255) / 256;
+        int64_t tiles = nq * nchunks;
+        unsigned grid = (unsigned)(tiles < 256 * 32 ? tiles : 256 * 32);
+        hipLaunchKernelGGL((spmm_wide<T, 1>), dim3(grid), dim3(256), 0, st, d_indptr, d_cols, d_vals, nq, B, n_out, out, nchunks);
+    } else {
+        int64_t tot = nq * n_out;
+        hipLaunchKernelGGL(spmm_narrow<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_indptr, d_cols, d_vals, nq, B, n_out, out);
+    }
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_spmm_dense_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const void *d_B, int64_t n_out, int32_t b_dtype, void *d_out) {
+    if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm: payload has no columns");
+    if (nq == 0) return CM_OK;
+    if (nq * n_out / 256 > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm: output too large for one launch; tile the call");
+    if (b_dtype == CM_F32) return spmm_dense_t<float>(h, d_indptr, d_cols, d_vals, nq, (const float *)d_B, n_out, (float *)d_out);
+    if (b_dtype == CM_F64) return spmm_dense_t<double>(h, d_indptr, d_cols, d_vals, nq, (const double *)d_B, n_out, (double *)d_out);
+    CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
+}
+
+static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                               int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_out,
+                               int32_t *d_row_nnz, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
+    if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm_csr: payload has no columns");
+    if (n_out > 36864) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: %lld output columns exceed the on-chip accumulator (36864); split the columns", (long long)n_out);
+    if (nq == 0) return CM_OK;
+    size_t lds = (((size_t)n_out + 3) & ~size_t(3)) * 4 + 512 * 4;
+    unsigned grid = (unsigned)(nq < 2048 ? nq : 2048);
+    if (mode == 0) {
+        auto kern = spgemm_rows<0>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
+                           (int)n_out, d_row_nnz, d_out_indptr, d_out_cols, d_out_vals);
+    } else {
+        auto kern = spgemm_rows<1>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
+                           (int)n_out, d_row_nnz, d_out_indptr, d_out_cols, d_out_vals);
+    }
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_spmm_csr_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                int64_t n_out, int32_t *d_row_nnz) {
+    return spgemm_launch(h, 0, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, d_row_nnz, nullptr, nullptr, nullptr);
+}
+cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                               int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                               int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
+    return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, d_out_cols, d_out_vals);
+}

@@ -1,0 +1,396 @@
+// K0: exact k-NN on gfx950 -- row preparation, phase-2 float64 re-rank + certification, exact fallback, shard merge,
+// and the host-side orchestration (cm_knn_run).  Phase 1 (MFMA candidate filter) lives in knn_phase1.h.
+//
+// Reference interface replaced: Neighbors.compute_neighbors, sklearn branch, /root/reference/src/cellmapper/model/
+// knn.py:428-440 (sklearn.neighbors.NearestNeighbors(...).fit(xrep).kneighbors(yrep)).
+#include "cm_internal.h"
+#include "knn_phase1.h"
+
+#include <math.h>
+
+// phase-1 instantiation groups (knn_phase1_inst.hip)
+#define CM_DECL_P1(g)                                                                                                  \
+    bool cm_p1_launch_g##g(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds, const float *Q, const float *R,       \
+                           int tps, int n_tiles, int Kc, int C, int *cand, float *cthr, cm_status *st);
+CM_DECL_P1(0) CM_DECL_P1(1) CM_DECL_P1(2) CM_DECL_P1(3)
+
+namespace {
+
+constexpr int kSupportedKP[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 84, 100, 132, 164, 196, 260};
+constexpr int RR_NCMAX = 1024;  // max candidates per query handled by the re-rank / merge kernels
+constexpr int RR_DMAX = 260;
+constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
+constexpr int FB_CAP = 2048;    // fallback collection capacity per query
+constexpr int FB_BLOCKS = 1024;
+
+int pick_kp(int d) {
+    for (int kp : kSupportedKP)
+        if (kp >= d + 1) return kp;
+    return -1;
+}
+
+// ------------------------------------------------------------------ row preparation -----------------
+// X [n,d] (T) -> P [n_pad, KP] float32:  reference rows [-2y, |y|^2, 0..], query rows [q, 1, 0..];
+// cosine: rows are L2-normalised first (zero rows stay zero, like sklearn.preprocessing.normalize).
+// Padded reference rows carry |y|^2 = +inf so they never pass a threshold.
+// gmax[0] = max |y|^2, gmax[1] = max |y| over reference rows (float bits; valid for non-negative floats).
+template <typename T>
+__global__ void prep_rows(const T *__restrict__ X, int64_t n, int d, int KP, int64_t n_pad, int is_ref, int metric,
+                          float *__restrict__ P, float *__restrict__ rownorm, unsigned *__restrict__ gmax) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float yn_f = 0.f;
+    if (i < n_pad) {
+        float *out = P + i * KP;
+        if (i < n) {
+            const T *x = X + i * d;
+            double scale = 1.0;
+            if (metric == CM_METRIC_COSINE) {
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+                double nrm = sqrt(s);
+                scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
+            }
+            double s2 = 0.0;
+            for (int c = 0; c < d; ++c) {
+                float v = (float)((double)x[c] * scale);
+                s2 = fma((double)v, (double)v, s2);
+                out[c] = is_ref ? -2.0f * v : v;
+            }
+            yn_f = (float)s2;
+            out[d] = is_ref ? yn_f : 1.0f;
+            for (int c = d + 1; c < KP; ++c) out[c] = 0.f;
+            if (rownorm) rownorm[i] = sqrtf(yn_f) * 1.0000002f;
+        } else {
+            for (int c = 0; c < KP; ++c) out[c] = 0.f;
+            out[d] = is_ref ? INFINITY : 1.0f;
+            yn_f = 0.f;
+        }
+    }
+    if (is_ref && gmax) {
+        float m = yn_f;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&gmax[0], __float_as_uint(m));
+            atomicMax(&gmax[1], __float_as_uint(sqrtf(m) * 1.0000002f));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact float64 pair value --------
+// The value that orders neighbours and (after sqrt) is returned, following sklearn's arithmetic exactly as the
+// CPU oracle restates it (oracle/cm_oracle.c: cmo_knn_euclidean):
+//   GEMM form   : (|q|^2 + (-2 * q.y)) + |y|^2 with fma chains, clamped at 0      (EuclideanArgKmin)
+//   DIRECT form : sum_j (q_j - y_j)^2, multiply and add rounded separately        (KDTree rdist)
+//   cosine      : clip(1 - q.y / (|q| |y|), 0, 2)                                 (pairwise cosine_distances)
+template <typename T>
+__device__ __forceinline__ double pair_value(const double *__restrict__ q, double xn, const T *__restrict__ y, int d,
+                                             int metric, int form) {
+    if (metric == CM_METRIC_COSINE) {
+        double dot = 0.0, yn = 0.0;
+        for (int c = 0; c < d; ++c) { double v = (double)y[c]; dot = fma(q[c], v, dot); yn = fma(v, v, yn); }
+        double nx = sqrt(xn), ny = sqrt(yn);
+        if (!(nx > 0.0)) nx = 1.0;
+        if (!(ny > 0.0)) ny = 1.0;
+        double s = 1.0 - dot / (nx * ny);
+        return s < 0.0 ? 0.0 : (s > 2.0 ? 2.0 : s);
+    }
+    if (form == CM_FORM_DIRECT) {
+        double acc = 0.0;
+        for (int c = 0; c < d; ++c) { double t = q[c] - (double)y[c]; acc = __dadd_rn(acc, __dmul_rn(t, t)); }
+        return acc;
+    }
+    double dot = 0.0, yn = 0.0;
+    for (int c = 0; c < d; ++c) { double v = (double)y[c]; dot = fma(q[c], v, dot); yn = fma(v, v, yn); }
+    double d2 = __dadd_rn(__dadd_rn(xn, __dmul_rn(-2.0, dot)), yn);
+    return d2 > 0.0 ? d2 : 0.0;
+}
+
+__device__ __forceinline__ bool pair_before(double va, int64_t ia, double vb, int64_t ib) {
+    return va < vb || (va == vb && ia < ib);
+}
+
+// ------------------------------------------------------------------ phase 2: re-rank + certify ------
+// One wave per query.  Candidates of all reference splits are re-evaluated in float64, ranked by (value, index),
+// the first k are written out.  Certification: every non-candidate has fp32 ranking value >= tau; with the fp32
+// error bound eps_q, the float64 top-k is provably the exact one iff  s_k < tau - eps_q  (s = d^2 - |q|^2).
+template <typename T>
+__global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, const T *__restrict__ qry, int64_t nq,
+                                                   int d, const int *__restrict__ cand, const float *__restrict__ cthr,
+                                                   int S, int Kc, int k, int metric, int form,
+                                                   const float *__restrict__ qnorm, const unsigned *__restrict__ gmax,
+                                                   float c_eps, int64_t idx_offset, int flags,
+                                                   void *__restrict__ out_dist, int64_t *__restrict__ out_idx,
+                                                   int *__restrict__ flag_list, int *__restrict__ flag_cnt,
+                                                   double *__restrict__ bound) {
+    __shared__ double s_q[4][RR_DMAX];
+    __shared__ double s_v[4][RR_NCMAX];
+    __shared__ int s_i[4][RR_NCMAX];
+    __shared__ double s_kth[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= nq) return;
+    double *q = s_q[w];
+    for (int c = lane; c < d; c += 64) q[c] = (double)qry[i * d + c];
+    __builtin_amdgcn_wave_barrier();
+    double xn = 0.0;
+    for (int c = 0; c < d; ++c) xn = fma(q[c], q[c], xn);
+    const int nc = S * Kc;
+    const int *cq = cand + i * nc;
+    for (int s = lane; s < nc; s += 64) {
+        int j = cq[s];
+        double v = INFINITY;
+        if (j >= 0) v = pair_value<T>(q, xn, ref + (int64_t)j * d, d, metric, form);
+        s_v[w][s] = v;
+        s_i[w][s] = j >= 0 ? j : 0x7fffffff;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < nc; s += 64) {
+        double v = s_v[w][s];
+        int id = s_i[w][s];
+        int rk = 0;
+        for (int j = 0; j < nc; ++j) rk += pair_before(s_v[w][j], s_i[w][j], v, id) ? 1 : 0;
+        if (rk < k) {
+            double o = v;
+            if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
+            if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+            else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
+            out_idx[i * k + rk] = (int64_t)id + idx_offset;
+            if (rk == k - 1) s_kth[w] = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double kth = s_kth[w];
+        float tau = INFINITY;
+        for (int s = 0; s < S; ++s) tau = fminf(tau, cthr[i * S + s]);
+        bool certified = true;
+        if (tau < INFINITY) {
+            double sk = (metric == CM_METRIC_COSINE) ? (2.0 * kth - 1.0) : (kth - xn);
+            double ymax2 = (double)__uint_as_float(gmax[0]), ymax = (double)__uint_as_float(gmax[1]);
+            double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30);
+            certified = sk < (double)tau - eps;
+        }
+        if (!certified || (flags & CM_KNN_FORCE_FALLBACK)) {
+            int pos = atomicAdd(flag_cnt, 1);
+            flag_list[pos] = (int)i;
+            bound[i] = kth;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact fallback ------------------
+// For queries that could not be certified: one workgroup scans ALL reference rows in float64 (same arithmetic as
+// phase 2), collects every row whose value is <= the k-th candidate value (an upper bound of the true k-th),
+// ranks the collection and overwrites the query's output row.  Rare by construction.
+template <typename T>
+__global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ ref, int64_t n_ref,
+                                                           const T *__restrict__ qry, int d, int k, int metric, int form,
+                                                           int64_t idx_offset, int flags, const int *__restrict__ flag_list,
+                                                           const int *__restrict__ flag_cnt,
+                                                           const double *__restrict__ bound, void *__restrict__ out_dist,
+                                                           int64_t *__restrict__ out_idx, int *__restrict__ overflow) {
+    __shared__ double s_q[RR_DMAX];
+    __shared__ double s_v[FB_CAP];
+    __shared__ int s_i[FB_CAP];
+    __shared__ int s_n;
+    const int nf = *flag_cnt;
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int64_t i = flag_list[f];
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        double xn = 0.0;
+        for (int c = 0; c < d; ++c) xn = fma(s_q[c], s_q[c], xn);
+        const double b = bound[i];
+        for (int64_t j = threadIdx.x; j < n_ref; j += blockDim.x) {
+            double v = pair_value<T>(s_q, xn, ref + j * d, d, metric, form);
+            if (v <= b) {
+                int pos = atomicAdd(&s_n, 1);
+                if (pos < FB_CAP) { s_v[pos] = v; s_i[pos] = (int)j; }
+            }
+        }
+        __syncthreads();
+        int m = s_n;
+        if (m > FB_CAP) { m = FB_CAP; if (threadIdx.x == 0) atomicExch(overflow, 1); }
+        for (int s = threadIdx.x; s < m; s += blockDim.x) {
+            double v = s_v[s];
+            int id = s_i[s];
+            int rk = 0;
+            for (int j = 0; j < m; ++j) rk += pair_before(s_v[j], s_i[j], v, id) ? 1 : 0;
+            if (rk < k) {
+                double o = v;
+                if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
+                if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+                else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
+                out_idx[i * k + rk] = (int64_t)id + idx_offset;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ shard merge ---------------------
+// parts [nparts, nq, k] -> the k smallest by (distance, global index).  One wave per query.
+__global__ __launch_bounds__(256) void knn_merge(const double *__restrict__ pd, const int64_t *__restrict__ pi,
+                                                  int nparts, int64_t nq, int k, int sqrt_out,
+                                                  double *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
+    __shared__ double s_v[4][MG_NCMAX];
+    __shared__ int64_t s_i[4][MG_NCMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= nq) return;
+    const int nc = nparts * k;
+    for (int s = lane; s < nc; s += 64) {
+        int p = s / k, t = s - p * k;
+        s_v[w][s] = pd[((int64_t)p * nq + i) * k + t];
+        s_i[w][s] = pi[((int64_t)p * nq + i) * k + t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < nc; s += 64) {
+        double v = s_v[w][s];
+        int64_t id = s_i[w][s];
+        int rk = 0;
+        for (int j = 0; j < nc; ++j) rk += pair_before(s_v[w][j], s_i[w][j], v, id) ? 1 : 0;
+        if (rk < k) {
+            out_dist[i * k + rk] = sqrt_out ? sqrt(v) : v;
+            out_idx[i * k + rk] = id;
+        }
+    }
+}
+
+__global__ void zero_words(unsigned *p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+struct KnnPlan {
+    int KP, NW, Kc, C, S, n_tiles, tps;
+    int64_t nq_pad, nref_pad;
+    size_t lds;
+};
+
+cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan *p) {
+    p->KP = pick_kp(d);
+    if (p->KP < 0) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of 259", d);
+    int slack = k / 4 > 8 ? k / 4 : 8;
+    p->Kc = k + slack;
+    p->C = p->Kc + 64;
+    p->NW = 0;
+    for (int nw : {4, 2, 1}) {
+        if (cmk::phase1_lds_bytes(p->KP, nw, p->C) <= 160 * 1024) { p->NW = nw; break; }
+    }
+    if (!p->NW) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip candidate buffers", k);
+    p->lds = cmk::phase1_lds_bytes(p->KP, p->NW, p->C);
+    int QB = p->NW * 32;
+    p->nq_pad = (nq + QB - 1) / QB * QB;
+    p->n_tiles = (int)((n_ref + cmk::BR - 1) / cmk::BR);
+    p->nref_pad = (int64_t)p->n_tiles * cmk::BR;
+    int64_t nqb = p->nq_pad / QB;
+    int S = 1;
+    if (nqb < 256) {
+        S = (int)((512 + nqb - 1) / nqb);
+        if (S > 8) S = 8;
+        if (S > p->n_tiles) S = p->n_tiles;
+        while (S > 1 && S * p->Kc > RR_NCMAX) --S;
+        if (S < 1) S = 1;
+    }
+    p->tps = (p->n_tiles + S - 1) / S;
+    p->S = (p->n_tiles + p->tps - 1) / p->tps;
+    if (p->S * p->Kc > RR_NCMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large (max %d)", k, RR_NCMAX - 64);
+    return CM_OK;
+}
+
+template <typename T>
+cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
+                    int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
+    KnnPlan p;
+    CM_TRY(make_plan(h, n_ref, nq, d, k, &p));
+    float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
+    float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
+    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad);
+    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * p.nq_pad * p.S * p.Kc);
+    float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.S);
+    int *flag_list = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
+    double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
+    unsigned *words = (unsigned *)cm_ws_alloc(h, 64);  // [0..1] gmax, [2] flag count, [3] overflow
+    if (!Rp || !Qp || !qnorm || !cand || !cthr || !flag_list || !bound || !words)
+        CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    hipStream_t st = h->stream;
+    hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 16);
+    {
+        int bs = 256;
+        hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                           p.KP, p.nref_pad, 1, metric, Rp, (float *)nullptr, words);
+        hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, p.KP,
+                           p.nq_pad, 0, metric, Qp, qnorm, (unsigned *)nullptr);
+    }
+    CM_HIP(h, hipGetLastError());
+    {
+        dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
+        cm_status s = CM_E_INTERNAL;
+        bool ok = cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+                  cm_p1_launch_g1(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+                  cm_p1_launch_g2(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+                  cm_p1_launch_g3(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s);
+        if (!ok) CM_FAIL(h, CM_E_INTERNAL, "k-NN: no phase-1 instantiation for KP=%d", p.KP);
+        CM_TRY(s);
+    }
+    // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
+    float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
+    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
+                       p.S, p.Kc, k, metric, form, qnorm, words, c_eps, idx_offset, flags, d_out_dist, d_out_idx,
+                       flag_list, (int *)(words + 2), bound);
+    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
+                       idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
+                       (int *)(words + 3));
+    CM_HIP(h, hipGetLastError());
+    // stats mirror (read back lazily by cm_knn_stats after a synchronize)
+    CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    h->knn_stats[1] = p.Kc;
+    h->knn_stats[2] = p.S;
+    h->knn_stats[3] = 0;
+    return CM_OK;
+}
+
+}  // namespace
+
+size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t /*dtype*/) {
+    int KP = pick_kp(d);
+    if (KP < 0) KP = 260;
+    int slack = k / 4 > 8 ? k / 4 : 8;
+    int Kc = k + slack;
+    int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
+    int64_t nq_pad = (nq + 127) / 128 * 128;
+    size_t b = 0;
+    b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP) + cm_align(4 * nq_pad);
+    b += cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) + cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1));
+    return b + 4096;
+}
+
+cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                     int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
+                     void *d_out_dist, int64_t *d_out_idx) {
+    if (n_ref < 1 || nq < 0 || d < 1) CM_FAIL(h, CM_E_INVALID, "k-NN: empty reference or bad shape (n_ref=%lld, d=%d)", (long long)n_ref, d);
+    if (k < 1 || k > n_ref)
+        CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
+    if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
+    if (d > RR_DMAX - 1) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, RR_DMAX - 1);
+    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE) CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
+    if (form == CM_FORM_AUTO) form = (d > 15 || k >= n_ref / 2) ? CM_FORM_GEMM : CM_FORM_DIRECT;
+    if (nq == 0) return CM_OK;
+    if (dtype == CM_F32)
+        return knn_run_t<float>(h, (const float *)d_ref, n_ref, (const float *)d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
+    if (dtype == CM_F64)
+        return knn_run_t<double>(h, (const double *)d_ref, n_ref, (const double *)d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
+    CM_FAIL(h, CM_E_INVALID, "k-NN: unknown dtype id %d", dtype);
+}
+
+cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
+                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx) {
+    if (nparts < 1 || k < 1 || nparts * k > MG_NCMAX) CM_FAIL(h, CM_E_INVALID, "merge: nparts*k = %d exceeds %d", nparts * k, MG_NCMAX);
+    if (nq == 0) return CM_OK;
+    hipLaunchKernelGGL(knn_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_dist, d_idx, nparts, nq, k,
+                       sqrt_out, d_out_dist, d_out_idx);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}

