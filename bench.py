@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the CellMapper hot path on MI355X: query cells/s end-to-end (k-NN + kernel + label transfer).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched through
+``torch.distributed.run``, one rank per GPU over RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 1.5 M query x 1.5 M reference cells, synthetic float32 standard-normal
+embeddings d=50, k=30, Gaussian kernel, one 20-class label column.  Inputs are resident in HBM when the timed
+region starts; outputs (labels, confidences) stay in HBM.  A "step" is one full pass of the hot path over all
+queries.  At N>1 the REFERENCE rows are sharded across ranks and per-shard top-k lists are merged after one RCCL
+exchange (strong scaling: the total work is fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nq", type=int, default=1_500_000)
+    ap.add_argument("--nref", type=int, default=1_500_000)
+    ap.add_argument("--d", type=int, default=50)
+    ap.add_argument("--k", type=int, default=30)
+    ap.add_argument("--ncat", type=int, default=20)
+    ap.add_argument("--kernel", default="gaussian")
+    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
+    ap.add_argument("--cpu-sample", type=int, default=768, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--check", type=int, default=256, help="queries verified against the CPU oracle (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
+    """Time the CPU oracle (plain C restatement of the reference path, OpenMP over host cores) on a bounded sample:
+    `n_sample` queries against the FULL reference; brute force is linear in the number of queries."""
+    from oracle import oracle as orc
+
+    orc.build()
+    q = qry_np[:n_sample]
+    t0 = time.perf_counter()
+    out = orc.run_path(ref_np, q, k, kernel=kernel, labels=codes_np, n_cat=ncat)
+    dt = time.perf_counter() - t0
+    return dict(value=n_sample / dt, unit="query cells/s", cores=orc.num_threads(), kind="port",
+                sample=f"{n_sample} queries x {ref_np.shape[0]} reference rows, d={ref_np.shape[1]}, k={k}, "
+                       f"k-NN+kernel+label vote, {dt:.2f} s"), out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cellmapper_amd.device import DevicePipeline
+    from cellmapper_amd.sharded import HipOps, shard_bounds, sharded_map_labels
+
+    pipe = DevicePipeline(local_rank)
+    pipe.h.set_profiling(True)
+
+    # synthetic inputs: standard-normal float32 embeddings drawn separately for reference and query
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    ref_full_rows = a.nref
+    lo, hi = shard_bounds(ref_full_rows, world, rank)
+    # every rank draws the same stream and keeps its shard, so the global problem is independent of N
+    ref = torch.empty((hi - lo, a.d), dtype=torch.float32, device=dev)
+    chunk = 250_000
+    for c0 in range(0, ref_full_rows, chunk):
+        c1 = min(ref_full_rows, c0 + chunk)
+        blk = torch.randn((c1 - c0, a.d), generator=g, dtype=torch.float32, device=dev)
+        s0, s1 = max(c0, lo), min(c1, hi)
+        if s0 < s1:
+            ref[s0 - lo:s1 - lo] = blk[s0 - c0:s1 - c0]
+    qry = torch.randn((a.nq, a.d), generator=g, dtype=torch.float32, device=dev)
+    codes = torch.randint(0, a.ncat, (ref_full_rows,), generator=g, device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+
+    ops = HipOps(pipe)
+    torch.cuda.set_stream(pipe.stream)  # library kernels, torch ops and RCCL collectives share one stream
+
+    def step():
+        if world == 1:
+            return pipe.map_labels(ref, qry, a.k, codes, a.ncat, kernel=a.kernel)
+        code, conf, _, _, _ = sharded_map_labels(ops, dist, ref, lo, ref_full_rows, qry, a.k, codes, a.ncat,
+                                                 kernel=a.kernel, exchange=a.exchange)
+        return code, conf
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    p1_ms = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-kernel time of the dominant kernel, from HIP events recorded on the launch stream (last step)
+    stages = pipe.h.stage_times()
+    p1_ms.append(stages["phase1_mfma"])
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    fb = pipe.h.knn_stats()
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = a.nq * a.steps / elapsed
+        flops = 2.0 * a.nq * (hi - lo) * a.d  # algorithmic flops of the distance contraction on this rank's shard
+        p1 = float(np.mean(p1_ms))
+        achieved = flops / (p1 * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "phase1_hbm_traffic.json")
+        if os.path.exists(tfile) and world == 1 and a.nq == 1_500_000 and a.nref == 1_500_000:
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "query cells/s end-to-end (k-NN+kernel+transfer)",
+            "value": value, "unit": "query cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.kernel} kernel, "
+                                   f"{a.ncat}-class label transfer (BASELINE configs[1]); reference rows sharded over "
+                                   f"{world} GPU(s), exchange={a.exchange if world > 1 else 'none'}",
+                       "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
+                       "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"]},
+            "roofline": {"bound": "mfma", "kernel": "knn_cand_mfma (fp32 MFMA distance GEMM + fused top-k filter)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel_ms": p1,
+                         "flops_per_launch": flops},
+            "stage_ms_last_step": stages,
+        }
+    # parity spot check + CPU baseline on rank 0 at N=1 only (bounded sample, outside the timed region)
+    if rank == 0 and world == 1 and (a.cpu_sample > 0 or a.check > 0):
+        ref_np = ref.cpu().numpy()
+        qry_np = qry.cpu().numpy()
+        codes_np = codes.cpu().numpy()
+        ns = max(a.cpu_sample, a.check)
+        cb, o = cpu_baseline(ref_np, qry_np, codes_np, a.k, a.ncat, a.kernel, ns)
+        if a.cpu_sample > 0:
+            result["cpu_baseline"] = cb
+        if a.check > 0:
+            code, conf, d_gpu, i_gpu = pipe.map_labels(ref, qry[:ns].contiguous(), a.k, codes, a.ncat, kernel=a.kernel,
+                                                      want_graph=True)
+            torch.cuda.synchronize()
+            idx_ok = bool(np.array_equal(i_gpu.cpu().numpy(), o["idx"]))
+            dist_ok = bool(np.array_equal(d_gpu.cpu().numpy(), o["dist"]))
+            lab = float((code.cpu().numpy() == o["pred_code"]).mean())
+            result["parity_check"] = {"queries": ns, "indices_bit_exact": idx_ok, "distances_bit_exact": dist_ok,
+                                      "label_agreement": lab}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

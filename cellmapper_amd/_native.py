@@ -36,6 +36,7 @@ EXPORTS = [
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
+    "cm_set_profiling", "cm_stage_times",
 ]
 
 
@@ -77,6 +78,8 @@ def load_library():
         lib.cm_spmm_csr.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.cm_map_labels_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, dbl, vp, i32, vp, vp, vp, vp]
         lib.cm_csr_normalize.argtypes = [vp, vp, vp, i64, vp]
+        lib.cm_set_profiling.argtypes = [vp, i32]
+        lib.cm_stage_times.argtypes = [vp, vp]
         for name in EXPORTS:
             fn = getattr(lib, name)
             if name not in ("cm_version", "cm_device_count", "cm_last_error"):
@@ -130,6 +133,16 @@ class Handle:
 
     def synchronize(self):
         self.call("cm_synchronize")
+
+    def set_profiling(self, on: bool):
+        self.call("cm_set_profiling", int(bool(on)))
+
+    def stage_times(self):
+        """Milliseconds per stage of the last device-tier call (HIP events on the handle's stream)."""
+        out = np.zeros(8, np.float32)
+        self.call("cm_stage_times", _ptr(out))
+        names = ["", "prep", "phase1_mfma", "rerank", "fallback", "stats", "weights", "vote"]
+        return {names[i]: float(out[i]) for i in range(1, 8)}
 
     def knn_stats(self):
         out = np.zeros(4, np.int64)

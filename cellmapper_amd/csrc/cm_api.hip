@@ -67,6 +67,12 @@ cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d
 }
 }  // namespace
 
+void cm_mark(cm_handle_t h, int which) {
+    if (!h->profiling || which < 0 || which >= CM_N_STAGE_EVENTS) return;
+    if (!h->ev[which] && hipEventCreate(&h->ev[which]) != hipSuccess) return;
+    if (hipEventRecord(h->ev[which], h->stream) == hipSuccess) h->ev_set[which] = true;
+}
+
 // ----------------------------------------------------------------------------- workspace ------------
 cm_status cm_ws_reserve(cm_handle_t h, size_t bytes) {
     bytes = cm_align(bytes) + 4096;
@@ -125,6 +131,7 @@ cm_status cm_destroy(cm_handle_t h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
     if (h->d_nflag_pinned) (void)hipHostFree(h->d_nflag_pinned);
+    for (int i = 0; i < CM_N_STAGE_EVENTS; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return CM_OK;
@@ -139,6 +146,27 @@ const char *cm_last_error(cm_handle_t h) {
 cm_status cm_set_stream(cm_handle_t h, void *hip_stream) {
     if (!h) return CM_E_INVALID;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CM_OK;
+}
+
+cm_status cm_set_profiling(cm_handle_t h, int32_t on) {
+    if (!h) return CM_E_INVALID;
+    h->profiling = on != 0;
+    for (int i = 0; i < CM_N_STAGE_EVENTS; ++i) h->ev_set[i] = false;
+    return CM_OK;
+}
+
+cm_status cm_stage_times(cm_handle_t h, float out_ms[8]) {
+    if (!h || !out_ms) return CM_E_INVALID;
+    CM_HIP(h, hipSetDevice(h->device));
+    CM_HIP(h, hipStreamSynchronize(h->stream));
+    int prev = -1;
+    for (int i = 0; i < CM_N_STAGE_EVENTS; ++i) {
+        out_ms[i] = 0.f;
+        if (!h->ev_set[i]) continue;
+        if (prev >= 0) CM_HIP(h, hipEventElapsedTime(&out_ms[i], h->ev[prev], h->ev[i]));
+        prev = i;
+    }
     return CM_OK;
 }
 
@@ -227,8 +255,12 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
     double *param = m3 + 5;
     CM_TRY(cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, CM_FORM_AUTO, 0, 0, dist, idx));
     CM_TRY(kernel_param_dev(h, dist, idx, (int64_t)nk, kernel, m3, param));
+    cm_mark(h, 5);
     CM_TRY(cm_weights_run(h, dist, idx, nq, k, n_ref, kernel, param, epsilon, cols, vals, cnt, nullptr));
-    return cm_vote_run(h, nullptr, cols, vals, nq, k, cnt, d_codes, n_cat, d_out_code, d_out_conf);
+    cm_mark(h, 6);
+    CM_TRY(cm_vote_run(h, nullptr, cols, vals, nq, k, cnt, d_codes, n_cat, d_out_code, d_out_conf));
+    cm_mark(h, 7);
+    return CM_OK;
 }
 
 // -------------------------------------------------------------------------------- host tier ---------

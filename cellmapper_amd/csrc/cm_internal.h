@@ -7,6 +7,7 @@
 
 #include "cellmap.h"
 
+#define CM_N_STAGE_EVENTS 8
 struct cm_handle_s {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -18,7 +19,14 @@ struct cm_handle_s {
     size_t ws_off = 0;
     int64_t knn_stats[4] = {0, 0, 0, 0};
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
+    // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
+    bool profiling = false;
+    hipEvent_t ev[CM_N_STAGE_EVENTS] = {};
+    bool ev_set[CM_N_STAGE_EVENTS] = {};
 };
+// stage boundaries: 0 start | 1 after row prep | 2 after phase-1 MFMA filter | 3 after re-rank | 4 after fallback |
+//                   5 after bandwidth statistics | 6 after weights/normalise | 7 after label vote
+void cm_mark(cm_handle_t h, int which);
 
 #define CM_FAIL(h, code, ...)                                   \
     do {                                                        \

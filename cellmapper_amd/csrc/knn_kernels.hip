@@ -316,6 +316,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     if (!Rp || !Qp || !qnorm || !cand || !cthr || !flag_list || !bound || !words)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     hipStream_t st = h->stream;
+    cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 16);
     {
         int bs = 256;
@@ -325,6 +326,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                            p.nq_pad, 0, metric, Qp, qnorm, (unsigned *)nullptr);
     }
     CM_HIP(h, hipGetLastError());
+    cm_mark(h, 1);
     {
         dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
         cm_status s = CM_E_INTERNAL;
@@ -335,15 +337,18 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         if (!ok) CM_FAIL(h, CM_E_INTERNAL, "k-NN: no phase-1 instantiation for KP=%d", p.KP);
         CM_TRY(s);
     }
+    cm_mark(h, 2);
     // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
     float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
     hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                        p.S, p.Kc, k, metric, form, qnorm, words, c_eps, idx_offset, flags, d_out_dist, d_out_idx,
                        flag_list, (int *)(words + 2), bound);
+    cm_mark(h, 3);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
                        (int *)(words + 3));
     CM_HIP(h, hipGetLastError());
+    cm_mark(h, 4);
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = p.Kc;

@@ -1,0 +1,123 @@
+"""Device tier plumbing: call the C ABI's ``cm_*_dev`` entry points on torch-owned device memory.
+
+torch is used for what the task allows it for -- device buffers, streams and ``torch.distributed`` -- while all
+compute goes through ``libcellmap_hip.so``.  Tensors must live on the handle's GPU and be contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import CM_F32, CM_F64, FORMS, KERNELS, METRICS, _ptr
+
+
+def _dp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class DevicePipeline:
+    """One GPU's worth of the hot path on device-resident tensors."""
+
+    def __init__(self, device_index: int = 0, use_torch_stream: bool = True):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        self.h = _native.Handle(device_index)
+        # a dedicated torch stream carries BOTH the library's kernels and torch's own ops / RCCL collectives, so
+        # ordering between them is plain stream order.  Use `with torch.cuda.stream(pipe.stream): ...`.
+        self.stream = torch.cuda.Stream(self.device) if use_torch_stream else None
+        if self.stream is not None:
+            self.h.set_stream(self.stream.cuda_stream)
+
+    def _dtype_id(self, t):
+        if t.dtype == self.torch.float32:
+            return CM_F32
+        if t.dtype == self.torch.float64:
+            return CM_F64
+        raise ValueError(f"unsupported dtype {t.dtype}")
+
+    def knn(self, ref, qry, k, metric="euclidean", form="auto", idx_offset=0, squared=False, force_fallback=False):
+        t = self.torch
+        nq = qry.shape[0]
+        out_dt = t.float64 if METRICS[metric] == 0 else ref.dtype
+        dist = t.empty((nq, k), dtype=out_dt, device=self.device)
+        idx = t.empty((nq, k), dtype=t.int64, device=self.device)
+        flags = (1 if squared else 0) | (2 if force_fallback else 0)
+        self.h.call("cm_knn_dev", _dp(ref), ref.shape[0], _dp(qry), nq, ref.shape[1], self._dtype_id(ref), int(k),
+                    METRICS[metric], FORMS[form], int(idx_offset), flags, _dp(dist), _dp(idx))
+        return dist, idx
+
+    def merge(self, dist_parts, idx_parts, k, sqrt_out=True):
+        """dist_parts / idx_parts: [nparts, nq, k] (squared distances if sqrt_out) -> merged [nq, k]."""
+        t = self.torch
+        nparts, nq, _ = dist_parts.shape
+        od = t.empty((nq, k), dtype=t.float64, device=self.device)
+        oi = t.empty((nq, k), dtype=t.int64, device=self.device)
+        self.h.call("cm_knn_merge_dev", _dp(dist_parts), _dp(idx_parts), int(nparts), int(nq), int(k),
+                    1 if sqrt_out else 0, _dp(od), _dp(oi))
+        return od, oi
+
+    def moments(self, dist, idx, center=None):
+        m = self.torch.zeros(3, dtype=self.torch.float64, device=self.device)
+        self.h.call("cm_dist_moments_dev", _dp(dist), _dp(idx), dist.numel(), _dp(center), _dp(m))
+        return m
+
+    def kernel_param(self, moments3, kernel):
+        p = self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
+        self.h.call("cm_kernel_param_dev", _dp(moments3), KERNELS[kernel], _dp(p))
+        return p
+
+    def weights(self, dist, idx, n_ref, kernel, param, epsilon=1e-8):
+        t = self.torch
+        nq, k = dist.shape
+        cols = t.empty((nq, k), dtype=t.int32, device=self.device)
+        vals = t.empty((nq, k), dtype=t.float32, device=self.device)
+        cnt = t.empty(nq, dtype=t.int32, device=self.device)
+        self.h.call("cm_weights_dev", _dp(dist), _dp(idx), nq, k, int(n_ref), KERNELS[kernel], _dp(param),
+                    float(epsilon), _dp(cols), _dp(vals), _dp(cnt), None)
+        return cols, vals, cnt
+
+    def to_csr(self, cols, vals, cnt):
+        t = self.torch
+        nq, k = cols.shape
+        indptr = t.empty(nq + 1, dtype=t.int64, device=self.device)
+        oc = t.empty(nq * k, dtype=t.int32, device=self.device)
+        ov = t.empty(nq * k, dtype=t.float32, device=self.device)
+        self.h.call("cm_ell_to_csr_dev", _dp(cols), _dp(vals), _dp(cnt), nq, k, _dp(indptr), _dp(oc), _dp(ov))
+        return indptr, oc, ov
+
+    def label_vote(self, indptr, cols, vals, codes, n_cat):
+        t = self.torch
+        nq = indptr.shape[0] - 1
+        code = t.empty(nq, dtype=t.int32, device=self.device)
+        conf = t.empty(nq, dtype=t.float32, device=self.device)
+        self.h.call("cm_label_vote_dev", _dp(indptr), _dp(cols), _dp(vals), nq, _dp(codes), codes.shape[0], int(n_cat),
+                    _dp(code), _dp(conf))
+        return code, conf
+
+    def spmm_dense(self, indptr, cols, vals, B):
+        t = self.torch
+        nq = indptr.shape[0] - 1
+        out = t.empty((nq, B.shape[1]), dtype=B.dtype, device=self.device)
+        self.h.call("cm_spmm_dense_dev", _dp(indptr), _dp(cols), _dp(vals), nq, _dp(B), B.shape[0], B.shape[1],
+                    self._dtype_id(B), _dp(out))
+        return out
+
+    def map_labels(self, ref, qry, k, codes, n_cat, metric="euclidean", kernel="gaussian", epsilon=1e-8,
+                   out_code=None, out_conf=None, want_graph=False):
+        """Fused k-NN -> kernel -> normalise -> label vote, every intermediate resident in HBM."""
+        t = self.torch
+        nq = qry.shape[0]
+        code = out_code if out_code is not None else t.empty(nq, dtype=t.int32, device=self.device)
+        conf = out_conf if out_conf is not None else t.empty(nq, dtype=t.float32, device=self.device)
+        dist = idx = None
+        if want_graph:
+            dist = t.empty((nq, k), dtype=t.float64, device=self.device)
+            idx = t.empty((nq, k), dtype=t.int64, device=self.device)
+        self.h.call("cm_map_labels_dev", _dp(ref), ref.shape[0], _dp(qry), nq, ref.shape[1], self._dtype_id(ref), int(k),
+                    METRICS[metric], KERNELS[kernel], float(epsilon), _dp(codes), int(n_cat), _dp(code), _dp(conf),
+                    _dp(dist), _dp(idx))
+        return (code, conf, dist, idx) if want_graph else (code, conf)

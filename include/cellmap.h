@@ -76,6 +76,12 @@ cm_status cm_destroy(cm_handle_t h);
 const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
 cm_status cm_set_stream(cm_handle_t h, void *hip_stream); /* NULL = the handle's own stream */
 cm_status cm_synchronize(cm_handle_t h);
+/* Per-stage device timing of the LAST device-tier call, from HIP events recorded on the handle's stream (used by
+ * bench.py for the roofline line).  out_ms[i] = time between stage boundary i-1 and i:
+ * 1 row prep | 2 phase-1 MFMA distance+filter kernel | 3 float64 re-rank | 4 exact fallback |
+ * 5 bandwidth statistics | 6 weights+normalise | 7 label vote.  cm_stage_times synchronises the stream. */
+cm_status cm_set_profiling(cm_handle_t h, int32_t on);
+cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
 /* counters of the last cm_knn / cm_knn_dev call: out[0] = queries sent to the exact fallback,
  * out[1] = candidate-list size K', out[2] = reference splits, out[3] = 1 if the low-d VALU path ran */
 cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]);

@@ -89,14 +89,24 @@ static int pair_cmp(const void *a, const void *b) {
 int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d, int32_t is_f64,
                       int32_t k, int32_t form, double *out_dist, int64_t *out_idx) {
     if (k < 1 || k > n_ref || d < 1 || nq < 0) return CMO_EINVAL;
+    /* float32 input is upcast to float64 first, as sklearn does per chunk (_middle_term_computer.pyx.tp) */
+    const double *R = (const double *)ref;
+    double *Rup = NULL;
+    if (!is_f64) {
+        Rup = (double *)malloc(sizeof(double) * (size_t)n_ref * (size_t)d);
+        if (!Rup) return CMO_ENOMEM;
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < n_ref * (int64_t)d; t++) Rup[t] = (double)((const float *)ref)[t];
+        R = Rup;
+    }
     double *yn = NULL;
     if (form == 0) {
-        yn = (double *)malloc(sizeof(double) * (size_t)(n_ref > 0 ? n_ref : 1));
-        if (!yn) return CMO_ENOMEM;
+        yn = (double *)malloc(sizeof(double) * (size_t)n_ref);
+        if (!yn) { free(Rup); return CMO_ENOMEM; }
 #pragma omp parallel for schedule(static)
         for (int64_t j = 0; j < n_ref; j++) {
             double s = 0.0;
-            for (int32_t c = 0; c < d; c++) { double v = ld(ref, is_f64, j * d + c); s = fma(v, v, s); }
+            for (int32_t c = 0; c < d; c++) { double v = R[j * d + c]; s = fma(v, v, s); }
             yn[j] = s;
         }
     }
@@ -109,21 +119,41 @@ int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t n
 #pragma omp atomic write
             err = CMO_ENOMEM;
         } else {
-#pragma omp for schedule(dynamic, 16)
+#pragma omp for schedule(dynamic, 4)
             for (int64_t i = 0; i < nq; i++) {
                 double xn = 0.0;
                 for (int32_t c = 0; c < d; c++) { q[c] = ld(qry, is_f64, i * d + c); xn = fma(q[c], q[c], xn); }
                 for (int32_t t = 0; t < k; t++) { h[t].v = INFINITY; h[t].i = INT64_MAX; }
-                for (int64_t j = 0; j < n_ref; j++) {
+                int64_t j = 0;
+                if (form == 0) {
+                    /* four reference rows at a time: four independent fma chains (per-pair arithmetic unchanged) */
+                    for (; j + 4 <= n_ref; j += 4) {
+                        const double *y0 = R + j * d, *y1 = y0 + d, *y2 = y1 + d, *y3 = y2 + d;
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                        for (int32_t c = 0; c < d; c++) {
+                            double qc = q[c];
+                            a0 = fma(qc, y0[c], a0); a1 = fma(qc, y1[c], a1);
+                            a2 = fma(qc, y2[c], a2); a3 = fma(qc, y3[c], a3);
+                        }
+                        double dots[4] = { a0, a1, a2, a3 };
+                        for (int u = 0; u < 4; u++) {
+                            double d2 = (xn + (-2.0 * dots[u])) + yn[j + u];
+                            if (!(d2 > 0.0)) d2 = 0.0; /* max(0., d2), also squashes -0. */
+                            if (d2 <= h[0].v) { pair_t x = { d2, j + u }; heap_push(h, k, x); }
+                        }
+                    }
+                }
+                for (; j < n_ref; j++) {
                     double d2;
+                    const double *y = R + j * d;
                     if (form == 0) {
                         double dot = 0.0;
-                        for (int32_t c = 0; c < d; c++) dot = fma(q[c], ld(ref, is_f64, j * d + c), dot);
+                        for (int32_t c = 0; c < d; c++) dot = fma(q[c], y[c], dot);
                         d2 = (xn + (-2.0 * dot)) + yn[j];
-                        if (!(d2 > 0.0)) d2 = 0.0; /* max(0., d2), also squashes -0. */
+                        if (!(d2 > 0.0)) d2 = 0.0;
                     } else {
                         d2 = 0.0;
-                        for (int32_t c = 0; c < d; c++) { double t = q[c] - ld(ref, is_f64, j * d + c); d2 = d2 + t * t; }
+                        for (int32_t c = 0; c < d; c++) { double t = q[c] - y[c]; d2 = d2 + t * t; }
                     }
                     pair_t x = { d2, j };
                     heap_push(h, k, x);
@@ -136,6 +166,7 @@ int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t n
         free(q);
     }
     free(yn);
+    free(Rup);
     return err;
 }
 
