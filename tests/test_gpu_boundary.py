@@ -1,0 +1,233 @@
+"""GPU tests of the drop-in boundary: CellMapper / Neighbors / NeighborsResults used exactly like the reference's
+tests use them (tests/model/test_neighbors*.py, test_query_to_reference_mapping.py, test_self_mapping.py),
+compared with golden vectors from the reference."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+from scipy.sparse import csr_matrix
+
+from parity import assert_csr_close, assert_knn_parity, golden_csr, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(g, rep_key="X_emb", sparse_x=False):
+    from cellmapper_amd import MiniAnnData
+
+    n_ref, nq = g["xrep"].shape[0], g["yrep"].shape[0]
+    X = golden_csr(g, "X_sparse") if sparse_x else g["X_dense"]
+    ref = MiniAnnData(X=X, obs=pd.DataFrame({"label": pd.Categorical([f"c{c:02d}" for c in g["label_codes"]]),
+                                             "num": g["num_values"]}, index=[f"r{i}" for i in range(n_ref)]),
+                      obsm={rep_key: g["xrep"], "X_umap": g["obsm_in"]},
+                      uns={"label_colors": [f"#{i:06x}" for i in range(len(g["categories"]))]})
+    qry = MiniAnnData(X=np.zeros((nq, 3), np.float32), obs=pd.DataFrame(index=[f"q{i}" for i in range(nq)]),
+                      obsm={rep_key: g["yrep"]})
+    return qry, ref
+
+
+@pytest.mark.parametrize("name,kern", [("synth_f32_k30", "gaussian"), ("synth_f32_k30", "scarches"),
+                                       ("synth_f32_k15", "inverse_distance"), ("synth_f32_k30", "equal"),
+                                       ("synth_f64_k30", "gaussian"), ("synth_clustered_k30", "gaussian"),
+                                       ("synth_d64_trunc50_k15", "gaussian"), ("synth_d10_k15", "gaussian")])
+def test_map_matches_reference(name, kern):
+    from cellmapper_amd import CellMapper
+
+    g = load_golden(name)
+    qry, ref = build_pair(g)
+    cm = CellMapper(qry, ref)
+    out = cm.map(obs_keys=["label", "num"], obsm_keys="X_umap", layer_key="X", n_neighbors=int(g["k"]),
+                 use_rep="X_emb", knn_method="sklearn", only_yx=True, mapping_method=kern)
+    assert out is cm and cm.only_yx is True and cm.prediction_postfix == "pred" and cm.confidence_postfix == "conf"
+    n = min(50, g["xrep"].shape[1])
+    assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, g["yx_dist"], g["yx_idx"], g["xrep"][:, :n],
+                      g["yrep"][:, :n])
+    assert cm.knn.yx.n_targets == ref.n_obs and cm.knn.xx is None
+    mm = cm.mapping_matrix
+    assert isinstance(mm, csr_matrix) and mm.dtype == np.float32 and mm.shape == (qry.n_obs, ref.n_obs)
+    assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, f"map_{kern}"), rtol=1e-5)
+    pred = qry.obs["label_pred"]
+    assert isinstance(pred.dtype, pd.CategoricalDtype)
+    got = np.array([int(s[1:]) for s in pred.astype(str)])
+    assert (got == g[f"pred_code_{kern}"]).mean() > 0.995
+    np.testing.assert_allclose(qry.obs["label_conf"].to_numpy(), g[f"conf_{kern}"], rtol=1e-5)
+    assert qry.obs["label_conf"].dtype == np.float32
+    assert "num_conf" not in qry.obs.columns and qry.obs["num_pred"].dtype == np.float64
+    np.testing.assert_allclose(qry.obs["num_pred"].to_numpy(), g[f"num_pred_{kern}"], rtol=1e-5, atol=1e-7)
+    assert qry.obsm["X_umap_pred"].shape == (qry.n_obs, 2) and qry.obsm["X_umap_pred"].dtype == np.float32
+    np.testing.assert_allclose(qry.obsm["X_umap_pred"], g[f"obsm_pred_{kern}"], rtol=1e-5, atol=1e-6)
+    qi = cm.query_imputed
+    assert qi.X.shape == (qry.n_obs, ref.n_vars) and qi.obs is qry.obs and qi.var is ref.var
+    np.testing.assert_allclose(qi.X, g[f"layer_dense_{kern}"], rtol=1e-5, atol=1e-6)
+    assert "label_pred_colors" in qry.uns
+
+
+def test_sparse_layer_and_full_mode_and_jaccard():
+    from cellmapper_amd import CellMapper
+
+    g = load_golden("synth_full_d37_k10")
+    qry, ref = build_pair(g, sparse_x=True)
+    cm = CellMapper(qry, ref)
+    cm.compute_neighbors(n_neighbors=10, use_rep="X_emb", only_yx=False)
+    for gname in ("xx", "yy", "xy", "yx"):
+        res = getattr(cm.knn, gname)
+        a = g["xrep"] if gname in ("xx", "yx") else g["yrep"]
+        b = g["xrep"] if gname in ("xx", "xy") else g["yrep"]
+        assert_knn_parity(res.distances, res.indices, g[f"{gname}_dist"], g[f"{gname}_idx"], a, b)
+    assert cm.knn.xy.n_targets == qry.n_obs and cm.knn.xx.n_targets == ref.n_obs
+    cm.compute_mapping_matrix("gaussian")
+    cm.map_layers("X")
+    res = cm.query_imputed.X
+    assert sp.issparse(res) and res.dtype == np.float32
+    gs = golden_csr(g, "layer_sparse_gaussian")
+    np.testing.assert_allclose(res.toarray(), gs.toarray(), rtol=1e-5, atol=1e-7)
+    for meth in ("jaccard", "hnoca"):
+        cm.compute_mapping_matrix(meth)
+        mm = cm.mapping_matrix
+        assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, f"map_{meth}"), rtol=1e-5)
+    cm.only_yx = True
+    with pytest.raises(ValueError, match="require both x and y"):
+        cm.compute_mapping_matrix("jaccard")
+
+
+def test_identity_mapping_k1():
+    """Reference tests/model/test_query_to_reference_mapping.py:75-92: k=1 + jaccard reproduces labels exactly."""
+    from cellmapper_amd import CellMapper
+
+    g = load_golden("identity_k1")
+    qry, ref = build_pair(g)
+    cm = CellMapper(qry, ref)
+    cm.map(obs_keys=["label", "num"], use_rep="X_emb", n_neighbors=1, mapping_method="jaccard")
+    assert (qry.obs["label_pred"].astype(str).to_numpy() == ref.obs["label"].astype(str).to_numpy()).all()
+    np.testing.assert_allclose(qry.obs["num_pred"].to_numpy(), g["num_values"], rtol=1e-6)
+    mm = cm.mapping_matrix
+    assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, "map_jaccard"), rtol=1e-6)
+
+
+def test_self_mapping_spatial():
+    from cellmapper_amd import CellMapper, MiniAnnData
+
+    g = load_golden("spatial32_self_k20")
+    n = g["xrep"].shape[0]
+    ad = MiniAnnData(X=g["X_dense"], obs=pd.DataFrame({"label": pd.Categorical([f"c{c:02d}" for c in g["label_codes"]])}),
+                     obsm={"spatial": g["xrep"]})
+    cm = CellMapper(ad)
+    assert cm.reference is ad and cm.query is ad
+    cm.map(obs_keys="label", layer_key="X", use_rep="spatial", n_neighbors=20, only_yx=True)
+    assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, g["yx_dist"], g["yx_idx"], g["xrep"], g["yrep"], atol=1e-9)
+    assert (cm.knn.yx.indices[:, 0] == np.arange(n)).all() and (cm.knn.yx.distances[:, 0] == 0).all()
+    np.testing.assert_allclose(cm.query_imputed.X, g["layer_dense_gaussian"], rtol=1e-5, atol=1e-6)
+
+
+def test_neighbors_results_graph_api():
+    """Reference tests/model/test_neighbors_results.py, on the GPU path."""
+    from cellmapper_amd import Neighbors, NeighborsResults
+
+    g = load_golden("small_data")
+    nb = Neighbors(g["xrep"], g["yrep"])
+    nb.compute_neighbors(n_neighbors=3, method="sklearn")
+    assert "xx=True" in repr(nb) and "yx=True" in repr(nb)
+    for graph in ("xx", "yy", "xy", "yx"):
+        r = getattr(nb, graph)
+        assert_knn_parity(r.distances, r.indices, g[f"{graph}_dist"], g[f"{graph}_idx"], g["xrep"], g["yrep"])
+    adj = nb.get_adjacency_matrices()
+    assert all(isinstance(a, csr_matrix) and (a.data == 1).all() for a in adj)
+    gold = NeighborsResults(g["yx_dist"], g["yx_idx"])
+    np.testing.assert_array_equal(gold.boolean_adjacency().toarray(), golden_csr(g, "bool_adj").toarray())
+    np.testing.assert_allclose(gold.knn_graph_distances.toarray(), golden_csr(g, "graph_dist").toarray())
+    assert np.allclose(gold.knn_graph_distances.diagonal(), 0)
+    for kern in ("gaussian", "scarches", "random", "inverse_distance", "equal"):
+        m = gold.knn_graph_connectivities(kernel=kern)
+        assert isinstance(m, csr_matrix) and m.shape == (5, 5) and m.dtype == np.float64
+        if kern != "random":
+            assert (m.data > 0).all()
+            np.testing.assert_allclose(m.toarray(), golden_csr(g, f"conn_{kern}").toarray(), rtol=1e-13)
+    assert gold.boolean_adjacency(set_diag=False).diagonal().sum() == 0
+    assert gold.boolean_adjacency(set_diag=True).diagonal().sum() == 5
+    with pytest.raises(ValueError, match="square"):
+        NeighborsResults(g["yx_dist"], g["yx_idx"], n_targets=9).boolean_adjacency(set_diag=True)
+
+
+def test_from_distances_and_precomputed():
+    from cellmapper_amd import CellMapper, MiniAnnData, Neighbors
+
+    g = load_golden("padded_graph")
+    dm = golden_csr(g, "dm")
+    for inc, tag in ((None, "none"), (True, "true"), (False, "false")):
+        nb = Neighbors.from_distances(dm, include_self=inc)
+        assert nb._is_self_mapping and nb.xx is nb.yy is nb.xy is nb.yx
+        conn = nb.xx.knn_graph_connectivities()
+        np.testing.assert_allclose(conn.toarray(), golden_csr(g, f"conn_gaussian_{tag}").toarray(), rtol=1e-13)
+    n = dm.shape[0]
+    ad = MiniAnnData(X=np.zeros((n, 2), np.float32), obs=pd.DataFrame({"v": np.arange(n, dtype=float)}), obsp={"distances": dm})
+    cm = CellMapper(ad)
+    cm.load_precomputed_distances(include_self=True)
+    cm.compute_mapping_matrix("gaussian")
+    mm = cm.mapping_matrix
+    assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, "map_gaussian_true"), rtol=2e-7)
+    cm.map_obs("v")
+    assert ad.obs["v_pred"].shape == (n,)
+
+
+def test_mapping_matrix_setter_and_errors():
+    from cellmapper_amd import CellMapper
+
+    g = load_golden("synth_f32_k15")
+    qry, ref = build_pair(g)
+    cm = CellMapper(qry, ref)
+    with pytest.raises(ValueError, match="shape mismatch"):
+        cm.mapping_matrix = sp.identity(5, format="csr")
+    raw = golden_csr(g, "conn_gaussian")
+    cm.mapping_matrix = raw.tocoo()
+    mm = cm.mapping_matrix
+    assert mm.dtype == np.float32
+    assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, "map_gaussian"), rtol=2e-7)
+    np.testing.assert_allclose(np.asarray(mm.sum(1)).ravel(), 1.0, rtol=1e-5)
+    with pytest.raises(KeyError):
+        cm.map_obs("missing")
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        cm.compute_neighbors(n_neighbors=10**6, use_rep="X_emb")
+    with pytest.raises(ValueError, match="not supported"):
+        cm.compute_neighbors(n_neighbors=5, use_rep="X_emb", metric="manhattan")
+    cm.map(use_rep="X_emb", n_neighbors=5)  # no keys: warning only
+
+
+def test_cosine_through_boundary():
+    from cellmapper_amd import CellMapper
+
+    g = load_golden("synth_f32_cosine_k15")
+    qry, ref = build_pair(g)
+    cm = CellMapper(qry, ref)
+    cm.map(obs_keys="label", use_rep="X_emb", n_neighbors=15, metric="cosine", only_yx=True)
+    assert cm.knn.yx.distances.dtype == np.float32
+    assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, g["yx_dist"], g["yx_idx"], g["xrep"], g["yrep"], "cosine")
+    mm = cm.mapping_matrix
+    assert_csr_close(mm.indptr, mm.indices, mm.data, golden_csr(g, "map_gaussian"), rtol=1e-5)
+
+
+def test_sharded_search_equals_single_search():
+    """Reference rows split into shards (as the multi-GPU driver does), per-shard top-k with global indices,
+    k-way merge: must reproduce the single-search result exactly (SURVEY.md 8e tie policy)."""
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+    from cellmapper_amd.sharded import shard_bounds
+
+    rng = np.random.default_rng(3)
+    n_ref, nq, d, k = 9001, 1200, 50, 30
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    ref[500] = ref[8000]  # a cross-shard exact tie
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    qry[0] = ref[500]
+    pipe = DevicePipeline(0)
+    with torch.cuda.stream(pipe.stream):
+        tr, tq = torch.from_numpy(ref).cuda(), torch.from_numpy(qry).cuda()
+        d_full, i_full = pipe.knn(tr, tq, k)
+        parts_d, parts_i = [], []
+        for r in range(3):
+            lo, hi = shard_bounds(n_ref, 3, r)
+            dd, ii = pipe.knn(tr[lo:hi].contiguous(), tq, k, idx_offset=lo, squared=True)
+            parts_d.append(dd), parts_i.append(ii)
+        md, mi = pipe.merge(torch.stack(parts_d), torch.stack(parts_i), k)
+        torch.cuda.synchronize()
+    assert torch.equal(mi, i_full) and torch.equal(md, d_full)
+    assert set(mi[0, :2].tolist()) == {500, 8000} and mi[0, 0].item() == 500

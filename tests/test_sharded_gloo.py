@@ -1,0 +1,113 @@
+"""World-size-2 gloo test (CPU) of the multi-GPU choreography in cellmapper_amd/sharded.py: reference sharding with
+global indices, the exchange (all-to-all by query slice, and the all-gather variant), the k-way merge rule and the
+all-reduced kernel bandwidth.  Compute is injected from the CPU oracle -- this tests the HOST logic that surrounds
+the HIP kernels, not the kernels (those are covered by the -m gpu tests)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleOps:
+    """CPU stand-in for HipOps with the same interface (torch CPU tensors in/out)."""
+
+    def __init__(self):
+        import torch
+        from oracle import oracle as orc
+
+        self.t, self.o = torch, orc
+
+    def local_knn(self, ref_shard, qry, k, metric, idx_offset):
+        d, i = self.o.knn_euclidean(ref_shard.numpy(), qry.numpy(), k)
+        return self.t.from_numpy(d * d), self.t.from_numpy(i + idx_offset)
+
+    def merge(self, dparts, iparts, k):
+        d = dparts.numpy().transpose(1, 0, 2).reshape(dparts.shape[1], -1)
+        i = iparts.numpy().transpose(1, 0, 2).reshape(dparts.shape[1], -1)
+        order = np.lexsort((i, d), axis=1)[:, :k]
+        return (self.t.from_numpy(np.sqrt(np.take_along_axis(d, order, 1))),
+                self.t.from_numpy(np.take_along_axis(i, order, 1)))
+
+    def moments(self, dist, idx, center=None):
+        c = 0.0 if center is None else float(center[0])
+        v = dist.numpy().ravel() - c
+        return self.t.tensor([v.sum(), (v * v).sum(), float(v.size)], dtype=self.t.float64)
+
+    def param(self, m3, kernel):
+        m = m3.numpy()
+        if kernel == "gaussian":
+            return self.t.tensor([m[0] / m[2]], dtype=self.t.float64)
+        return self.t.tensor([(2.0 / np.sqrt(m[1] / m[2])) ** 2], dtype=self.t.float64)
+
+    def weights_vote(self, dist, idx, n_ref, kernel, param, codes, n_cat, epsilon):
+        d, i = dist.numpy(), idx.numpy()
+        p = float(param[0]) if param is not None else 0.0
+        w = {"gaussian": lambda: np.exp(-(d * d) / (2 * p * p)), "scarches": lambda: np.exp(-d / p),
+             "inverse_distance": lambda: 1.0 / (d + epsilon), "equal": lambda: np.ones_like(d)}[kernel]()
+        indptr, cols, v32, _ = self.o.mapping_matrix(w, d, i, n_ref)
+        code, conf = self.o.label_vote(indptr, cols, v32, codes.numpy(), n_cat)
+        return self.t.from_numpy(code), self.t.from_numpy(conf)
+
+    def empty_like_parts(self, world, n, k, like):
+        return self.t.empty((world, n, k), dtype=like.dtype)
+
+    def pad_rows(self, x, n):
+        if x.shape[0] == n:
+            return x
+        return self.t.cat([x, self.t.zeros((n - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype)], 0)
+
+
+def _worker(rank, world, port, exchange, kernel, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from cellmapper_amd.sharded import shard_bounds, sharded_map_labels
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    n_ref, nq, d, k, n_cat = 3001, 203, 20, 12, 7
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    ref[10] = ref[2500]  # exact tie across the shard boundary
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    qry[0] = ref[10]
+    codes = rng.integers(0, n_cat, n_ref).astype(np.int32)
+    lo, hi = shard_bounds(n_ref, world, rank)
+    code, conf, (q_lo, q_hi), dd, ii = sharded_map_labels(
+        OracleOps(), dist, torch.from_numpy(ref[lo:hi].copy()), lo, n_ref, torch.from_numpy(qry), k,
+        torch.from_numpy(codes), n_cat, kernel=kernel, exchange=exchange)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), code=code.numpy(), conf=conf.numpy(), q_lo=q_lo, q_hi=q_hi,
+             dist=dd.numpy(), idx=ii.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,kernel", [("alltoall", "gaussian"), ("allgather", "scarches")])
+def test_sharded_choreography_world2(exchange, kernel, tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + (0 if exchange == "alltoall" else 1)
+    mp.spawn(_worker, args=(world, port, exchange, kernel, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    n_ref, nq, d, k, n_cat = 3001, 203, 20, 12, 7
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    ref[10] = ref[2500]
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    qry[0] = ref[10]
+    codes = rng.integers(0, n_cat, n_ref).astype(np.int32)
+    full = oracle.run_path(ref, qry, k, kernel=kernel, labels=codes, n_cat=n_cat)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert int(parts[0]["q_lo"]) == 0 and int(parts[-1]["q_hi"]) == nq and int(parts[0]["q_hi"]) == int(parts[1]["q_lo"])
+    idx = np.concatenate([p["idx"] for p in parts])
+    dist_ = np.concatenate([p["dist"] for p in parts])
+    assert np.array_equal(idx, full["idx"]), "merged global indices must equal the unsharded search"
+    np.testing.assert_allclose(dist_, full["dist"], rtol=1e-12)
+    assert idx[0, 0] == 10 and idx[0, 1] == 2500  # lower global index wins the cross-shard tie
+    np.testing.assert_array_equal(np.concatenate([p["code"] for p in parts]), full["pred_code"])
+    np.testing.assert_allclose(np.concatenate([p["conf"] for p in parts]), full["conf"], rtol=1e-6)
