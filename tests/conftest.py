@@ -9,6 +9,14 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+# PyTorch-ROCm wheels bundle their own HIP runtime.  If libcellmap_hip.so (linked against /opt/rocm) is loaded
+# first, torch later fails with "No HIP GPUs are available"; importing torch first makes both share one runtime.
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
