@@ -23,7 +23,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# /opt/skills/guides/MI355X_MICROARCH.md, dense MFMA peaks: f32-input 157.3 TFLOP/s, f16/bf16 ~2500 TFLOP/s
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -140,6 +142,13 @@ def main():
         flops = 2.0 * a.nq * (hi - lo) * a.d  # algorithmic flops of the distance contraction on this rank's shard
         p1 = float(np.mean(p1_ms))
         achieved = flops / (p1 * 1e-3) / 1e12
+        f16_path = fb["lowd_path"] == 2  # knn_stats[3]: 1 = f32-input MFMA kernel, 2 = split-fp16 MFMA kernel
+        peak = PEAK_F16_MFMA_TFLOPS if f16_path else PEAK_F32_MFMA_TFLOPS
+        kname = ("knn_cand_f16 (split-fp16 v_mfma_f32_32x32x16_f16 distance GEMM + fused top-k filter)" if f16_path
+                 else "knn_cand_mfma (v_mfma_f32_32x32x2_f32 distance GEMM + fused top-k filter)")
+        # the split-fp16 kernel executes 3 MFMA products over the feature dimension padded to a multiple of 16 (+3 slots)
+        kpad = 32 if a.d + 3 <= 32 else 64
+        executed = 3.0 * 2.0 * a.nq * (hi - lo) * kpad if f16_path else 2.0 * a.nq * (hi - lo) * (4 * ((a.d + 4) // 4))
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "phase1_hbm_traffic.json")
         if os.path.exists(tfile) and world == 1 and a.nq == 1_500_000 and a.nref == 1_500_000:
@@ -151,16 +160,19 @@ def main():
             "metric": "query cells/s end-to-end (k-NN+kernel+transfer)",
             "value": value, "unit": "query cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f16x2-split MFMA filter + f64 exact re-rank" if fb["lowd_path"] == 2 else "f32 MFMA filter + f64 exact re-rank",
+            "data": "synthetic",
             "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.kernel} kernel, "
                                    f"{a.ncat}-class label transfer (BASELINE configs[1]); reference rows sharded over "
                                    f"{world} GPU(s), exchange={a.exchange if world > 1 else 'none'}",
                        "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
                        "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"]},
-            "roofline": {"bound": "mfma", "kernel": "knn_cand_mfma (fp32 MFMA distance GEMM + fused top-k filter)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel_ms": p1,
-                         "flops_per_launch": flops},
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "kernel_ms": p1,
+                         "flops_per_launch": flops, "executed_mfma_tflops": executed / (p1 * 1e-3) / 1e12,
+                         "executed_frac_of_peak": executed / (p1 * 1e-3) / 1e12 / peak,
+                         "f32_mfma_equivalent_frac": achieved / PEAK_F32_MFMA_TFLOPS},
             "stage_ms_last_step": stages,
         }
     # parity spot check + CPU baseline on rank 0 at N=1 only (bounded sample, outside the timed region)

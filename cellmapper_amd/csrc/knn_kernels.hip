@@ -5,8 +5,13 @@
 // knn.py:428-440 (sklearn.neighbors.NearestNeighbors(...).fit(xrep).kneighbors(yrep)).
 #include "cm_internal.h"
 #include "knn_phase1.h"
+#include "knn_phase1_f16.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 
 // phase-1 instantiation groups (knn_phase1_inst.hip)
 #define CM_DECL_P1(g)                                                                                                  \
@@ -76,6 +81,121 @@ __global__ void prep_rows(const T *__restrict__ X, int64_t n, int d, int KP, int
     }
 }
 
+// ------------------------------------------------------------------ split-fp16 preparation ----------
+// max |coordinate| over a matrix (after the optional cosine normalisation): decides the power-of-two scale that
+// keeps the fp16 halves in range.  gmax[4] holds the float bits of the maximum.
+template <typename T>
+__global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metric, unsigned *__restrict__ gmax) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.f;
+    if (i < n) {
+        const T *x = X + i * d;
+        double scale = 1.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+            double nrm = sqrt(s);
+            scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+        for (int c = 0; c < d; ++c) m = fmaxf(m, fabsf((float)((double)x[c] * scale)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&gmax[4], __float_as_uint(m));
+}
+// sc = 2^(12 - e) with maxabs = m * 2^e, m in [0.5, 1): scaled coordinates land in [2048, 4096) at most
+__global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__restrict__ scale3) {
+    if (threadIdx.x == 0) {
+        float mx = __uint_as_float(gmax[4]);
+        int e = 0;
+        float sc = 1.f;
+        if (mx > 0.f && isfinite(mx)) { (void)frexpf(mx, &e); sc = ldexpf(1.f, 12 - e); }
+        scale3[0] = sc;
+        scale3[1] = sc * sc;
+        scale3[2] = 1.f / (sc * sc);
+    }
+}
+// X [n,d] -> split-fp16 prepared rows [hi(K) | lo(K)], K = 16*KSTEPS >= d + 3.
+//   queries   : hi/lo of sc*q in slots [0,d); slots d..d+2 of hi hold the constants 2^15, 2^4, 2^-7; plain rows.
+//   references: hi/lo of -2*sc*y in slots [0,d); slots d..d+2 of hi hold fp16 digits a1,a2,a3 of N = sc^2*|y|^2 with
+//               N = a1*2^15 + a2*2^4 + a3*2^-7 (residual <= 2^-33 N), so q'.y' = sc^2 (|y|^2 - 2 q.y); padded rows carry
+//               a1 = +inf.  Rows are grouped in 128-row tile images whose 16-byte granules are XOR-swizzled by row
+//               (the LDS image knn_cand_f16 copies verbatim with LDS-DMA).
+template <typename T>
+__global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
+                              const float *__restrict__ scale3, char *__restrict__ P, float *__restrict__ rownorm,
+                              unsigned *__restrict__ gmax) {
+    const int ROWB = cmk2::row_bytes(KSTEPS), GRAN = ROWB / 16, TILEB = cmk2::tile_bytes(KSTEPS);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float yn_f = 0.f;
+    if (i < n_pad) {
+        const float sc = scale3[0];
+        const int64_t tile = i / cmk2::BR;
+        const int r = (int)(i - tile * cmk2::BR);
+        char *rowp = is_ref ? P + tile * TILEB + (size_t)r * ROWB : P + i * (size_t)ROWB;
+        const int f = is_ref ? cmk2::swz(r, KSTEPS) : 0;
+        double nscale = 1.0;
+        const T *x = X + i * d;
+        double s2 = 0.0;
+        if (i < n) {
+            for (int c = 0; c < d; ++c) { double v = (double)x[c]; s2 = fma(v, v, s2); }
+            if (metric == CM_METRIC_COSINE) {
+                double nrm = sqrt(s2);
+                nscale = nrm > 0.0 ? 1.0 / nrm : 1.0;
+                s2 = nrm > 0.0 ? 1.0 : 0.0;
+            }
+        }
+        // norm digits / query constants for slots d, d+1, d+2
+        float slot[3];
+        if (is_ref) {
+            if (i < n) {
+                double N = s2 * (double)sc * (double)sc;
+                _Float16 a1 = (_Float16)(float)(N * 0x1p-15);
+                double r1 = N - (double)(float)a1 * 0x1p15;
+                _Float16 a2 = (_Float16)(float)(r1 * 0x1p-4);
+                double r2 = r1 - (double)(float)a2 * 0x1p4;
+                _Float16 a3 = (_Float16)(float)(r2 * 0x1p7);
+                slot[0] = (float)a1; slot[1] = (float)a2; slot[2] = (float)a3;
+            } else {
+                slot[0] = INFINITY; slot[1] = 0.f; slot[2] = 0.f;
+            }
+        } else {
+            slot[0] = 0x1p15f; slot[1] = 0x1p4f; slot[2] = 0x1p-7f;
+        }
+        const float mul = (is_ref ? -2.0f : 1.0f) * sc;
+        for (int g = 0; g < GRAN / 2; ++g) {
+            cmk2::half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int c = g * 8 + e;
+                _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+                if (c < d) {
+                    if (i < n) {
+                        float v = (float)((double)x[c] * nscale) * mul;
+                        h = (_Float16)v;
+                        l = (_Float16)(v - (float)h);
+                    }
+                } else if (c < d + cmk2::NORM_SLOTS) {
+                    h = (_Float16)slot[c - d];
+                }
+                hi[e] = h;
+                lo[e] = l;
+            }
+            *reinterpret_cast<cmk2::half8 *>(rowp + ((g ^ f) * 16)) = hi;
+            *reinterpret_cast<cmk2::half8 *>(rowp + (((GRAN / 2 + g) ^ f) * 16)) = lo;
+        }
+        yn_f = (i < n) ? (float)s2 : 0.f;
+        if (rownorm && i < n) rownorm[i] = sqrtf(yn_f) * 1.0000002f;
+    }
+    if (is_ref && gmax) {
+        float m = yn_f;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&gmax[0], __float_as_uint(m * 1.0000002f));
+            atomicMax(&gmax[1], __float_as_uint(sqrtf(m) * 1.0000002f));
+        }
+    }
+}
+
 // ------------------------------------------------------------------ exact float64 pair value --------
 // The value that orders neighbours and (after sqrt) is returned, following sklearn's arithmetic exactly as the
 // CPU oracle restates it (oracle/cm_oracle.c: cmo_knn_euclidean):
@@ -118,10 +238,10 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int d, const int *__restrict__ cand, const float *__restrict__ cthr,
                                                    int S, int Kc, int k, int metric, int form,
                                                    const float *__restrict__ qnorm, const unsigned *__restrict__ gmax,
-                                                   float c_eps, int64_t idx_offset, int flags,
-                                                   void *__restrict__ out_dist, int64_t *__restrict__ out_idx,
-                                                   int *__restrict__ flag_list, int *__restrict__ flag_cnt,
-                                                   double *__restrict__ bound) {
+                                                   float c_eps, const float *__restrict__ scale3, int64_t idx_offset,
+                                                   int flags, void *__restrict__ out_dist,
+                                                   int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
+                                                   int *__restrict__ flag_cnt, double *__restrict__ bound) {
     __shared__ double s_q[4][RR_DMAX];
     __shared__ double s_v[4][RR_NCMAX];
     __shared__ int s_i[4][RR_NCMAX];
@@ -163,6 +283,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         double kth = s_kth[w];
         float tau = INFINITY;
         for (int s = 0; s < S; ++s) tau = fminf(tau, cthr[i * S + s]);
+        if (scale3) tau *= scale3[2];  // phase-1 values were computed on rows scaled by sc: back to input units
         bool certified = true;
         if (tau < INFINITY) {
             double sk = (metric == CM_METRIC_COSINE) ? (2.0 * kth - 1.0) : (kth - xn);
@@ -300,34 +421,122 @@ cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnP
     return CM_OK;
 }
 
+unsigned long long *g_dbg_ctr = nullptr;  // CELLMAP_DBG=4 diagnostics only
+
+struct KnnPlan2 {
+    int KSTEPS, Kc, S, n_tiles, tps, nqb, grid;
+    int64_t nq_pad;
+    size_t lds, tileb, rowb;
+};
+
+int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
+
+bool use_f16_path(int d, int k) {
+    const char *e = getenv("CELLMAP_PHASE1");
+    if (e && !strcmp(e, "f32")) return false;
+    if (k + knn_slack(k) + 2 * cmk2::CL > 256) return false;  // the in-register merge handles 256 entries per query
+    return d + cmk2::NORM_SLOTS <= 64;                        // needs three spare feature slots for the norm digits
+}
+
+cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan2 *p) {
+    p->KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
+    int slack = k / 4 > 8 ? k / 4 : 8;
+    p->Kc = k + slack;
+    p->tileb = cmk2::tile_bytes(p->KSTEPS);
+    p->rowb = cmk2::row_bytes(p->KSTEPS);
+    p->lds = cmk2::lds_bytes(p->KSTEPS, 0);
+    if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
+    p->nq_pad = (nq + cmk2::QB - 1) / cmk2::QB * cmk2::QB;
+    p->nqb = (int)(p->nq_pad / cmk2::QB);
+    p->n_tiles = (int)((n_ref + cmk2::BR - 1) / cmk2::BR);
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const int resident = ncu * (8 / cmk2::NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
+    int S = 1;
+    if (p->nqb < resident) {
+        S = (resident + p->nqb - 1) / p->nqb;
+        if (S > 8) S = 8;
+        if (S > p->n_tiles) S = p->n_tiles;
+        while (S > 1 && S * p->Kc > RR_NCMAX) --S;
+        if (S < 1) S = 1;
+    }
+    p->tps = (p->n_tiles + S - 1) / S;
+    p->S = (p->n_tiles + p->tps - 1) / p->tps;
+    if (p->S * p->Kc > RR_NCMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large (max %d)", k, RR_NCMAX - 64);
+    int64_t n_work = (int64_t)p->nqb * p->S;
+    p->grid = (int)(n_work < resident ? n_work : resident);
+    return CM_OK;
+}
+
 template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
+    hipStream_t st = h->stream;
+    const bool f16 = use_f16_path(d, k);
     KnnPlan p;
-    CM_TRY(make_plan(h, n_ref, nq, d, k, &p));
-    float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
-    float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
-    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad);
-    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * p.nq_pad * p.S * p.Kc);
-    float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.S);
+    KnnPlan2 p2;
+    int Kc, S;
+    int64_t nq_pad;
+    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
+    else { CM_TRY(make_plan(h, n_ref, nq, d, k, &p)); Kc = p.Kc; S = p.S; nq_pad = p.nq_pad; }
+    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
+    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc);
+    float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad * S);
     int *flag_list = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
     double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
-    unsigned *words = (unsigned *)cm_ws_alloc(h, 64);  // [0..1] gmax, [2] flag count, [3] overflow
-    if (!Rp || !Qp || !qnorm || !cand || !cthr || !flag_list || !bound || !words)
-        CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-    hipStream_t st = h->stream;
+    unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
+    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    float *scale3 = reinterpret_cast<float *>(words + 8);
     cm_mark(h, 0);
-    hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 16);
-    {
-        int bs = 256;
+    hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
+    float c_eps;
+    const int bs = 256;
+    if (f16) {
+        char *Rp = (char *)cm_ws_alloc(h, (size_t)p2.n_tiles * p2.tileb);
+        char *Qp = (char *)cm_ws_alloc(h, (size_t)p2.nq_pad * p2.rowb);
+        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * p2.Kc);
+        uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * 2 * cmk2::CL);
+        if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        int64_t nref_pad = (int64_t)p2.n_tiles * cmk2::BR;
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, words);
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, words);
+        hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3);
+        hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                           p2.KSTEPS, nref_pad, 1, metric, scale3, Rp, (float *)nullptr, words);
+        hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
+                           p2.KSTEPS, p2.nq_pad, 0, metric, scale3, Qp, qnorm, (unsigned *)nullptr);
+        CM_HIP(h, hipGetLastError());
+        cm_mark(h, 1);
+        cmk2::P1Args a;
+        a.Q = reinterpret_cast<const _Float16 *>(Qp);
+        a.R = Rp;
+        a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
+        a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
+        a.dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
+        a.ctr = nullptr;
+        g_dbg_ctr = nullptr;
+        if (a.dbg & 4) {
+            static unsigned long long *d_ctr = nullptr;
+            if (!d_ctr) (void)hipMalloc((void **)&d_ctr, 64);
+            (void)hipMemsetAsync(d_ctr, 0, 64, st);
+            a.ctr = d_ctr;
+            g_dbg_ctr = d_ctr;
+        }
+        CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
+        // split-fp16 error bound: f32 accumulation of 3*K+1 terms (taken at 2^-22 per term to be safe about the
+        // MFMA's internal summation) + dropped lo*lo term + representation residuals
+        c_eps = 5.5e-5f;
+    } else {
+        float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
+        float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
+        if (!Rp || !Qp) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                            p.KP, p.nref_pad, 1, metric, Rp, (float *)nullptr, words);
         hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, p.KP,
                            p.nq_pad, 0, metric, Qp, qnorm, (unsigned *)nullptr);
-    }
-    CM_HIP(h, hipGetLastError());
-    cm_mark(h, 1);
-    {
+        CM_HIP(h, hipGetLastError());
+        cm_mark(h, 1);
         dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
         cm_status s = CM_E_INTERNAL;
         bool ok = cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
@@ -336,13 +545,21 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                   cm_p1_launch_g3(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s);
         if (!ok) CM_FAIL(h, CM_E_INTERNAL, "k-NN: no phase-1 instantiation for KP=%d", p.KP);
         CM_TRY(s);
+        // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
+        c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
     }
     cm_mark(h, 2);
-    // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
-    float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
+    if (f16 && g_dbg_ctr) {
+        unsigned long long hc[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hc, g_dbg_ctr, 64, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu\n",
+                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5]);
+    }
+    if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
     hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                       p.S, p.Kc, k, metric, form, qnorm, words, c_eps, idx_offset, flags, d_out_dist, d_out_idx,
-                       flag_list, (int *)(words + 2), bound);
+                       S, Kc, k, metric, form, qnorm, words, c_eps, f16 ? scale3 : (const float *)nullptr, idx_offset, flags,
+                       d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
     cm_mark(h, 3);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
@@ -351,25 +568,32 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     cm_mark(h, 4);
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    h->knn_stats[1] = p.Kc;
-    h->knn_stats[2] = p.S;
-    h->knn_stats[3] = 0;
+    h->knn_stats[1] = Kc;
+    h->knn_stats[2] = S;
+    h->knn_stats[3] = f16 ? 2 : 1;
     return CM_OK;
 }
 
 }  // namespace
 
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t /*dtype*/) {
-    int KP = pick_kp(d);
-    if (KP < 0) KP = 260;
     int slack = k / 4 > 8 ? k / 4 : 8;
     int Kc = k + slack;
-    int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
-    int64_t nq_pad = (nq + 127) / 128 * 128;
-    size_t b = 0;
-    b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP) + cm_align(4 * nq_pad);
-    b += cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) + cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1));
-    return b + 4096;
+    int64_t nq_pad = (nq + 511) / 512 * 512;
+    size_t b = cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
+               cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096;
+    if (use_f16_path(d, k)) {
+        int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
+        int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
+        b += cm_align((size_t)n_tiles * cmk2::tile_bytes(KSTEPS)) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
+        b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * Kc) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * 2 * cmk2::CL);
+    } else {
+        int KP = pick_kp(d);
+        if (KP < 0) KP = 260;
+        int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
+        b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP);
+    }
+    return b;
 }
 
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,

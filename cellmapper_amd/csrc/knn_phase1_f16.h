@@ -1,0 +1,450 @@
+// Phase 1 (v2) of the exact k-NN: split-fp16 MFMA distance GEMM fused with a per-query top-K' candidate filter.
+//
+// Same contract as knn_phase1.h (certified superset filter: K' candidate rows per query + threshold tau, consumed by
+// knn_rerank), but the contraction runs on v_mfma_f32_32x32x16_f16 -- 16x the per-instruction MAC count of the
+// f32-input MFMA -- with every operand split into two fp16 halves:
+//     x*sc = hi + lo + r,   hi = fp16(x*sc),  lo = fp16(x*sc - hi),  |r| <= 2^-22 |x*sc|      (sc = power of two)
+//     q.y ~= qh.yh + qh.yl + ql.yh            (three MFMA chains; the dropped ql.yl term is <= 2^-22 |q||y|)
+// fp16 x fp16 products are exact in the f32 accumulator, so the filter value differs from the float64 value by a bound
+// of the same order as the f32 path's; the float64 re-rank + certificate make the result exact.
+//
+// gfx950 mapping
+//   * workgroup = 4 waves, two workgroups per CU (2 waves per SIMD; a stalled workgroup -- merge/prune, barrier --
+//     leaves the matrix pipe to the other one), persistent over (query block, reference split) work items;
+//   * wave tile = 32 reference rows x 64 queries: two 32x32 accumulators share one A (reference) fragment; the 64
+//     queries' hi/lo fragments (B operand) stay in VGPRs for the whole pass;
+//   * |y|^2 rides in three spare feature slots as fp16 digits (exact to 2^-33), -2 and the scale are folded into
+//     the rows, so the accumulator is the ranking value |y|^2 - 2 q.y with no epilogue arithmetic;
+//   * 128-row reference tiles are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4; no VGPR staging, no
+//     ds_write pass) into a 2-deep ring, one s_barrier per tile; the global tile image is byte-identical to the LDS
+//     image, rows XOR-swizzled by 16-byte granule so the fragment ds_read_b128s are bank-conflict free;
+//   * queries sit on the accumulator's lane (column) index: each lane owns 2 queries x 16 rows per tile, the filter is
+//     a v_min3 tree + one compare against a threshold register; a passing value is appended with a plain 8-byte store
+//     to a LANE-PRIVATE global buffer (no atomics; L2-resident); when a lane's buffer could overflow the wave merges
+//     it with the query's kept list (rank-by-counting in LDS), keeps the K' smallest and tightens the threshold.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace cmk2 {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CM2_BR
+#define CM2_BR 128
+#endif
+#ifndef CM2_NW
+#define CM2_NW 4
+#endif
+constexpr int BR = CM2_BR;  // reference rows per LDS tile
+constexpr int NW = CM2_NW;  // waves per workgroup (two workgroups per CU when NW = 4)
+constexpr int NT = NW * 64;
+constexpr int QB = NW * 64;  // queries per workgroup pass
+constexpr int CL = 96;       // lane-private append buffer capacity (entries)
+
+__host__ __device__ constexpr int row_bytes(int KSTEPS) { return KSTEPS * 16 * 2 * 2; }  // hi + lo halves
+__host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes(KSTEPS); }
+// |y|^2 rides in three spare feature slots as fp16 "digits": sc^2|y|^2 = a1*2^15 + a2*2^4 + a3*2^-7 (query side holds
+// the three constants), so it is summed by the hi*hi MFMA chain itself -- no accumulator initialisation, no extra reads.
+constexpr int NORM_SLOTS = 3;
+// XOR applied to a row's 16-byte granule index (row stride is a power of two: spread rows over the 16 LDS slots)
+__host__ __device__ constexpr int swz(int row, int KSTEPS) {
+    return KSTEPS >= 4 ? (row & 15) : ((row >> 1) & 7);  // KSTEPS=2: 128-byte rows, two rows per 256-byte bank row
+}
+__host__ inline size_t lds_bytes(int KSTEPS, int scratch_entries) {
+    return 2 * size_t(tile_bytes(KSTEPS)) + size_t(NW) * scratch_entries * 8 + 64;
+}
+
+struct P1Args {
+    const _Float16 *Q;     // [nq_pad][2*K] prepared query rows (hi | lo), scaled
+    const char *R;         // [n_tiles] tile images: BR swizzled rows (hi | lo of [-2*sc*y, norm digits, 0..])
+    int n_tiles, tiles_per_split, S;
+    int nqb;               // query blocks of QB rows
+    int Kc;                // candidates kept per (query, split)
+    int *cand;             // [nq_pad][S][Kc]
+    float *cthr;           // [nq_pad][S]   (scaled units)
+    uint2 *kept;           // [gridDim.x][NW][64][Kc]    per-resident-wave kept lists
+    uint2 *lbuf;           // [gridDim.x][NW][64][2][CL] lane-private append buffers
+    int dbg;               // timing experiments only (CELLMAP_DBG): 1 = never append, 2 = skip the filter, 4 = counters
+    unsigned long long *ctr;  // [8] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
+};
+
+__device__ __forceinline__ uint2 ld_fresh(const uint2 *p) {
+    // L1-bypassing load: the wave reads back entries it stored earlier (stores are write-through to L2)
+    unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
+}
+
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;  // plain v_min3_f32: no canonicalising v_max pair like fminf() lowers to; NaNs cannot occur here
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Merge one query's kept list with its two lane buffers and keep the Kc smallest (value, row) pairs (unordered).
+// Wave-uniform arguments; all 64 lanes participate; at most 4 entries per lane live in registers (n <= 256).
+// Selection is a 32-step radix select on the order-preserving integer image of the float values (ballot + popcount
+// per step) instead of a sort; ties at the K'-th value are broken arbitrarily, which keeps the filter invariant
+// (every discarded entry is >= the new threshold).  Returns the new kept count; *thr_out is updated when full.
+__device__ __forceinline__ unsigned f2key(float v) {
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+template <int E>
+__device__ __forceinline__ int wave_merge_prune_e(const uint2 *kept_src, int nk, const uint2 *b0, int n0, const uint2 *b1,
+                                                  int n1, int Kc, uint2 *dst_pairs, int *dst_rows, float *thr_out, int lane) {
+    const int n = nk + n0 + n1;
+    unsigned key[E], row[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        valid[e] = i < n;
+        key[e] = 0xffffffffu;
+        row[e] = 0;
+        if (valid[e]) {
+            const uint2 *src = i < nk ? kept_src + i : (i < nk + n0 ? b0 + (i - nk) : b1 + (i - nk - n0));
+            uint2 x = ld_fresh(src);
+            key[e] = f2key(__uint_as_float(x.x));
+            row[e] = x.y;
+        }
+    }
+    unsigned kth = 0xffffffffu;  // n <= Kc: keep everything
+    if (n > Kc) {
+        // all keys share their leading bits (the values sit in a narrow band below the old threshold): skip them
+        unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            kmin = valid[e] ? (key[e] < kmin ? key[e] : kmin) : kmin;
+            kmax = valid[e] ? (key[e] > kmax ? key[e] : kmax) : kmax;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        const unsigned diff = kmin ^ kmax;
+        const int hb = diff ? 31 - __clz(diff) : -1;  // highest bit in which the keys differ
+        unsigned prefix = hb >= 31 ? 0u : (kmin & ~((2u << (hb < 0 ? 0 : hb)) - 1u));
+        if (hb < 0) prefix = kmin;
+        int remaining = Kc;  // rank (1-based) of the wanted key among the entries that match `prefix` so far
+        for (int bit = hb; bit >= 0; --bit) {
+            const unsigned himask = bit == 31 ? 0u : ~((2u << bit) - 1u);
+            int cnt0 = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                bool m = valid[e] && ((key[e] & himask) == prefix) && !((key[e] >> bit) & 1u);
+                cnt0 += __popcll(__ballot(m));
+            }
+            if (remaining > cnt0) { prefix |= (1u << bit); remaining -= cnt0; }
+        }
+        kth = prefix;
+    }
+    // compaction: all entries below the K'-th key, then as many equal ones as still fit
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        bool less = valid[e] && (n <= Kc || key[e] < kth);
+        unsigned long long b = __ballot(less);
+        if (less) {
+            int p = pos + __popcll(b & ((1ull << lane) - 1ull));
+            if (dst_pairs) dst_pairs[p] = make_uint2(__float_as_uint(key2f(key[e])), row[e]);
+            if (dst_rows) dst_rows[p] = (int)row[e];
+        }
+        pos += __popcll(b);
+    }
+    if (n > Kc) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            bool eq = valid[e] && key[e] == kth;
+            unsigned long long b = __ballot(eq);
+            int p = pos + __popcll(b & ((1ull << lane) - 1ull));
+            if (eq && p < Kc) {
+                if (dst_pairs) dst_pairs[p] = make_uint2(__float_as_uint(key2f(key[e])), row[e]);
+                if (dst_rows) dst_rows[p] = (int)row[e];
+            }
+            pos += __popcll(b);
+        }
+        *thr_out = key2f(kth);
+        return Kc;
+    }
+    return n;
+}
+__device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 *kept_src, int nk, const uint2 *b0, int n0,
+                                                const uint2 *b1, int n1, int Kc, uint2 *dst_pairs, int *dst_rows,
+                                                float *thr_out, int lane) {
+    if (nk + n0 + n1 <= 128) return wave_merge_prune_e<2>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
+    return wave_merge_prune_e<4>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
+}
+
+#define CM2_AS1 __attribute__((address_space(1)))
+#define CM2_AS3 __attribute__((address_space(3)))
+
+template <int KSTEPS>
+__global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
+    constexpr int K = KSTEPS * 16;
+    constexpr int ROWB = row_bytes(KSTEPS);
+    constexpr int GRAN = ROWB / 16;        // granules per row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
+    constexpr int TILEB = tile_bytes(KSTEPS);
+    constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
+    constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *ring = smem;                                            // [2][TILEB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    uint2 *wsc = nullptr;
+    uint2 *wkept = a.kept + (size_t(blockIdx.x) * NW + wave) * 64 * a.Kc;
+    uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NW + wave) * 64 * 2 * CL;
+
+    // Asynchronous tile staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPRs, no ds_write pass.
+    // The tile image in global memory is byte-for-byte the LDS image (rows pre-swizzled by prep_rows_f16), so every
+    // wave-instruction copies one contiguous KiB.  Wave w moves pieces w, w+NW, ...
+#define CM2_DMA_TILE(t_, buf_)                                                                                  \
+    {                                                                                                           \
+        const char *gsrc_ = a.R + (size_t)(t_) * TILEB + lane * 16;                                             \
+        unsigned char *ldst_ = ring + (buf_) * TILEB;                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < (NCHUNK + NW - 1) / NW; ++q_) {                                 \
+            const int piece_ = wave + q_ * NW;                                                                  \
+            if (piece_ < NCHUNK)                                                                                \
+                __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + piece_ * 1024),                 \
+                                                 (CM2_AS3 void *)(ldst_ + piece_ * 1024), 16, 0, 0);            \
+        }                                                                                                       \
+    }
+
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
+    const int n_work = a.nqb * a.S;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int qb = work / a.S, split = work - qb * a.S;
+        const int t0 = split * a.tiles_per_split;
+        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        const int64_t qbase = (int64_t)qb * QB + wave * 64;
+
+        // ---- query fragments (B operand): lane (c,hh), k-step s -> granule 2s+hh of the hi / lo half
+        half8 qh[2][KSTEPS], ql[2][KSTEPS];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const _Float16 *qrow = a.Q + (qbase + j * 32 + c) * (2 * K);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                qh[j][s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
+                ql[j][s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
+            }
+        }
+        const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
+        float thr[2] = {thr_init, thr_init};
+        int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
+        int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
+
+        __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
+        if (t0 < t1) CM2_DMA_TILE(t0, t0 & 1);
+
+        // Software pipeline: the filter of sub-tile i-1 (VALU) is issued in the shadow of sub-tile i's MFMA chain.
+        f32x16 p0, p1;          // accumulators of the previous sub-tile, waiting to be filtered (+inf = nothing pending)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p0[e] = INFINITY; p1[e] = INFINITY; }
+        int prbase = 0;         // first reference row (+4*hh) of the previous sub-tile
+
+#define CM2_MIN16(A, OUT)                                                                                      \
+    {                                                                                                          \
+        float m0_ = vmin3((A)[0], (A)[1], (A)[2]), m1_ = vmin3((A)[3], (A)[4], (A)[5]);                        \
+        float m2_ = vmin3((A)[6], (A)[7], (A)[8]), m3_ = vmin3((A)[9], (A)[10], (A)[11]);                      \
+        float m4_ = vmin3((A)[12], (A)[13], (A)[14]);                                                          \
+        OUT = vmin3(vmin3(m0_, m1_, m2_), vmin3(m3_, m4_, (A)[15]), m0_);                                      \
+    }
+#define CM2_APPEND1(V, RR, RB)                                                                                 \
+    if ((V) < tj_) {                                                                                           \
+        mybuf_[cj_] = make_uint2(__float_as_uint(V), (unsigned)((RB) + ((RR) & 3) + 8 * ((RR) >> 2)));         \
+        ++cj_;                                                                                                 \
+    }
+#define CM2_APPEND3(A, R0, RB)                                                                                 \
+    if (vmin3((A)[R0], (A)[(R0) + 1], (A)[(R0) + 2]) < tj_) {                                                  \
+        CM2_APPEND1((A)[R0], R0, RB) CM2_APPEND1((A)[(R0) + 1], (R0) + 1, RB) CM2_APPEND1((A)[(R0) + 2], (R0) + 2, RB) \
+    }
+        // rare path: a value of the previous sub-tile beats a threshold.  Tests are hierarchical (accumulator ->
+        // group of three registers -> register) because typically ONE value in ONE lane passes.
+#define CM2_FILTER(P0, P1, M0, M1, RB)                                                                         \
+    {                                                                                                          \
+        const bool pass0_ = (M0) < thr[0], pass1_ = (M1) < thr[1];                                             \
+        if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
+            if (a.dbg & 4) ++c_br;                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+                const f32x16 &acc = j ? (P1) : (P0);                                                           \
+                if (j ? pass1_ : pass0_) {                                                                     \
+                    uint2 *mybuf_ = wlbuf + (size_t)((j * 32 + c) * 2 + hh) * CL;                              \
+                    const float tj_ = thr[j];                                                                  \
+                    int cj_ = cnt[j];                                                                          \
+                    CM2_APPEND3(acc, 0, RB) CM2_APPEND3(acc, 3, RB) CM2_APPEND3(acc, 6, RB)                    \
+                    CM2_APPEND3(acc, 9, RB) CM2_APPEND3(acc, 12, RB) CM2_APPEND1(acc[15], 15, RB)              \
+                    cnt[j] = cj_;                                                                              \
+                }                                                                                              \
+            }                                                                                                  \
+            const bool any_full = (cnt[0] > CL - 16) || (cnt[1] > CL - 16);                                    \
+            if (__ballot(any_full) != 0ull) {                                                                  \
+                unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                   \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own appends visible to own L2 reads */     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
+                    unsigned long long need = __ballot(cnt[j] > CL - 16);                                      \
+                    need = (need | (need >> 32)) & 0xffffffffull;                                              \
+                    while (need) {                                                                             \
+                        const int ql_ = __ffsll((long long)need) - 1;                                          \
+                        need &= need - 1;                                                                      \
+                        const int wq = j * 32 + ql_;                                                           \
+                        const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
+                        float tq = __shfl(thr[j], ql_);                                                        \
+                        uint2 *kq = wkept + (size_t)wq * a.Kc;                                                 \
+                        int nn = wave_merge_prune(wsc, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,              \
+                                                  wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
+                        if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }                              \
+                        if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                           \
+                    }                                                                                          \
+                }                                                                                              \
+                if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                 \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+        // A-operand fragments and row norms of one 32-row sub-tile (conflict-free swizzled ds_read_b128)
+#define CM2_LOAD_AH(TILE, ST)                                                                                  \
+    {                                                                                                          \
+        const int r_ = (ST) * 32 + c;                                                                          \
+        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
+        const int f_ = swz(r_, KSTEPS);                                                                        \
+        _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
+            ah[s] = *reinterpret_cast<const half8 *>(rowp_ + (((2 * s + hh)) ^ f_) * 16);                      \
+    }
+#define CM2_LOAD_AL_YN(TILE, ST)                                                                               \
+    {                                                                                                          \
+        const int r_ = (ST) * 32 + c;                                                                          \
+        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
+        const int f_ = swz(r_, KSTEPS);                                                                        \
+        _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
+            al[s] = *reinterpret_cast<const half8 *>(rowp_ + ((GRAN / 2 + 2 * s + hh) ^ f_) * 16);             \
+    }
+
+        int next_refresh = t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
+        for (int t = t0; t < t1; ++t) {
+            // this wave's DMA pieces of tile t (issued one tile ago) have landed; after the barrier everyone's have,
+            // and every wave is done reading tile t-1, whose buffer the next DMA overwrites.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < t1) CM2_DMA_TILE(t + 1, (t + 1) & 1);
+            const unsigned char *tile = ring + (t & 1) * TILEB;
+            half8 ah[KSTEPS], al[KSTEPS];
+            CM2_LOAD_AH(tile, 0);
+            CM2_LOAD_AL_YN(tile, 0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                // accumulator registers map to rows (r&3) + 8*(r>>2) + 4*hh of the sub-tile, one query per lane column
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[0][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[1][s], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[0][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[1][s], acc1, 0, 0, 0);
+                }
+                // the hi fragment is dead: fetch the next sub-tile's while the lo products run
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NST) CM2_LOAD_AH(tile, st + 1);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NST) CM2_LOAD_AL_YN(tile, st + 1);
+                // min-trees of the PREVIOUS sub-tile: independent of the MFMA chain above, issued in its shadow
+                float mp0, mp1;
+                CM2_MIN16(p0, mp0);
+                CM2_MIN16(p1, mp1);
+                if (!(a.dbg & 2)) CM2_FILTER(p0, p1, mp0, mp1, prbase);
+                p0 = acc0;
+                p1 = acc1;
+                prbase = t * BR + st * 32 + 4 * hh;
+            }
+            // Scheduled threshold refresh.  All waves of the workgroup reach this point at the same tile, so nobody
+            // waits at the next barrier for a straggler (overflow-triggered merges above are the rare exception).
+            // With refreshes after 2, 4, 8, ... tiles a query appends ~K' entries per doubling of scanned rows.
+            if (t == next_refresh && !(a.dbg & 3)) {
+                next_refresh = t0 + 2 * (t - t0 + 1) - 1;
+                unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    unsigned long long need = __ballot(cnt[j] > 0);
+                    need = (need | (need >> 32)) & 0xffffffffull;
+                    while (need) {
+                        const int ql_ = __ffsll((long long)need) - 1;
+                        need &= need - 1;
+                        const int wq = j * 32 + ql_;
+                        const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_);
+                        float tq = __shfl(thr[j], ql_);
+                        uint2 *kq = wkept + (size_t)wq * a.Kc;
+                        int nn = wave_merge_prune(wsc, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,
+                                                  wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane);
+                        if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }
+                        if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }
+                    }
+                }
+                if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;
+            }
+        }
+        if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
+            float mp0, mp1;
+            CM2_MIN16(p0, mp0);
+            CM2_MIN16(p1, mp1);
+            CM2_FILTER(p0, p1, mp0, mp1, prbase);
+        }
+        if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
+#undef CM2_FILTER
+#undef CM2_MIN16
+#undef CM2_APPEND1
+#undef CM2_APPEND3
+#undef CM2_LOAD_AH
+#undef CM2_LOAD_AL_YN
+
+        // ---- final: merge every query's lists, emit K' candidate rows (-1 padded) and the threshold
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            for (int ql_ = 0; ql_ < 32; ++ql_) {
+                const int wq = j * 32 + ql_;
+                const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_);
+                float tq = __shfl(thr[j], ql_);
+                const int64_t qg = qbase + wq;
+                int *dst = a.cand + (qg * a.S + split) * a.Kc;
+                int nn = wave_merge_prune(wsc, wkept + (size_t)wq * a.Kc, nk, wlbuf + (size_t)(wq * 2) * CL, n0,
+                                          wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, nullptr, dst, &tq, lane);
+                for (int i = nn + lane; i < a.Kc; i += 64) dst[i] = -1;
+                if (lane == 0) a.cthr[qg * a.S + split] = tq;
+            }
+        }
+    }
+#undef CM2_DMA_TILE
+    if ((a.dbg & 4) && lane == 0) {
+        atomicAdd(&a.ctr[0], c_br);
+        atomicAdd(&a.ctr[1], c_app);
+        atomicAdd(&a.ctr[2], c_pr);
+        atomicAdd(&a.ctr[3], c_prcyc);
+        atomicAdd(&a.ctr[4], __builtin_amdgcn_s_memtime() - c_t0);
+        atomicAdd(&a.ctr[5], 1ull);
+    }
+}
+
+}  // namespace cmk2

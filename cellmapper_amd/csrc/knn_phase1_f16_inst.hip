@@ -1,0 +1,20 @@
+// Instantiations + launcher of the split-fp16 phase-1 kernel (knn_phase1_f16.h).
+#include "cm_internal.h"
+#include "knn_phase1_f16.h"
+
+template <int KSTEPS>
+static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    auto kern = cmk2::knn_cand_f16<KSTEPS>;
+    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
+    switch (KSTEPS) {
+    case 2: return launch_f16<2>(h, grid, lds, a);
+    case 4: return launch_f16<4>(h, grid, lds, a);
+    }
+    CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d", KSTEPS);
+}
