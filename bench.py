@@ -160,7 +160,7 @@ def main():
             "metric": "query cells/s end-to-end (k-NN+kernel+transfer)",
             "value": value, "unit": "query cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16x2-split MFMA filter + f64 exact re-rank" if fb["lowd_path"] == 2 else "f32 MFMA filter + f64 exact re-rank",
+            "dtype": "f16" if fb["lowd_path"] == 2 else "f32",
             "data": "synthetic",
             "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.kernel} kernel, "
                                    f"{a.ncat}-class label transfer (BASELINE configs[1]); reference rows sharded over "

@@ -12,6 +12,7 @@
 #include <string.h>
 
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 
 // phase-1 instantiation groups (knn_phase1_inst.hip)
 #define CM_DECL_P1(g)                                                                                                  \
@@ -196,6 +197,28 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
     }
 }
 
+// X [n,d] -> float32 rows [n_pad][d] for the low-d kernel (cosine: normalised); padded reference rows are +inf.
+template <typename T>
+__global__ void prep_rows_lowd(const T *__restrict__ X, int64_t n, int d, int64_t n_pad, int is_ref, int metric,
+                               float *__restrict__ P) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float *out = P + i * d;
+    if (i < n) {
+        const T *x = X + i * d;
+        double nscale = 1.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+            double nrm = sqrt(s);
+            nscale = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+        for (int c = 0; c < d; ++c) out[c] = (float)((double)x[c] * nscale);
+    } else {
+        for (int c = 0; c < d; ++c) out[c] = is_ref ? INFINITY : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ exact float64 pair value --------
 // The value that orders neighbours and (after sqrt) is returned, following sklearn's arithmetic exactly as the
 // CPU oracle restates it (oracle/cm_oracle.c: cmo_knn_euclidean):
@@ -285,11 +308,23 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         for (int s = 0; s < S; ++s) tau = fminf(tau, cthr[i * S + s]);
         if (scale3) tau *= scale3[2];  // phase-1 values were computed on rows scaled by sc: back to input units
         bool certified = true;
-        if (tau < INFINITY) {
+        if (tau < INFINITY && c_eps >= 0.f) {
             double sk = (metric == CM_METRIC_COSINE) ? (2.0 * kth - 1.0) : (kth - xn);
             double ymax2 = (double)__uint_as_float(gmax[0]), ymax = (double)__uint_as_float(gmax[1]);
             double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30);
             certified = sk < (double)tau - eps;
+        } else if (tau < INFINITY) {
+            // low-d kernel: phase-1 value is the full direct squared distance sum (q-y)^2 in fp32; relative error
+            // -c_eps, plus the rounding of float64 inputs to fp32 (2^-24 * max|coordinate| per coordinate)
+            double sk = (metric == CM_METRIC_COSINE) ? 2.0 * kth : kth;
+            // GEMM-form distances requested for d <= 15 (k >= n_ref/2): the float64 GEMM-form value differs from the
+            // direct-form one by ~1e-16 (|q|^2+|y|^2); inflate conservatively
+            if (metric != CM_METRIC_COSINE && form != CM_FORM_DIRECT) sk = kth * (1.0 + 1e-9) + 1e-9 * xn;
+            double crel = (double)(-c_eps);
+            double dlt = sizeof(T) == 8 ? 2.0 * 5.9604645e-8 * (double)__uint_as_float(gmax[4]) : 0.0;
+            double big = fmax(sk, (double)tau);
+            double eps = crel * big + 2.0 * dlt * sqrt((double)d) * sqrt(big) + (double)d * dlt * dlt;
+            certified = sk + eps < (double)tau - eps;
         }
         if (!certified || (flags & CM_KNN_FORCE_FALLBACK)) {
             int pos = atomicAdd(flag_cnt, 1);
@@ -431,24 +466,28 @@ struct KnnPlan2 {
 
 int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
 
-bool use_f16_path(int d, int k) {
+// phase-1 kernel choice: 2 = low-d VALU direct form (d <= 15), 1 = split-fp16 MFMA (d <= 61), 0 = f32-input MFMA
+int phase1_path(int d, int k) {
     const char *e = getenv("CELLMAP_PHASE1");
-    if (e && !strcmp(e, "f32")) return false;
-    if (k + knn_slack(k) + 2 * cmk2::CL > 256) return false;  // the in-register merge handles 256 entries per query
-    return d + cmk2::NORM_SLOTS <= 64;                        // needs three spare feature slots for the norm digits
+    if (e && !strcmp(e, "f32")) return 0;
+    if (k + knn_slack(k) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
+    if (d <= 15 && !(e && !strcmp(e, "f16"))) return 2;
+    return d + cmk2::NORM_SLOTS <= 64 ? 1 : 0;            // needs three spare feature slots for the norm digits
 }
+bool use_f16_path(int d, int k) { return phase1_path(d, k) != 0; }
 
-cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan2 *p) {
+cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int path, KnnPlan2 *p) {
     p->KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
     int slack = k / 4 > 8 ? k / 4 : 8;
     p->Kc = k + slack;
-    p->tileb = cmk2::tile_bytes(p->KSTEPS);
-    p->rowb = cmk2::row_bytes(p->KSTEPS);
-    p->lds = cmk2::lds_bytes(p->KSTEPS, 0);
+    const int tile_rows = path == 2 ? cmk2::BRL : cmk2::BR;
+    p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d) : (size_t)cmk2::tile_bytes(p->KSTEPS);
+    p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
+    p->lds = 2 * p->tileb + 64;
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
     p->nq_pad = (nq + cmk2::QB - 1) / cmk2::QB * cmk2::QB;
     p->nqb = (int)(p->nq_pad / cmk2::QB);
-    p->n_tiles = (int)((n_ref + cmk2::BR - 1) / cmk2::BR);
+    p->n_tiles = (int)((n_ref + tile_rows - 1) / tile_rows);
     int ncu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
@@ -473,12 +512,13 @@ template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
-    const bool f16 = use_f16_path(d, k);
+    const int path = phase1_path(d, k);
+    const bool f16 = path != 0;  // either of the persistent-workgroup kernels (split-fp16 MFMA or low-d VALU)
     KnnPlan p;
     KnnPlan2 p2;
     int Kc, S;
     int64_t nq_pad;
-    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
+    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, path, &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
     else { CM_TRY(make_plan(h, n_ref, nq, d, k, &p)); Kc = p.Kc; S = p.S; nq_pad = p.nq_pad; }
     float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
     int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc);
@@ -498,14 +538,21 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * p2.Kc);
         uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * 2 * cmk2::CL);
         if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-        int64_t nref_pad = (int64_t)p2.n_tiles * cmk2::BR;
+        int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::BRL : cmk2::BR);
         hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, words);
         hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, words);
-        hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3);
-        hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                           p2.KSTEPS, nref_pad, 1, metric, scale3, Rp, (float *)nullptr, words);
-        hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                           p2.KSTEPS, p2.nq_pad, 0, metric, scale3, Qp, qnorm, (unsigned *)nullptr);
+        if (path == 2) {
+            hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                               nref_pad, 1, metric, reinterpret_cast<float *>(Rp));
+            hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
+                               p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp));
+        } else {
+            hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3);
+            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                               p2.KSTEPS, nref_pad, 1, metric, scale3, Rp, (float *)nullptr, words);
+            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, Qp, qnorm, (unsigned *)nullptr);
+        }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
         cmk2::P1Args a;
@@ -523,10 +570,13 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             a.ctr = d_ctr;
             g_dbg_ctr = d_ctr;
         }
-        CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
+        if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
+        else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
         // split-fp16 error bound: f32 accumulation of 3*K+1 terms (taken at 2^-22 per term to be safe about the
         // MFMA's internal summation) + dropped lo*lo term + representation residuals
         c_eps = 5.5e-5f;
+        // low-d kernel: relative bound of the fp32 direct sum (sign of c_eps selects the certificate form)
+        if (path == 2) c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;
     } else {
         float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
         float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
@@ -558,7 +608,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     }
     if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
     hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                       S, Kc, k, metric, form, qnorm, words, c_eps, f16 ? scale3 : (const float *)nullptr, idx_offset, flags,
+                       S, Kc, k, metric, form, qnorm, words, c_eps, path == 1 ? scale3 : (const float *)nullptr, idx_offset, flags,
                        d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
     cm_mark(h, 3);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
@@ -570,7 +620,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = Kc;
     h->knn_stats[2] = S;
-    h->knn_stats[3] = f16 ? 2 : 1;
+    h->knn_stats[3] = path == 1 ? 2 : (path == 2 ? 3 : 1);
     return CM_OK;
 }
 
@@ -585,7 +635,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
-        b += cm_align((size_t)n_tiles * cmk2::tile_bytes(KSTEPS)) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
+        b += cm_align((size_t)n_tiles * cmk2::tile_bytes(KSTEPS) + 65536) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
         b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * Kc) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * 2 * cmk2::CL);
     } else {
         int KP = pick_kp(d);

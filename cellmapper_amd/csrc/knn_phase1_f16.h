@@ -182,9 +182,115 @@ __device__ __forceinline__ int wave_merge_prune_e(const uint2 *kept_src, int nk,
 __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 *kept_src, int nk, const uint2 *b0, int n0,
                                                 const uint2 *b1, int n1, int Kc, uint2 *dst_pairs, int *dst_rows,
                                                 float *thr_out, int lane) {
-    if (nk + n0 + n1 <= 128) return wave_merge_prune_e<2>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
-    return wave_merge_prune_e<4>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
+    const int n = nk + n0 + n1;
+    if (n <= 128) return wave_merge_prune_e<2>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
+    if (n <= 256) return wave_merge_prune_e<4>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
+    return wave_merge_prune_e<8>(kept_src, nk, b0, n0, b1, n1, Kc, dst_pairs, dst_rows, thr_out, lane);
 }
+
+// ---- shared by the MFMA and the low-d kernels (they use the same lane <-> (query, row) mapping and variable names) --
+#define CM2_MIN16(A, OUT)                                                                                      \
+    {                                                                                                          \
+        float m0_ = vmin3((A)[0], (A)[1], (A)[2]), m1_ = vmin3((A)[3], (A)[4], (A)[5]);                        \
+        float m2_ = vmin3((A)[6], (A)[7], (A)[8]), m3_ = vmin3((A)[9], (A)[10], (A)[11]);                      \
+        float m4_ = vmin3((A)[12], (A)[13], (A)[14]);                                                          \
+        OUT = vmin3(vmin3(m0_, m1_, m2_), vmin3(m3_, m4_, (A)[15]), m0_);                                      \
+    }
+#define CM2_APPEND1(V, RR, RB)                                                                                 \
+    if ((V) < tj_) {                                                                                           \
+        mybuf_[cj_] = make_uint2(__float_as_uint(V), (unsigned)((RB) + ((RR) & 3) + 8 * ((RR) >> 2)));         \
+        ++cj_;                                                                                                 \
+    }
+#define CM2_APPEND3(A, R0, RB)                                                                                 \
+    if (vmin3((A)[R0], (A)[(R0) + 1], (A)[(R0) + 2]) < tj_) {                                                  \
+        CM2_APPEND1((A)[R0], R0, RB) CM2_APPEND1((A)[(R0) + 1], (R0) + 1, RB) CM2_APPEND1((A)[(R0) + 2], (R0) + 2, RB) \
+    }
+// rare path: a value of the previous sub-tile beats a threshold.  Tests are hierarchical (accumulator ->
+// group of three registers -> register) because typically ONE value in ONE lane passes.
+#define CM2_FILTER(P0, P1, M0, M1, RB)                                                                         \
+    {                                                                                                          \
+        const bool pass0_ = (M0) < thr[0], pass1_ = (M1) < thr[1];                                             \
+        if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
+            if (a.dbg & 4) ++c_br;                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+                const f32x16 &acc = j ? (P1) : (P0);                                                           \
+                if (j ? pass1_ : pass0_) {                                                                     \
+                    uint2 *mybuf_ = wlbuf + (size_t)((j * 32 + c) * 2 + hh) * CL;                              \
+                    const float tj_ = thr[j];                                                                  \
+                    int cj_ = cnt[j];                                                                          \
+                    CM2_APPEND3(acc, 0, RB) CM2_APPEND3(acc, 3, RB) CM2_APPEND3(acc, 6, RB)                    \
+                    CM2_APPEND3(acc, 9, RB) CM2_APPEND3(acc, 12, RB) CM2_APPEND1(acc[15], 15, RB)              \
+                    cnt[j] = cj_;                                                                              \
+                }                                                                                              \
+            }                                                                                                  \
+            const bool any_full = (cnt[0] > CL - 16) || (cnt[1] > CL - 16);                                    \
+            if (__ballot(any_full) != 0ull) {                                                                  \
+                unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                   \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own appends visible to own L2 reads */     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
+                    unsigned long long need = __ballot(cnt[j] > CL - 16);                                      \
+                    need = (need | (need >> 32)) & 0xffffffffull;                                              \
+                    while (need) {                                                                             \
+                        const int ql_ = __ffsll((long long)need) - 1;                                          \
+                        need &= need - 1;                                                                      \
+                        const int wq = j * 32 + ql_;                                                           \
+                        const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
+                        float tq = __shfl(thr[j], ql_);                                                        \
+                        uint2 *kq = wkept + (size_t)wq * a.Kc;                                                 \
+                        int nn = wave_merge_prune(wsc, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,              \
+                                                  wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
+                        if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }                              \
+                        if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                           \
+                    }                                                                                          \
+                }                                                                                              \
+                if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                 \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+// Scheduled threshold refresh.  All waves of the workgroup reach this point at the same tile, so nobody waits at
+// the next barrier for a straggler (overflow-triggered merges in CM2_FILTER are the rare exception).  With refreshes
+// after 2, 4, 8, ... tiles a query appends ~K' entries per doubling of scanned rows.
+#define CM2_REFRESH(T, T0)                                                                                     \
+    if ((T) == next_refresh && !(a.dbg & 3)) {                                                                 \
+        next_refresh = (T0) + 2 * ((T) - (T0) + 1) - 1;                                                        \
+        unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+            unsigned long long need = __ballot(cnt[j] > 0);                                                    \
+            need = (need | (need >> 32)) & 0xffffffffull;                                                      \
+            while (need) {                                                                                     \
+                const int ql_ = __ffsll((long long)need) - 1;                                                  \
+                need &= need - 1;                                                                              \
+                const int wq = j * 32 + ql_;                                                                   \
+                const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
+                float tq = __shfl(thr[j], ql_);                                                                \
+                uint2 *kq = wkept + (size_t)wq * a.Kc;                                                         \
+                int nn = wave_merge_prune(nullptr, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,                  \
+                                          wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
+                if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }                                      \
+                if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                                   \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                         \
+    }
+// Final merge of a work item: emit K' candidate rows (-1 padded) and the threshold of every query of the wave.
+#define CM2_FINAL()                                                                                            \
+    {                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+            for (int ql_ = 0; ql_ < 32; ++ql_) {                                                               \
+                const int wq = j * 32 + ql_;                                                                   \
+                const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
+                float tq = __shfl(thr[j], ql_);                                                                \
+                const int64_t qg = qbase + wq;                                                                 \
+                int *dst = a.cand + (qg * a.S + split) * a.Kc;                                                 \
+                int nn = wave_merge_prune(nullptr, wkept + (size_t)wq * a.Kc, nk, wlbuf + (size_t)(wq * 2) * CL, n0, \
+                                          wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, nullptr, dst, &tq, lane); \
+                for (int i = nn + lane; i < a.Kc; i += 64) dst[i] = -1;                                        \
+                if (lane == 0) a.cthr[qg * a.S + split] = tq;                                                  \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
 
 #define CM2_AS1 __attribute__((address_space(1)))
 #define CM2_AS3 __attribute__((address_space(3)))
@@ -256,64 +362,6 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         for (int e = 0; e < 16; ++e) { p0[e] = INFINITY; p1[e] = INFINITY; }
         int prbase = 0;         // first reference row (+4*hh) of the previous sub-tile
 
-#define CM2_MIN16(A, OUT)                                                                                      \
-    {                                                                                                          \
-        float m0_ = vmin3((A)[0], (A)[1], (A)[2]), m1_ = vmin3((A)[3], (A)[4], (A)[5]);                        \
-        float m2_ = vmin3((A)[6], (A)[7], (A)[8]), m3_ = vmin3((A)[9], (A)[10], (A)[11]);                      \
-        float m4_ = vmin3((A)[12], (A)[13], (A)[14]);                                                          \
-        OUT = vmin3(vmin3(m0_, m1_, m2_), vmin3(m3_, m4_, (A)[15]), m0_);                                      \
-    }
-#define CM2_APPEND1(V, RR, RB)                                                                                 \
-    if ((V) < tj_) {                                                                                           \
-        mybuf_[cj_] = make_uint2(__float_as_uint(V), (unsigned)((RB) + ((RR) & 3) + 8 * ((RR) >> 2)));         \
-        ++cj_;                                                                                                 \
-    }
-#define CM2_APPEND3(A, R0, RB)                                                                                 \
-    if (vmin3((A)[R0], (A)[(R0) + 1], (A)[(R0) + 2]) < tj_) {                                                  \
-        CM2_APPEND1((A)[R0], R0, RB) CM2_APPEND1((A)[(R0) + 1], (R0) + 1, RB) CM2_APPEND1((A)[(R0) + 2], (R0) + 2, RB) \
-    }
-        // rare path: a value of the previous sub-tile beats a threshold.  Tests are hierarchical (accumulator ->
-        // group of three registers -> register) because typically ONE value in ONE lane passes.
-#define CM2_FILTER(P0, P1, M0, M1, RB)                                                                         \
-    {                                                                                                          \
-        const bool pass0_ = (M0) < thr[0], pass1_ = (M1) < thr[1];                                             \
-        if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
-            if (a.dbg & 4) ++c_br;                                                                             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-                const f32x16 &acc = j ? (P1) : (P0);                                                           \
-                if (j ? pass1_ : pass0_) {                                                                     \
-                    uint2 *mybuf_ = wlbuf + (size_t)((j * 32 + c) * 2 + hh) * CL;                              \
-                    const float tj_ = thr[j];                                                                  \
-                    int cj_ = cnt[j];                                                                          \
-                    CM2_APPEND3(acc, 0, RB) CM2_APPEND3(acc, 3, RB) CM2_APPEND3(acc, 6, RB)                    \
-                    CM2_APPEND3(acc, 9, RB) CM2_APPEND3(acc, 12, RB) CM2_APPEND1(acc[15], 15, RB)              \
-                    cnt[j] = cj_;                                                                              \
-                }                                                                                              \
-            }                                                                                                  \
-            const bool any_full = (cnt[0] > CL - 16) || (cnt[1] > CL - 16);                                    \
-            if (__ballot(any_full) != 0ull) {                                                                  \
-                unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                   \
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own appends visible to own L2 reads */     \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
-                    unsigned long long need = __ballot(cnt[j] > CL - 16);                                      \
-                    need = (need | (need >> 32)) & 0xffffffffull;                                              \
-                    while (need) {                                                                             \
-                        const int ql_ = __ffsll((long long)need) - 1;                                          \
-                        need &= need - 1;                                                                      \
-                        const int wq = j * 32 + ql_;                                                           \
-                        const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
-                        float tq = __shfl(thr[j], ql_);                                                        \
-                        uint2 *kq = wkept + (size_t)wq * a.Kc;                                                 \
-                        int nn = wave_merge_prune(wsc, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,              \
-                                                  wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
-                        if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }                              \
-                        if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                           \
-                    }                                                                                          \
-                }                                                                                              \
-                if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                 \
-            }                                                                                                  \
-        }                                                                                                      \
-    }
         // A-operand fragments and row norms of one 32-row sub-tile (conflict-free swizzled ds_read_b128)
 #define CM2_LOAD_AH(TILE, ST)                                                                                  \
     {                                                                                                          \
@@ -378,32 +426,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 p1 = acc1;
                 prbase = t * BR + st * 32 + 4 * hh;
             }
-            // Scheduled threshold refresh.  All waves of the workgroup reach this point at the same tile, so nobody
-            // waits at the next barrier for a straggler (overflow-triggered merges above are the rare exception).
-            // With refreshes after 2, 4, 8, ... tiles a query appends ~K' entries per doubling of scanned rows.
-            if (t == next_refresh && !(a.dbg & 3)) {
-                next_refresh = t0 + 2 * (t - t0 + 1) - 1;
-                unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    unsigned long long need = __ballot(cnt[j] > 0);
-                    need = (need | (need >> 32)) & 0xffffffffull;
-                    while (need) {
-                        const int ql_ = __ffsll((long long)need) - 1;
-                        need &= need - 1;
-                        const int wq = j * 32 + ql_;
-                        const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_);
-                        float tq = __shfl(thr[j], ql_);
-                        uint2 *kq = wkept + (size_t)wq * a.Kc;
-                        int nn = wave_merge_prune(wsc, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,
-                                                  wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane);
-                        if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }
-                        if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }
-                    }
-                }
-                if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;
-            }
+            CM2_REFRESH(t, t0);
         }
         if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
             float mp0, mp1;
@@ -412,29 +435,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             CM2_FILTER(p0, p1, mp0, mp1, prbase);
         }
         if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
-#undef CM2_FILTER
-#undef CM2_MIN16
-#undef CM2_APPEND1
-#undef CM2_APPEND3
 #undef CM2_LOAD_AH
 #undef CM2_LOAD_AL_YN
 
-        // ---- final: merge every query's lists, emit K' candidate rows (-1 padded) and the threshold
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            for (int ql_ = 0; ql_ < 32; ++ql_) {
-                const int wq = j * 32 + ql_;
-                const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_);
-                float tq = __shfl(thr[j], ql_);
-                const int64_t qg = qbase + wq;
-                int *dst = a.cand + (qg * a.S + split) * a.Kc;
-                int nn = wave_merge_prune(wsc, wkept + (size_t)wq * a.Kc, nk, wlbuf + (size_t)(wq * 2) * CL, n0,
-                                          wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, nullptr, dst, &tq, lane);
-                for (int i = nn + lane; i < a.Kc; i += 64) dst[i] = -1;
-                if (lane == 0) a.cthr[qg * a.S + split] = tq;
-            }
-        }
+        CM2_FINAL();
     }
 #undef CM2_DMA_TILE
     if ((a.dbg & 4) && lane == 0) {
@@ -445,6 +449,96 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         atomicAdd(&a.ctr[4], __builtin_amdgcn_s_memtime() - c_t0);
         atomicAdd(&a.ctr[5], 1ull);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Low-dimensional variant (d <= 15, e.g. spatial coordinates): the candidate filter is computed on the VALU as the
+// DIRECT squared difference sum_c (q_c - y_c)^2 in fp32.  For such inputs the |y|^2 - 2q.y form loses everything to
+// cancellation (coordinates ~1e3, neighbour distances ~1), while the direct form has a purely RELATIVE error
+// (~(D+2)*2^-24), so the certificate in knn_rerank stays tight.  Same workgroup geometry, lane <-> (query, row)
+// mapping, candidate logs, merges and refresh schedule as knn_cand_f16; reference rows are plain [row][D] floats in
+// 512-row tiles copied by LDS-DMA, read back as half-wave broadcasts.
+constexpr int BRL = 512;  // reference rows per tile of the low-d kernel
+__host__ __device__ constexpr int lowd_tile_bytes(int D) { return BRL * D * 4; }
+
+template <int D>
+__global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
+    constexpr int TILEB = lowd_tile_bytes(D);
+    constexpr int NCHUNK = TILEB / 1024;
+    constexpr int NST = BRL / 32;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *ring = smem;  // [2][TILEB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    uint2 *wsc = nullptr;
+    uint2 *wkept = a.kept + (size_t(blockIdx.x) * NW + wave) * 64 * a.Kc;
+    uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NW + wave) * 64 * 2 * CL;
+    const float *Qf = reinterpret_cast<const float *>(a.Q);
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    (void)wsc;
+
+    const int n_work = a.nqb * a.S;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int qb = work / a.S, split = work - qb * a.S;
+        const int t0 = split * a.tiles_per_split;
+        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        const int64_t qbase = (int64_t)qb * QB + wave * 64;
+        float q0[D], q1[D];
+#pragma unroll
+        for (int e = 0; e < D; ++e) { q0[e] = Qf[(qbase + c) * D + e]; q1[e] = Qf[(qbase + 32 + c) * D + e]; }
+        float thr[2] = {INFINITY, INFINITY};
+        int cnt[2] = {0, 0};
+        int keptn[2] = {0, 0};
+
+#define CM2_DMA_TILE_L(t_, buf_)                                                                                \
+    {                                                                                                           \
+        const char *gsrc_ = a.R + (size_t)(t_) * TILEB + lane * 16;                                             \
+        unsigned char *ldst_ = ring + (buf_) * TILEB;                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < (NCHUNK + NW - 1) / NW; ++q_) {                                 \
+            const int piece_ = wave + q_ * NW;                                                                  \
+            if (piece_ < NCHUNK)                                                                                \
+                __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + piece_ * 1024),                 \
+                                                 (CM2_AS3 void *)(ldst_ + piece_ * 1024), 16, 0, 0);            \
+        }                                                                                                       \
+    }
+        __builtin_amdgcn_s_barrier();
+        if (t0 < t1) CM2_DMA_TILE_L(t0, t0 & 1);
+        int next_refresh = t0;  // tiles are 512 rows: refresh after 1, 2, 4, ... tiles
+        for (int t = t0; t < t1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < t1) CM2_DMA_TILE_L(t + 1, (t + 1) & 1);
+            const float *tile = reinterpret_cast<const float *>(ring + (t & 1) * TILEB);
+#pragma unroll 1
+            for (int st = 0; st < NST; ++st) {
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float *y = tile + (st * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh) * D;  // half-wave broadcast
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < D; ++e) {
+                        const float ye = y[e];
+                        const float d0 = q0[e] - ye, d1 = q1[e] - ye;
+                        s0 = fmaf(d0, d0, s0);
+                        s1 = fmaf(d1, d1, s1);
+                    }
+                    acc0[rr] = s0;
+                    acc1[rr] = s1;
+                }
+                float mp0, mp1;
+                CM2_MIN16(acc0, mp0);
+                CM2_MIN16(acc1, mp1);
+                const int rbase = t * BRL + st * 32 + 4 * hh;
+                CM2_FILTER(acc0, acc1, mp0, mp1, rbase);
+            }
+            CM2_REFRESH(t, t0);
+        }
+#undef CM2_DMA_TILE_L
+        CM2_FINAL();
+    }
+    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc;
 }
 
 }  // namespace cmk2

@@ -18,3 +18,22 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
     }
     CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d", KSTEPS);
 }
+
+template <int D>
+static cm_status launch_lowd(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    auto kern = cmk2::knn_cand_lowd<D>;
+    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a) {
+    switch (D) {
+#define CM_LD_CASE(d_) case d_: return launch_lowd<d_>(h, grid, lds, a);
+        CM_LD_CASE(1) CM_LD_CASE(2) CM_LD_CASE(3) CM_LD_CASE(4) CM_LD_CASE(5) CM_LD_CASE(6) CM_LD_CASE(7) CM_LD_CASE(8)
+        CM_LD_CASE(9) CM_LD_CASE(10) CM_LD_CASE(11) CM_LD_CASE(12) CM_LD_CASE(13) CM_LD_CASE(14) CM_LD_CASE(15)
+#undef CM_LD_CASE
+    }
+    CM_FAIL(h, CM_E_INTERNAL, "phase1/lowd: no instantiation for D=%d", D);
+}

@@ -117,6 +117,26 @@ def test_knn_matches_oracle(n_ref, nq, d, k, dtype, hip, oracle):
     assert st["fallback_queries"] <= max(2, nq // 100), st
 
 
+@pytest.mark.parametrize("n,nq,d,k,dtype,scale", [
+    (30000, 4000, 2, 90, np.float32, 2000.0),   # spatial coordinates (BASELINE config 5 shape), self-style
+    (20000, 2500, 2, 30, np.float64, 2000.0),   # float64 coordinates
+    (8000, 1500, 3, 15, np.float32, 50.0),
+    (6000, 1000, 10, 15, np.float32, 1.0),      # still sklearn's kd_tree regime (d <= 15)
+    (5000, 700, 15, 40, np.float64, 1.0),
+])
+def test_lowd_direct_path_matches_oracle(n, nq, d, k, dtype, scale, hip, oracle):
+    rng = np.random.default_rng(n + d)
+    ref = (rng.uniform(0, scale, (n, d)) if d <= 3 else rng.standard_normal((n, d)) * scale).astype(dtype)
+    qry = ref[rng.choice(n, nq, replace=False)].copy() if d <= 3 else rng.standard_normal((nq, d)).astype(dtype)
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)  # direct (kd_tree) form for d <= 15
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(dist, od)
+    st = hip.knn_stats()
+    assert st["lowd_path"] == 3, st
+    assert st["fallback_queries"] <= max(2, nq // 200), st
+
+
 def test_knn_forced_fallback_and_duplicates(hip, oracle):
     from cellmapper_amd import _native
     import ctypes as C
