@@ -98,25 +98,31 @@ __device__ __forceinline__ float key2f(unsigned k) {
     unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __uint_as_float(u);
 }
+// load phase: entry i of the concatenation (kept list, lane-0 buffer, lane-1 buffer) goes to lane i%64, slot i/64
 template <int E>
-__device__ __forceinline__ int wave_merge_prune_e(const uint2 *kept_src, int nk, const uint2 *b0, int n0, const uint2 *b1,
-                                                  int n1, int Kc, uint2 *dst_pairs, int *dst_rows, float *thr_out, int lane) {
+__device__ __forceinline__ void prune_load(const uint2 *kept_src, int nk, const uint2 *b0, int n0, const uint2 *b1, int n1,
+                                           int lane, unsigned (&key)[E], unsigned (&row)[E]) {
     const int n = nk + n0 + n1;
-    unsigned key[E], row[E];
-    bool valid[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * 64 + lane;
-        valid[e] = i < n;
         key[e] = 0xffffffffu;
         row[e] = 0;
-        if (valid[e]) {
+        if (i < n) {
             const uint2 *src = i < nk ? kept_src + i : (i < nk + n0 ? b0 + (i - nk) : b1 + (i - nk - n0));
             uint2 x = ld_fresh(src);
             key[e] = f2key(__uint_as_float(x.x));
             row[e] = x.y;
         }
     }
+}
+// select phase: keep the Kc smallest of the n loaded entries, write them (unordered) and refresh the threshold
+template <int E>
+__device__ __forceinline__ int prune_select(const unsigned (&key)[E], const unsigned (&row)[E], int n, int Kc,
+                                            uint2 *dst_pairs, int *dst_rows, float *thr_out, int lane) {
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) valid[e] = e * 64 + lane < n;
     unsigned kth = 0xffffffffu;  // n <= Kc: keep everything
     if (n > Kc) {
         // all keys share their leading bits (the values sit in a narrow band below the old threshold): skip them
@@ -178,6 +184,13 @@ __device__ __forceinline__ int wave_merge_prune_e(const uint2 *kept_src, int nk,
         return Kc;
     }
     return n;
+}
+template <int E>
+__device__ __forceinline__ int wave_merge_prune_e(const uint2 *kept_src, int nk, const uint2 *b0, int n0, const uint2 *b1,
+                                                  int n1, int Kc, uint2 *dst_pairs, int *dst_rows, float *thr_out, int lane) {
+    unsigned key[E], row[E];
+    prune_load<E>(kept_src, nk, b0, n0, b1, n1, lane, key, row);
+    return prune_select<E>(key, row, nk + n0 + n1, Kc, dst_pairs, dst_rows, thr_out, lane);
 }
 __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 *kept_src, int nk, const uint2 *b0, int n0,
                                                 const uint2 *b1, int n1, int Kc, uint2 *dst_pairs, int *dst_rows,
