@@ -137,6 +137,48 @@ def test_lowd_direct_path_matches_oracle(n, nq, d, k, dtype, scale, hip, oracle)
     assert st["fallback_queries"] <= max(2, nq // 200), st
 
 
+@pytest.mark.parametrize("n_ref,nq,d,k,dtype", [
+    (1, 1, 20, 1, np.float32),        # smallest possible problem
+    (7, 3, 1, 7, np.float64),         # d = 1, k = n_ref
+    (300, 1, 50, 30, np.float32),     # single query
+    (2000, 600, 61, 20, np.float32),  # widest embedding of the split-fp16 kernel (61 + 3 norm slots = 64)
+    (2000, 600, 62, 20, np.float32),  # first width served by the f32-input MFMA kernel
+    (1500, 300, 200, 10, np.float32), # wide embedding (f32-input MFMA kernel)
+    (4000, 500, 50, 100, np.float32), # k = 100: K' = 125, 512-entry merges
+    (3000, 200, 30, 300, np.float32), # k beyond the in-register merge: f32-input kernel with LDS candidate buffers
+    (2500, 400, 16, 5, np.float32),   # smallest d on the MFMA path (d > 15 -> GEMM-form distances)
+])
+def test_knn_edge_shapes_match_oracle(n_ref, nq, d, k, dtype, hip, oracle):
+    rng = np.random.default_rng(1000 * d + k)
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_knn_empty_query_and_offsets(hip):
+    ref = np.random.default_rng(0).standard_normal((100, 20)).astype(np.float32)
+    dist, idx = hip.knn(ref, np.zeros((0, 20), np.float32), 5)
+    assert dist.shape == (0, 5) and idx.shape == (0, 5)
+    indptr, cols, vals, conn, _ = hip.mapping_matrix(np.zeros((4, 3)), np.array([[0, 1, -1]] * 4), 5, "equal", want_conn=True)
+    assert indptr.tolist() == [0, 2, 4, 6, 8] and vals.tolist() == [0.5] * 8
+
+
+def test_mixed_scale_data_stays_exact(hip, oracle):
+    """Coordinates spanning 12 orders of magnitude and a large common offset: the split-fp16 filter loses precision,
+    the certificate notices and the float64 stages keep the result exact."""
+    rng = np.random.default_rng(77)
+    ref = rng.standard_normal((5000, 40)) * np.logspace(-6, 6, 40)[None, :]
+    ref[:, 0] += 1e7
+    qry = ref[rng.choice(5000, 300, replace=False)] + rng.standard_normal((300, 40)) * 1e-3
+    for dt in (np.float64, np.float32):
+        r, q = ref.astype(dt), qry.astype(dt)
+        dist, idx = hip.knn(r, q, 10)
+        od, oi = oracle.knn_euclidean(r, q, 10)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
 def test_knn_forced_fallback_and_duplicates(hip, oracle):
     from cellmapper_amd import _native
     import ctypes as C
