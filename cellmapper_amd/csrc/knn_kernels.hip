@@ -85,8 +85,44 @@ __global__ void prep_rows(const T *__restrict__ X, int64_t n, int d, int KP, int
 // ------------------------------------------------------------------ split-fp16 preparation ----------
 // max |coordinate| over a matrix (after the optional cosine normalisation): decides the power-of-two scale that
 // keeps the fp16 halves in range.  gmax[4] holds the float bits of the maximum.
+// Column means of the (cosine: normalised) reference rows.  Distances are translation invariant, so phase 1 works on
+// rows centred at the reference mean: the fp16 split and the error bound then scale with the SPREAD of the data, not
+// with its offset from the origin.  (Phase 2 always uses the caller's original rows.)  Deterministic two-stage sum.
+constexpr int CMEAN_BLOCKS = 256;
 template <typename T>
-__global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metric, unsigned *__restrict__ gmax) {
+__global__ __launch_bounds__(256) void colmean_partial(const T *__restrict__ X, int64_t n, int d, int metric,
+                                                        double *__restrict__ partial /*[CMEAN_BLOCKS][64]*/) {
+    __shared__ double sh[4][64];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;  // lane = column, 4 waves stride over rows
+    double acc = 0.0;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    for (int64_t i = r0 + w; i < r1; i += 4) {
+        double scale = 1.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s = 0.0;
+            for (int e = 0; e < d; ++e) { double v = (double)X[i * d + e]; s = fma(v, v, s); }
+            double nrm = sqrt(s);
+            scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+        if (c < d) acc += (double)X[i * d + c] * scale;
+    }
+    sh[w][c] = acc;
+    __syncthreads();
+    if (w == 0) partial[blockIdx.x * 64 + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+__global__ void colmean_final(const double *__restrict__ partial, int64_t n, int d, double *__restrict__ mean /*[64]*/) {
+    const int c = threadIdx.x;
+    if (c < 64) {
+        double s = 0.0;
+        for (int b = 0; b < CMEAN_BLOCKS; ++b) s += partial[b * 64 + c];
+        mean[c] = (c < d && n > 0) ? s / (double)n : 0.0;
+    }
+}
+
+template <typename T>
+__global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metric, const double *__restrict__ mean,
+                            unsigned *__restrict__ gmax) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float m = 0.f;
     if (i < n) {
@@ -98,7 +134,7 @@ __global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metri
             double nrm = sqrt(s);
             scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
         }
-        for (int c = 0; c < d; ++c) m = fmaxf(m, fabsf((float)((double)x[c] * scale)));
+        for (int c = 0; c < d; ++c) m = fmaxf(m, fabsf((float)((double)x[c] * scale - (mean ? mean[c] : 0.0))));
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(&gmax[4], __float_as_uint(m));
@@ -123,8 +159,8 @@ __global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__res
 //               (the LDS image knn_cand_f16 copies verbatim with LDS-DMA).
 template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
-                              const float *__restrict__ scale3, char *__restrict__ P, float *__restrict__ rownorm,
-                              unsigned *__restrict__ gmax) {
+                              const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
+                              float *__restrict__ rownorm, unsigned *__restrict__ gmax) {
     const int ROWB = cmk2::row_bytes(KSTEPS), GRAN = ROWB / 16, TILEB = cmk2::tile_bytes(KSTEPS);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float yn_f = 0.f;
@@ -136,14 +172,15 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
         const int f = is_ref ? cmk2::swz(r, KSTEPS) : 0;
         double nscale = 1.0;
         const T *x = X + i * d;
-        double s2 = 0.0;
+        double s2 = 0.0;  // squared norm of the centred (cosine: normalised, then centred) row
         if (i < n) {
-            for (int c = 0; c < d; ++c) { double v = (double)x[c]; s2 = fma(v, v, s2); }
             if (metric == CM_METRIC_COSINE) {
-                double nrm = sqrt(s2);
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+                double nrm = sqrt(s);
                 nscale = nrm > 0.0 ? 1.0 / nrm : 1.0;
-                s2 = nrm > 0.0 ? 1.0 : 0.0;
             }
+            for (int c = 0; c < d; ++c) { double v = (double)x[c] * nscale - mean[c]; s2 = fma(v, v, s2); }
         }
         // norm digits / query constants for slots d, d+1, d+2
         float slot[3];
@@ -171,7 +208,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                 _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
                 if (c < d) {
                     if (i < n) {
-                        float v = (float)((double)x[c] * nscale) * mul;
+                        float v = (float)((double)x[c] * nscale - mean[c]) * mul;
                         h = (_Float16)v;
                         l = (_Float16)(v - (float)h);
                     }
@@ -261,7 +298,8 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int d, const int *__restrict__ cand, const float *__restrict__ cthr,
                                                    int S, int Kc, int k, int metric, int form,
                                                    const float *__restrict__ qnorm, const unsigned *__restrict__ gmax,
-                                                   float c_eps, const float *__restrict__ scale3, int64_t idx_offset,
+                                                   float c_eps, const float *__restrict__ scale3,
+                                                   const double *__restrict__ mean, int64_t idx_offset,
                                                    int flags, void *__restrict__ out_dist,
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
                                                    int *__restrict__ flag_cnt, double *__restrict__ bound) {
@@ -309,7 +347,16 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (scale3) tau *= scale3[2];  // phase-1 values were computed on rows scaled by sc: back to input units
         bool certified = true;
         if (tau < INFINITY && c_eps >= 0.f) {
-            double sk = (metric == CM_METRIC_COSINE) ? (2.0 * kth - 1.0) : (kth - xn);
+            // phase 1 ranked by |y'|^2 - 2 q'.y' = D - |q'|^2 with D = d^2 (cosine: 2*dist) and q', y' the rows as
+            // prepared for the filter (cosine: normalised; split-fp16 path: centred at the reference mean)
+            double qn2 = xn;
+            if (metric == CM_METRIC_COSINE || mean) {
+                double ns = 1.0;
+                if (metric == CM_METRIC_COSINE) { double nx = sqrt(xn); ns = nx > 0.0 ? 1.0 / nx : 1.0; }
+                qn2 = 0.0;
+                for (int c = 0; c < d; ++c) { double v = q[c] * ns - (mean ? mean[c] : 0.0); qn2 = fma(v, v, qn2); }
+            }
+            double sk = ((metric == CM_METRIC_COSINE) ? 2.0 * kth : kth) - qn2;
             double ymax2 = (double)__uint_as_float(gmax[0]), ymax = (double)__uint_as_float(gmax[1]);
             double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30);
             certified = sk < (double)tau - eps;
@@ -528,6 +575,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
     if (!qnorm || !cand || !cthr || !flag_list || !bound || !words) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     float *scale3 = reinterpret_cast<float *>(words + 8);
+    double *d_mean = nullptr;
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
     float c_eps;
@@ -539,8 +587,15 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * 2 * cmk2::CL);
         if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::BRL : cmk2::BR);
-        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, words);
-        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, words);
+        if (path == 1) {  // centre at the reference mean (translation leaves every distance unchanged)
+            double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
+            d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
+            if (!cpart || !d_mean) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+            hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
+            hipLaunchKernelGGL(colmean_final, dim3(1), dim3(64), 0, st, cpart, n_ref, d, d_mean);
+        }
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, (const double *)d_mean, words);
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, (const double *)d_mean, words);
         if (path == 2) {
             hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                nref_pad, 1, metric, reinterpret_cast<float *>(Rp));
@@ -549,9 +604,9 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         } else {
             hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3);
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               p2.KSTEPS, nref_pad, 1, metric, scale3, Rp, (float *)nullptr, words);
+                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words);
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, Qp, qnorm, (unsigned *)nullptr);
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr);
         }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
@@ -608,7 +663,8 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     }
     if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
     hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                       S, Kc, k, metric, form, qnorm, words, c_eps, path == 1 ? scale3 : (const float *)nullptr, idx_offset, flags,
+                       S, Kc, k, metric, form, qnorm, words, c_eps, path == 1 ? scale3 : (const float *)nullptr,
+                       (const double *)d_mean, idx_offset, flags,
                        d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
     cm_mark(h, 3);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
@@ -630,7 +686,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int slack = k / 4 > 8 ? k / 4 : 8;
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
-    size_t b = cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
+    size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096;
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
