@@ -36,7 +36,7 @@ EXPORTS = [
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
-    "cm_set_profiling", "cm_stage_times",
+    "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores",
 ]
 
 
@@ -78,6 +78,8 @@ def load_library():
         lib.cm_spmm_csr.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.cm_map_labels_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, dbl, vp, i32, vp, vp, vp, vp]
         lib.cm_csr_normalize.argtypes = [vp, vp, vp, i64, vp]
+        lib.cm_shared_neighbors.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp, vp, vp, i64, vp]
+        lib.cm_presence_scores.argtypes = [vp, vp, vp, i64, i32, i64, vp, i32, vp]
         lib.cm_set_profiling.argtypes = [vp, i32]
         lib.cm_stage_times.argtypes = [vp, vp]
         for name in EXPORTS:
@@ -201,6 +203,34 @@ class Handle:
         data64 = np.ascontiguousarray(data64, np.float64)
         out = np.empty(data64.shape[0], np.float32)
         self.call("cm_csr_normalize", _ptr(indptr), _ptr(data64), len(indptr) - 1, _ptr(out))
+        return out
+
+    def shared_neighbors(self, yx, xx, yy, xy, transform: str = "jaccard"):
+        """Shared-neighbour matrix of the four k-NN graphs -> (indptr int64, cols int32, vals float64), canonical CSR."""
+        tid = {"counts": 0, "jaccard": 1, "hnoca": 2}[transform]
+        yx, xx, yy, xy = (np.ascontiguousarray(a, np.int64) for a in (yx, xx, yy, xy))
+        nq, k = yx.shape
+        nr = xx.shape[0]
+        if yy.shape != (nq, k) or xx.shape != (nr, k) or xy.shape != (nr, k):
+            raise ValueError("The four neighbor graphs must share n_neighbors and have consistent shapes.")
+        indptr = np.empty(nq + 1, np.int64)
+        nnz = C.c_int64(0)
+        self.call("cm_shared_neighbors", _ptr(yx), _ptr(xx), _ptr(yy), _ptr(xy), nq, nr, k, tid, _ptr(indptr), None, None,
+                  0, C.byref(nnz))
+        cols = np.empty(nnz.value, np.int32)
+        vals = np.empty(nnz.value, np.float64)
+        self.call("cm_shared_neighbors", _ptr(yx), _ptr(xx), _ptr(yy), _ptr(xy), nq, nr, k, tid, _ptr(indptr), _ptr(cols),
+                  _ptr(vals), nnz.value, C.byref(nnz))
+        return indptr, cols, vals
+
+    def presence_scores(self, dist, idx, n_ref: int, group=None, n_groups: int = 0):
+        """Raw presence scores [n_ref, n_groups + 1] (column 0: all query cells)."""
+        dist = np.ascontiguousarray(dist, np.float64)
+        idx = np.ascontiguousarray(idx, np.int64)
+        nq, k = idx.shape
+        grp = None if group is None else np.ascontiguousarray(group, np.int32)
+        out = np.empty((int(n_ref), int(n_groups) + 1), np.float64)
+        self.call("cm_presence_scores", _ptr(dist), _ptr(idx), nq, k, int(n_ref), _ptr(grp), int(n_groups), _ptr(out))
         return out
 
     def label_vote(self, indptr, cols, vals, codes, n_cat: int):

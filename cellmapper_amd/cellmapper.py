@@ -16,6 +16,7 @@ import pandas as pd
 from scipy.sparse import csr_matrix, issparse
 
 from . import _native
+from .evaluate import PresenceMixin
 from .knn import Neighbors
 from .logging import logger
 from .utils import create_imputed_anndata, get_n_comps
@@ -23,7 +24,7 @@ from .utils import create_imputed_anndata, get_n_comps
 _KERNEL_METHODS = ("gaussian", "scarches", "inverse_distance", "random", "equal")
 
 
-class CellMapper:
+class CellMapper(PresenceMixin):
     """Mapping of labels, embeddings, and expression values between reference and query datasets."""
 
     def __init__(self, query, reference=None) -> None:
@@ -126,16 +127,13 @@ class CellMapper:
             if self.only_yx:
                 raise ValueError("Jaccard and HNOCa methods require both x and y neighbors to be computed. "
                                  "Set only_yx=False.")
-            xx, yy, xy, yx = self.knn.get_adjacency_matrices()
-            n_neighbors = self.knn.xx.n_neighbors
-            # shared-neighbour counts; the SpGEMM of 0/1 adjacencies is a "next" row
-            jac = ((yx @ xx.T) + (yy @ xy.T)).tocsr()
-            with np.errstate(divide="ignore", invalid="ignore"):
-                if method == "jaccard":
-                    jac.data = jac.data / (4 * n_neighbors - jac.data)
-                else:
-                    jac.data = (jac.data / (2 * n_neighbors - jac.data)) ** 2
-            self.mapping_matrix = jac
+            knn = self.knn
+            if knn.xx is None or knn.yy is None or knn.xy is None or knn.yx is None:
+                raise ValueError("Neighbors must be computed before accessing adjacency matrices.")
+            # (yx @ xx.T) + (yy @ xy.T) on the 0/1 adjacencies + the jaccard / hnoca transform, on the GPU
+            indptr, cols, vals = _native.default_handle().shared_neighbors(
+                knn.yx.indices, knn.xx.indices, knn.yy.indices, knn.xy.indices, transform=method)
+            self.mapping_matrix = csr_matrix((vals, cols, indptr), shape=(self.query.n_obs, self.reference.n_obs))
         elif method in _KERNEL_METHODS:
             if method == "random":
                 self.mapping_matrix = self.knn.yx.knn_graph_connectivities(kernel="random")

@@ -355,6 +355,32 @@ cm_status cm_csr_normalize(cm_handle_t h, const int64_t *indptr, const double *d
     return sync(h);
 }
 
+cm_status cm_presence_scores(cm_handle_t h, const double *dist, const int64_t *idx, int64_t nq, int32_t k, int64_t n_ref,
+                             const int32_t *group, int32_t n_groups, double *out) {
+    if (!h) return CM_E_INVALID;
+    if (nq < 0 || k < 1 || n_ref < 1 || n_groups < 0) CM_FAIL(h, CM_E_INVALID, "presence scores: bad shape");
+    CM_TRY(begin_call(h, 64 * 1024));
+    size_t nk = (size_t)nq * k, no = (size_t)n_ref * (n_groups + 1);
+    DevBuf dd, di, dg, dout, dm;
+    CM_TRY(dd.alloc(h, 8 * nk)); CM_TRY(di.alloc(h, 8 * nk)); CM_TRY(dout.alloc(h, 8 * no)); CM_TRY(dm.alloc(h, 64));
+    CM_TRY(h2d(h, dd.p, dist, 8 * nk));
+    CM_TRY(h2d(h, di.p, idx, 8 * nk));
+    if (group) { CM_TRY(dg.alloc(h, 4 * (size_t)nq)); CM_TRY(h2d(h, dg.p, group, 4 * (size_t)nq)); }
+    CM_HIP(h, hipMemsetAsync(dout.p, 0, 8 * no, h->stream));
+    double *m3 = dm.as<double>(), *param = m3 + 5;
+    CM_HIP(h, hipMemsetAsync(m3, 0, 64, h->stream));
+    CM_TRY(cm_moments_run(h, dd.as<double>(), di.as<int64_t>(), (int64_t)nk, nullptr, m3));
+    double hm[3] = {0, 0, 0};
+    CM_TRY(d2h(h, hm, m3, 24));
+    CM_TRY(sync(h));
+    if (!(hm[2] > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
+    CM_TRY(cm_param_run(h, m3, CM_KERNEL_GAUSSIAN, param));
+    CM_TRY(cm_presence_run(h, dd.as<double>(), di.as<int64_t>(), nq, k, param, group ? dg.as<int32_t>() : nullptr, n_groups,
+                           dout.as<double>()));
+    CM_TRY(d2h(h, out, dout.p, 8 * no));
+    return sync(h);
+}
+
 static cm_status upload_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
                             DevBuf &dp, DevBuf &dc, DevBuf &dv) {
     int64_t nnz = indptr[nq];

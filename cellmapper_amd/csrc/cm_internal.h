@@ -72,6 +72,8 @@ cm_status cm_ell_to_csr_run(cm_handle_t h, const int32_t *d_cols, const float *d
                             const int32_t *d_cnt, int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols,
                             float *d_out_vals, double *d_out_conn);
 size_t cm_scan_ws_bytes(int64_t n);
+cm_status cm_presence_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                          const double *d_param, const int32_t *d_group, int32_t n_groups, double *d_out);
 cm_status cm_csr_normalize_run(cm_handle_t h, const int64_t *d_indptr, const double *d_data, int64_t nq, float *d_out);
 cm_status cm_vote_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                       int32_t ell_k, const int32_t *d_cnt, const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code,

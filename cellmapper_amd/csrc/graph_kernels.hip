@@ -136,6 +136,26 @@ __global__ __launch_bounds__(256) void weights_rows(const double *__restrict__ d
     if (lane == 0) cntp[i] = m;
 }
 
+// Presence scores (evaluate.py:426-521): column sums of the un-normalised gaussian connectivities, overall (column 0)
+// and per query group (columns 1..G).  One thread per (query, neighbour) entry, float64 atomics into [n_ref, G+1].
+__global__ void presence_scatter(const double *__restrict__ dist, const int64_t *__restrict__ idx, int64_t nq, int k,
+                                 const double *__restrict__ param_p, const int32_t *__restrict__ group, int n_groups,
+                                 double *__restrict__ out) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nq * k) return;
+    double dd = dist[g];
+    int64_t c = idx[g];
+    if (c == -1 || !isfinite(dd)) return;
+    const double sigma = *param_p;
+    const double w = exp(-(dd * dd) / (2.0 * (sigma * sigma)));
+    double *row = out + c * (int64_t)(n_groups + 1);
+    atomicAdd(&row[0], w);
+    if (group) {
+        int gi = group[g / k];
+        if (gi >= 0 && gi < n_groups) atomicAdd(&row[1 + gi], w);
+    }
+}
+
 // K3 for a caller-supplied canonical CSR: one thread per row (rows are short), float64 sequential sum.
 __global__ void csr_normalize_rows(const int64_t *__restrict__ indptr, const double *__restrict__ data, int64_t nq,
                                    float *__restrict__ out) {
@@ -417,6 +437,16 @@ cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_i
     size_t lds = 4 * ((size_t)k * 28 + 32) + 16;
     hipLaunchKernelGGL(weights_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
                        d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_presence_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
+                          const double *d_param, const int32_t *d_group, int32_t n_groups, double *d_out) {
+    if (nq == 0) return CM_OK;
+    int64_t tot = nq * k;
+    hipLaunchKernelGGL(presence_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,
+                       d_param, d_group, n_groups, d_out);
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }

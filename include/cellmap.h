@@ -176,6 +176,24 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
                       const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                       int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals);
 
+/* ------------------------------------- shared-neighbour counts: jaccard / hnoca mapping methods ------
+ * Replaces `(yx @ xx.T) + (yy @ xy.T)` on the 0/1 adjacency matrices of the four k-NN graphs and the following
+ * transform (cellmapper.py:287-301; adjacencies: knn.py:228-266,467-483).  yx, yy: int64 [nq,k]; xx, xy: int64 [nr,k]
+ * neighbour indices (-1 = padded).  J[i,j] = |N_yx(i) & N_xx(j)| + |N_yy(i) & N_xy(j)|.
+ * transform: 0 = raw counts, 1 = jaccard  J/(4k - J), 2 = hnoca  (J/(2k - J))^2.   Output: canonical CSR, float64
+ * values (feed cm_csr_normalize for the mapping matrix).  Call once with out_cols = NULL to obtain out_indptr and
+ * *out_nnz, allocate, call again with capacity >= nnz. */
+cm_status cm_shared_neighbors(cm_handle_t h, const int64_t *yx, const int64_t *xx, const int64_t *yy, const int64_t *xy,
+                              int64_t nq, int64_t nr, int32_t k, int32_t transform, int64_t *out_indptr,
+                              int32_t *out_cols, double *out_vals, int64_t capacity, int64_t *out_nnz);
+
+/* ------------------------------------------------- presence scores -----------
+ * Replaces the column sums in EvaluationMixin.estimate_presence_score (evaluate.py:426-480): raw score of reference
+ * cell r = sum over query cells of the un-normalised gaussian connectivity (global sigma, as in K1), overall and per
+ * query group.  group int32 [nq] in [0, n_groups) or NULL.  out float64 [n_ref, n_groups + 1]: column 0 = all queries. */
+cm_status cm_presence_scores(cm_handle_t h, const double *dist, const int64_t *idx, int64_t nq, int32_t k, int64_t n_ref,
+                             const int32_t *group, int32_t n_groups, double *out);
+
 /* ---------------------------------------------------------------- fused device pipeline -------------
  * k-NN -> kernel -> normalise -> label vote with every intermediate resident in HBM (BASELINE config 2;
  * CellMapper.map(obs_keys=label), cellmapper.py:426-491).  Outputs (device): d_out_code int32 [nq],

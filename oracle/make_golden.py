@@ -151,10 +151,41 @@ def run_mapping_case(cm_mod, name, xrep, yrep, k, metric="euclidean", seed=0, n_
     return out
 
 
+def presence_case(cm_mod):
+    """estimate_presence_score (evaluate.py:426-521) with and without groups, log / percentile variants."""
+    rng = np.random.default_rng(11)
+    n_ref, nq, d, k = 900, 400, 30, 15
+    xrep = rng.standard_normal((n_ref, d)).astype(np.float32)
+    yrep = (rng.standard_normal((nq, d)) * 0.7 + 0.3).astype(np.float32)
+    groups = np.array(["g%d" % v for v in rng.integers(0, 4, nq)])
+    out = dict(xrep=xrep, yrep=yrep, k=np.int64(k), groups=groups, **VERSIONS)
+    for tag, kw in (("default", {}), ("log", dict(log=True)), ("nopct", dict(percentile=(0, 100)))):
+        ref = MiniAnnData(X=np.zeros((n_ref, 2), np.float32), obs=pd.DataFrame(index=[f"r{i}" for i in range(n_ref)]),
+                          obsm={"X_emb": xrep})
+        qry = MiniAnnData(X=np.zeros((nq, 2), np.float32), obs=pd.DataFrame({"grp": groups}, index=[f"q{i}" for i in range(nq)]),
+                          obsm={"X_emb": yrep})
+        cmap = cm_mod.CellMapper(qry, ref)
+        cmap.compute_neighbors(n_neighbors=k, use_rep="X_emb", method="sklearn", only_yx=True)
+        cmap.estimate_presence_score(groupby="grp", key_added="ps", **kw)
+        out[f"all_{tag}"] = ref.obs["ps"].to_numpy()
+        df = ref.obsm["ps"]
+        out[f"groups_{tag}"] = df.to_numpy()
+        out["group_names"] = np.array([str(c) for c in df.columns])
+        if tag == "default":
+            conn = cmap.knn.yx.knn_graph_connectivities()
+            out["raw_all"] = np.asarray(conn.sum(axis=0)).ravel()
+            out["yx_dist"], out["yx_idx"] = cmap.knn.yx.distances, cmap.knn.yx.indices
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cm_mod, knn_mod, utils_mod = load_reference()
     saved = {}
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "presence":
+        np.savez_compressed(os.path.join(OUT, "presence.npz"), **presence_case(cm_mod))
+        print("presence.npz written")
+        return
 
     def save(name, d):
         path = os.path.join(OUT, f"{name}.npz")
@@ -260,6 +291,8 @@ def main():
     # ---- 7. k = 1 identity mapping (tests/model/test_query_to_reference_mapping.py:75-92 restated on synthetic data)
     xr7, _ = synth(9, 300, 1, 20, np.float32)
     save("identity_k1", run_mapping_case(cm_mod, "identity_k1", xr7, xr7.copy(), 1, only_yx=False, n_cat=7, G=16))
+
+    save("presence", presence_case(cm_mod))
 
     for k_, v in saved.items():
         print(f"{k_:28s} {v/1024:8.1f} KiB")

@@ -231,3 +231,28 @@ def test_sharded_search_equals_single_search():
         torch.cuda.synchronize()
     assert torch.equal(mi, i_full) and torch.equal(md, d_full)
     assert set(mi[0, :2].tolist()) == {500, 8000} and mi[0, 0].item() == 500
+
+
+def test_presence_scores_match_reference():
+    """estimate_presence_score (reference evaluate.py:426-521) vs golden output of the reference."""
+    from cellmapper_amd import CellMapper, MiniAnnData
+
+    g = load_golden("presence")
+    n_ref, nq = g["xrep"].shape[0], g["yrep"].shape[0]
+    for tag, kw in (("default", {}), ("log", dict(log=True)), ("nopct", dict(percentile=(0, 100)))):
+        ref = MiniAnnData(X=np.zeros((n_ref, 2), np.float32), obs=pd.DataFrame(index=[f"r{i}" for i in range(n_ref)]),
+                          obsm={"X_emb": g["xrep"]})
+        qry = MiniAnnData(X=np.zeros((nq, 2), np.float32), obs=pd.DataFrame({"grp": g["groups"]}, index=[f"q{i}" for i in range(nq)]),
+                          obsm={"X_emb": g["yrep"]})
+        cm = CellMapper(qry, ref)
+        with pytest.raises(ValueError, match="Neighbors must be computed"):
+            cm.estimate_presence_score()
+        cm.compute_neighbors(n_neighbors=int(g["k"]), use_rep="X_emb", only_yx=True)
+        cm.estimate_presence_score(groupby="grp", key_added="ps", **kw)
+        np.testing.assert_allclose(ref.obs["ps"].to_numpy(), g[f"all_{tag}"], rtol=1e-6, atol=1e-9)
+        df = ref.obsm["ps"]
+        assert [str(c) for c in df.columns] == [str(c) for c in g["group_names"]]
+        np.testing.assert_allclose(df.to_numpy(), g[f"groups_{tag}"], rtol=2e-5, atol=1e-6)
+    from cellmapper_amd import _native
+    raw = _native.default_handle().presence_scores(g["yx_dist"], g["yx_idx"], n_ref)
+    np.testing.assert_allclose(raw[:, 0], g["raw_all"], rtol=1e-12)

@@ -204,6 +204,34 @@ def test_cosine_matches_oracle(hip, oracle):
     assert_knn_parity(dist, idx, od, oi, ref, qry, "cosine")
 
 
+def test_shared_neighbors_match_reference_and_scipy(hip):
+    """jaccard / hnoca matrices (cellmapper.py:287-301) vs the golden mapping matrices and vs scipy SpGEMM counts."""
+    g = load_golden("synth_full_d37_k10")
+    k = int(g["k"])
+    for meth in ("jaccard", "hnoca"):
+        ip, cc, vv = hip.shared_neighbors(g["yx_idx"], g["xx_idx"], g["yy_idx"], g["xy_idx"], meth)
+        norm = hip.csr_normalize(ip, vv)
+        assert_csr_close(ip, cc, norm, golden_csr(g, f"map_{meth}"), rtol=1e-6)
+    rng = np.random.default_rng(4)
+    nq, nr, k = 700, 900, 25
+    yx, yy = rng.integers(0, nr, (nq, k)), rng.integers(0, nq, (nq, k))
+    xx, xy = rng.integers(0, nr, (nr, k)), rng.integers(0, nq, (nr, k))
+    xx[:, 0] = 7  # a hub: reference cell 7 is everybody's neighbour -> one very long transposed list
+    yx[5, 3] = -1  # padded entries are skipped
+
+    # upstream builds adjacencies by summing duplicate (row, col) pairs, so a repeated neighbour weighs twice there too
+    def adj_sum(ix, ncols):
+        r = np.repeat(np.arange(ix.shape[0]), ix.shape[1])
+        m = ix.ravel() >= 0
+        return sp.csr_matrix((np.ones(m.sum()), (r[m], ix.ravel()[m])), shape=(ix.shape[0], ncols))
+    ref = (adj_sum(yx, nr) @ adj_sum(xx, nr).T + adj_sum(yy, nq) @ adj_sum(xy, nq).T).tocsr()
+    ref.sort_indices()
+    ip, cc, vv = hip.shared_neighbors(yx, xx, yy, xy, "counts")
+    ours = sp.csr_matrix((vv, cc, ip), shape=(nq, nr))
+    assert np.array_equal(ours.indptr, ref.indptr) and np.array_equal(ours.indices, ref.indices)
+    np.testing.assert_array_equal(ours.data, ref.data)
+
+
 def test_error_conventions(hip):
     x = np.zeros((5, 20), np.float32)
     with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
