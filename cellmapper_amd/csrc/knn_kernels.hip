@@ -13,6 +13,7 @@
 
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a);
 
 // phase-1 instantiation groups (knn_phase1_inst.hip)
 #define CM_DECL_P1(g)                                                                                                  \
@@ -139,13 +140,14 @@ __global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metri
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(&gmax[4], __float_as_uint(m));
 }
-// sc = 2^(12 - e) with maxabs = m * 2^e, m in [0.5, 1): scaled coordinates land in [2048, 4096) at most
-__global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__restrict__ scale3) {
+// sc = 2^(top_exp - e) with maxabs = m * 2^e, m in [0.5, 1): scaled coordinates land in [2^(top_exp-1), 2^top_exp) at most
+// (top_exp = 12 for K <= 64, 11 for K = 128 so that sc^2 |y|^2 <= 2^30 still fits the first norm digit a1 = N * 2^-15)
+__global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__restrict__ scale3, int top_exp) {
     if (threadIdx.x == 0) {
         float mx = __uint_as_float(gmax[4]);
         int e = 0;
         float sc = 1.f;
-        if (mx > 0.f && isfinite(mx)) { (void)frexpf(mx, &e); sc = ldexpf(1.f, 12 - e); }
+        if (mx > 0.f && isfinite(mx)) { (void)frexpf(mx, &e); sc = ldexpf(1.f, top_exp - e); }
         scale3[0] = sc;
         scale3[1] = sc * sc;
         scale3[2] = 1.f / (sc * sc);
@@ -160,8 +162,9 @@ __global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__res
 template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
                               const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
-                              float *__restrict__ rownorm, unsigned *__restrict__ gmax) {
-    const int ROWB = cmk2::row_bytes(KSTEPS), GRAN = ROWB / 16, TILEB = cmk2::tile_bytes(KSTEPS);
+                              float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block) {
+    // yn_block != 0 (K = 128 kernel): no norm slots; the tile image ends with a block of 128 floats sc^2|y|^2
+    const int ROWB = cmk2::row_bytes(KSTEPS), GRAN = ROWB / 16, TILEB = cmk2::tile_bytes(KSTEPS) + (yn_block ? 1024 : 0);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float yn_f = 0.f;
     if (i < n_pad) {
@@ -212,7 +215,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                         h = (_Float16)v;
                         l = (_Float16)(v - (float)h);
                     }
-                } else if (c < d + cmk2::NORM_SLOTS) {
+                } else if (!yn_block && c < d + cmk2::NORM_SLOTS) {
                     h = (_Float16)slot[c - d];
                 }
                 hi[e] = h;
@@ -222,6 +225,11 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
             *reinterpret_cast<cmk2::half8 *>(rowp + (((GRAN / 2 + g) ^ f) * 16)) = lo;
         }
         yn_f = (i < n) ? (float)s2 : 0.f;
+        if (yn_block && is_ref) {
+            float *ynp = reinterpret_cast<float *>(P + tile * TILEB + (size_t)cmk2::BR * ROWB);
+            ynp[r] = (i < n) ? (float)(s2 * (double)sc * (double)sc) : INFINITY;
+            if (r == 0) for (int e = cmk2::BR; e < 256; ++e) ynp[e] = 0.f;
+        }
         if (rownorm && i < n) rownorm[i] = sqrtf(yn_f) * 1.0000002f;
     }
     if (is_ref && gmax) {
@@ -513,22 +521,25 @@ struct KnnPlan2 {
 
 int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
 
-// phase-1 kernel choice: 2 = low-d VALU direct form (d <= 15), 1 = split-fp16 MFMA (d <= 61), 0 = f32-input MFMA
+// phase-1 kernel choice: 2 = low-d VALU direct form (d <= 15), 1 = split-fp16 MFMA K <= 64 (d <= 61),
+// 3 = split-fp16 MFMA K = 128 (d <= 125), 0 = f32-input MFMA
 int phase1_path(int d, int k) {
     const char *e = getenv("CELLMAP_PHASE1");
     if (e && !strcmp(e, "f32")) return 0;
     if (k + knn_slack(k) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
     if (d <= 15 && !(e && !strcmp(e, "f16"))) return 2;
-    return d + cmk2::NORM_SLOTS <= 64 ? 1 : 0;            // needs three spare feature slots for the norm digits
+    if (d + cmk2::NORM_SLOTS <= 64) return 1;             // needs three spare feature slots for the norm digits
+    return d <= 128 ? 3 : 0;  // the K = 128 kernel carries |y|^2 in a side block, all 128 slots hold features
 }
 bool use_f16_path(int d, int k) { return phase1_path(d, k) != 0; }
 
 cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int path, KnnPlan2 *p) {
-    p->KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
+    p->KSTEPS = path == 3 ? cmk2::KSTEPS_W : (d + cmk2::NORM_SLOTS <= 32 ? 2 : 4);
     int slack = k / 4 > 8 ? k / 4 : 8;
     p->Kc = k + slack;
     const int tile_rows = path == 2 ? cmk2::BRL : cmk2::BR;
-    p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d) : (size_t)cmk2::tile_bytes(p->KSTEPS);
+    p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d)
+                         : (path == 3 ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(p->KSTEPS));
     p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
     p->lds = 2 * p->tileb + 64;
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
@@ -538,7 +549,7 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     int ncu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    const int resident = ncu * (8 / cmk2::NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
+    const int resident = path == 3 ? ncu : ncu * (8 / cmk2::NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
     int S = 1;
     if (p->nqb < resident) {
         S = (resident + p->nqb - 1) / p->nqb;
@@ -583,11 +594,12 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     if (f16) {
         char *Rp = (char *)cm_ws_alloc(h, (size_t)p2.n_tiles * p2.tileb);
         char *Qp = (char *)cm_ws_alloc(h, (size_t)p2.nq_pad * p2.rowb);
-        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * p2.Kc);
-        uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * cmk2::NW * 64 * 2 * cmk2::CL);
+        const int wpb = path == 3 ? cmk2::NWW : cmk2::NW;  // waves per workgroup
+        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * p2.Kc);
+        uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * 2 * cmk2::CL);
         if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::BRL : cmk2::BR);
-        if (path == 1) {  // centre at the reference mean (translation leaves every distance unchanged)
+        if (path == 1 || path == 3) {  // centre at the reference mean (translation leaves every distance unchanged)
             double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
             d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
             if (!cpart || !d_mean) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
@@ -602,11 +614,11 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
                                p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp));
         } else {
-            hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3);
+            hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words);
+                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words, path == 3);
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr);
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3);
         }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
@@ -626,10 +638,11 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             g_dbg_ctr = d_ctr;
         }
         if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
+        else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
         else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
         // split-fp16 error bound: f32 accumulation of 3*K+1 terms (taken at 2^-22 per term to be safe about the
         // MFMA's internal summation) + dropped lo*lo term + representation residuals
-        c_eps = 5.5e-5f;
+        c_eps = path == 3 ? 1.0e-4f : 5.5e-5f;  // K = 128: 385 accumulated terms
         // low-d kernel: relative bound of the fp32 direct sum (sign of c_eps selects the certificate form)
         if (path == 2) c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;
     } else {
@@ -663,7 +676,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     }
     if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
     hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                       S, Kc, k, metric, form, qnorm, words, c_eps, path == 1 ? scale3 : (const float *)nullptr,
+                       S, Kc, k, metric, form, qnorm, words, c_eps, (path == 1 || path == 3) ? scale3 : (const float *)nullptr,
                        (const double *)d_mean, idx_offset, flags,
                        d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
     cm_mark(h, 3);
@@ -676,7 +689,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = Kc;
     h->knn_stats[2] = S;
-    h->knn_stats[3] = path == 1 ? 2 : (path == 2 ? 3 : 1);
+    h->knn_stats[3] = path == 1 ? 2 : (path == 2 ? 3 : (path == 3 ? 4 : 1));
     return CM_OK;
 }
 
@@ -689,9 +702,9 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096;
     if (use_f16_path(d, k)) {
-        int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : 4;
+        int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
-        b += cm_align((size_t)n_tiles * cmk2::tile_bytes(KSTEPS) + 65536) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
+        b += cm_align((size_t)n_tiles * (cmk2::tile_bytes(KSTEPS) + 1024) + 65536) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
         b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * Kc) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * 2 * cmk2::CL);
     } else {
         int KP = pick_kp(d);

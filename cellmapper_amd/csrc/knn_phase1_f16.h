@@ -290,7 +290,7 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
 #define CM2_FINAL()                                                                                            \
     {                                                                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+        _Pragma("unroll") for (int j = 0; j < NJ_; ++j) {                                                      \
             for (int ql_ = 0; ql_ < 32; ++ql_) {                                                               \
                 const int wq = j * 32 + ql_;                                                                   \
                 const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int TILEB = tile_bytes(KSTEPS);
     constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
+    constexpr int NJ_ = 2;                 // 32-query accumulators per wave
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;                                            // [2][TILEB]
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     constexpr int TILEB = lowd_tile_bytes(D);
     constexpr int NCHUNK = TILEB / 1024;
     constexpr int NST = BRL / 32;
+    constexpr int NJ_ = 2;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;  // [2][TILEB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -551,6 +553,156 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
 #undef CM2_DMA_TILE_L
         CM2_FINAL();
     }
+    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide variant (62 <= d <= 128): K = 128 feature slots.  The 64-query fragment set of knn_cand_f16 would need 128
+// VGPRs here, so a wave owns 32 queries (one 32x32 accumulator; hi/lo fragments = 64 VGPRs) and a workgroup has 8
+// waves (one workgroup per CU, 256 queries) so that a 64 KB tile still feeds 256 queries.  Rows are 512 B (hi | lo) and
+// use all 128 slots, so |y|^2 cannot ride in spare slots: each tile image carries a block of 128 floats sc^2|y|^2 that
+// is added to the accumulator when the sub-tile is filtered (in the shadow of the next MFMA chain).  Everything else --
+// LDS-DMA ring, swizzle, pipelined filter, lane-private logs, refresh schedule -- is shared with knn_cand_f16.
+constexpr int NWW = 8;            // waves per workgroup of the wide kernel
+constexpr int NTW = NWW * 64;
+constexpr int QBW = NWW * 32;     // queries per workgroup pass
+constexpr int KSTEPS_W = 8;
+__host__ __device__ constexpr int wide_tile_bytes() { return BR * row_bytes(KSTEPS_W) + 1024; }
+
+template <int KSTEPS>
+__global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
+    constexpr int K = KSTEPS * 16;
+    constexpr int ROWB = row_bytes(KSTEPS);
+    constexpr int GRAN = ROWB / 16;
+    constexpr int TILEB = BR * ROWB + 1024;
+    constexpr int NCHUNK = TILEB / 1024;
+    constexpr int NST = BR / 32;
+    constexpr int NJ_ = 1;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *ring = smem;  // [2][TILEB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    uint2 *wsc = nullptr;
+    uint2 *wkept = a.kept + (size_t(blockIdx.x) * NWW + wave) * 64 * a.Kc;
+    uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NWW + wave) * 64 * 2 * CL;
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    (void)wsc;
+
+#define CM2_DMA_TILE_W(t_, buf_)                                                                                \
+    {                                                                                                           \
+        const char *gsrc_ = a.R + (size_t)(t_) * TILEB + lane * 16;                                             \
+        unsigned char *ldst_ = ring + (buf_) * TILEB;                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < (NCHUNK + NWW - 1) / NWW; ++q_) {                               \
+            const int piece_ = wave + q_ * NWW;                                                                 \
+            if (piece_ < NCHUNK)                                                                                \
+                __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + piece_ * 1024),                 \
+                                                 (CM2_AS3 void *)(ldst_ + piece_ * 1024), 16, 0, 0);            \
+        }                                                                                                       \
+    }
+#define CM2_LOAD_AH_W(TILE, ST)                                                                                \
+    {                                                                                                          \
+        const int r_ = (ST) * 32 + c;                                                                          \
+        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
+        const int f_ = swz(r_, KSTEPS);                                                                        \
+        _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
+            ah[s] = *reinterpret_cast<const half8 *>(rowp_ + (((2 * s + hh)) ^ f_) * 16);                      \
+    }
+#define CM2_LOAD_AL_W(TILE, ST)                                                                                \
+    {                                                                                                          \
+        const int r_ = (ST) * 32 + c;                                                                          \
+        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
+        const int f_ = swz(r_, KSTEPS);                                                                        \
+        _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
+            al[s] = *reinterpret_cast<const half8 *>(rowp_ + ((GRAN / 2 + 2 * s + hh) ^ f_) * 16);             \
+        const float *yp_ = reinterpret_cast<const float *>((TILE) + BR * ROWB) + (ST) * 32 + 4 * hh;           \
+        y0 = *reinterpret_cast<const f32x4 *>(yp_);                                                            \
+        y1 = *reinterpret_cast<const f32x4 *>(yp_ + 8);                                                        \
+        y2 = *reinterpret_cast<const f32x4 *>(yp_ + 16);                                                       \
+        y3 = *reinterpret_cast<const f32x4 *>(yp_ + 24);                                                       \
+    }
+
+    const int n_work = a.nqb * a.S;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int qb = work / a.S, split = work - qb * a.S;
+        const int t0 = split * a.tiles_per_split;
+        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        const int64_t qbase = (int64_t)qb * QBW + wave * 32;
+        half8 qh[KSTEPS], ql[KSTEPS];
+        {
+            const _Float16 *qrow = a.Q + (qbase + c) * (2 * K);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                qh[s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
+                ql[s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
+            }
+        }
+        // slot 1 of the per-lane state is inert (threshold -inf): the shared macros iterate over two accumulators
+        float thr[2] = {INFINITY, -INFINITY};
+        int cnt[2] = {0, 0};
+        int keptn[2] = {0, 0};
+
+        __builtin_amdgcn_s_barrier();
+        if (t0 < t1) CM2_DMA_TILE_W(t0, t0 & 1);
+        f32x16 p0, py;   // previous sub-tile: raw accumulator (-2 q.y) and its rows' |y|^2
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p0[e] = INFINITY; py[e] = 0.f; }
+        int prbase = 0;
+        int next_refresh = t0 + 1;
+        for (int t = t0; t < t1; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < t1) CM2_DMA_TILE_W(t + 1, (t + 1) & 1);
+            const unsigned char *tile = ring + (t & 1) * TILEB;
+            half8 ah[KSTEPS], al[KSTEPS];
+            f32x4 y0, y1, y2, y3;
+            CM2_LOAD_AH_W(tile, 0);
+            CM2_LOAD_AL_W(tile, 0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                f32x16 acc0, cy;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cy[e] = y0[e]; cy[4 + e] = y1[e]; cy[8 + e] = y2[e]; cy[12 + e] = y3[e]; }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[s], acc0, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[s], acc0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NST) CM2_LOAD_AH_W(tile, st + 1);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[s], acc0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NST) CM2_LOAD_AL_W(tile, st + 1);
+                // filter the PREVIOUS sub-tile in the shadow of the chain above: value = |y|^2 - 2 q.y
+                f32x16 pv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[e] = p0[e] + py[e];
+                float mp0;
+                CM2_MIN16(pv, mp0);
+                const float mp1 = INFINITY;
+                CM2_FILTER(pv, pv, mp0, mp1, prbase);
+                p0 = acc0;
+                py = cy;
+                prbase = t * BR + st * 32 + 4 * hh;
+            }
+            CM2_REFRESH(t, t0);
+        }
+        {
+            f32x16 pv;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pv[e] = p0[e] + py[e];
+            float mp0;
+            CM2_MIN16(pv, mp0);
+            const float mp1 = INFINITY;
+            CM2_FILTER(pv, pv, mp0, mp1, prbase);
+        }
+        CM2_FINAL();
+    }
+#undef CM2_DMA_TILE_W
+#undef CM2_LOAD_AH_W
+#undef CM2_LOAD_AL_W
     (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc;
 }
 

@@ -37,3 +37,11 @@ cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk
     }
     CM_FAIL(h, CM_E_INTERNAL, "phase1/lowd: no instantiation for D=%d", D);
 }
+
+cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    auto kern = cmk2::knn_cand_f16w<cmk2::KSTEPS_W>;
+    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NTW), lds, h->stream, a);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}

@@ -144,6 +144,9 @@ def test_lowd_direct_path_matches_oracle(n, nq, d, k, dtype, scale, hip, oracle)
     (2000, 600, 61, 20, np.float32),  # widest embedding of the split-fp16 kernel (61 + 3 norm slots = 64)
     (2000, 600, 62, 20, np.float32),  # first width served by the f32-input MFMA kernel
     (1500, 300, 200, 10, np.float32), # wide embedding (f32-input MFMA kernel)
+    (9000, 1300, 128, 30, np.float32),      # widest embedding of the K=128 split-fp16 kernel (config 4 width)
+    (40000, 700, 100, 15, np.float64),      # K=128 kernel, float64 input, reference splits
+    (3000, 300, 129, 10, np.float32),       # first width beyond it (f32-input MFMA kernel)
     (4000, 500, 50, 100, np.float32), # k = 100: K' = 125, 512-entry merges
     (3000, 200, 30, 300, np.float32), # k beyond the in-register merge: f32-input kernel with LDS candidate buffers
     (2500, 400, 16, 5, np.float32),   # smallest d on the MFMA path (d > 15 -> GEMM-form distances)
