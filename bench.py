@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--ncat", type=int, default=20)
     ap.add_argument("--kernel", default="gaussian")
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
+    ap.add_argument("--ref-shards", type=int, default=0,
+                    help="reference shards R (world = query groups x R); 0 = default (2 when world is even), world = pure reference sharding")
     ap.add_argument("--cpu-sample", type=int, default=768, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--check", type=int, default=256, help="queries verified against the CPU oracle (0 = skip)")
     return ap.parse_args()
@@ -78,7 +80,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from cellmapper_amd.device import DevicePipeline
-    from cellmapper_amd.sharded import HipOps, shard_bounds, sharded_map_labels
+    from cellmapper_amd.sharded import HipOps, grid_2d, make_groups, shard_bounds, sharded_map_labels
 
     pipe = DevicePipeline(local_rank)
     pipe.h.set_profiling(True)
@@ -87,7 +89,11 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     ref_full_rows = a.nref
-    lo, hi = shard_bounds(ref_full_rows, world, rank)
+    n_groups, ref_shards = grid_2d(world, a.ref_shards or None)
+    qgroup, ref_rank = rank // ref_shards, rank % ref_shards
+    pg = make_groups(dist, world, n_groups, ref_shards) if world > 1 else None
+    lo, hi = shard_bounds(ref_full_rows, ref_shards, ref_rank)
+    gq_lo, gq_hi = shard_bounds(a.nq, n_groups, qgroup)  # this query group's rows
     # every rank draws the same stream and keeps its shard, so the global problem is independent of N
     ref = torch.empty((hi - lo, a.d), dtype=torch.float32, device=dev)
     chunk = 250_000
@@ -97,7 +103,9 @@ def main():
         s0, s1 = max(c0, lo), min(c1, hi)
         if s0 < s1:
             ref[s0 - lo:s1 - lo] = blk[s0 - c0:s1 - c0]
-    qry = torch.randn((a.nq, a.d), generator=g, dtype=torch.float32, device=dev)
+    qry_all = torch.randn((a.nq, a.d), generator=g, dtype=torch.float32, device=dev)
+    qry = qry_all[gq_lo:gq_hi].contiguous() if n_groups > 1 else qry_all
+    del qry_all
     codes = torch.randint(0, a.ncat, (ref_full_rows,), generator=g, device=dev, dtype=torch.int32)
     torch.cuda.synchronize()
 
@@ -108,7 +116,8 @@ def main():
         if world == 1:
             return pipe.map_labels(ref, qry, a.k, codes, a.ncat, kernel=a.kernel)
         code, conf, _, _, _ = sharded_map_labels(ops, dist, ref, lo, ref_full_rows, qry, a.k, codes, a.ncat,
-                                                 kernel=a.kernel, exchange=a.exchange)
+                                                 kernel=a.kernel, exchange=a.exchange, group=pg, ref_world=ref_shards,
+                                                 ref_rank=ref_rank)
         return code, conf
 
     for _ in range(a.warmup):
@@ -139,16 +148,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         value = a.nq * a.steps / elapsed
-        flops = 2.0 * a.nq * (hi - lo) * a.d  # algorithmic flops of the distance contraction on this rank's shard
+        flops = 2.0 * qry.shape[0] * (hi - lo) * a.d  # algorithmic flops of the distance contraction on this rank
         p1 = float(np.mean(p1_ms))
         achieved = flops / (p1 * 1e-3) / 1e12
-        f16_path = fb["lowd_path"] == 2  # knn_stats[3]: 1 = f32-input MFMA kernel, 2 = split-fp16 MFMA kernel
+        # knn_stats[3]: 1 = f32-input MFMA kernel, 2 = split-fp16 MFMA (K<=64), 3 = low-d VALU, 4 = split-fp16 MFMA (K=128)
+        f16_path = fb["lowd_path"] in (2, 4)
         peak = PEAK_F16_MFMA_TFLOPS if f16_path else PEAK_F32_MFMA_TFLOPS
         kname = ("knn_cand_f16 (split-fp16 v_mfma_f32_32x32x16_f16 distance GEMM + fused top-k filter)" if f16_path
                  else "knn_cand_mfma (v_mfma_f32_32x32x2_f32 distance GEMM + fused top-k filter)")
         # the split-fp16 kernel executes 3 MFMA products over the feature dimension padded to a multiple of 16 (+3 slots)
-        kpad = 32 if a.d + 3 <= 32 else 64
-        executed = 3.0 * 2.0 * a.nq * (hi - lo) * kpad if f16_path else 2.0 * a.nq * (hi - lo) * (4 * ((a.d + 4) // 4))
+        kpad = 128 if fb["lowd_path"] == 4 else (32 if a.d + 3 <= 32 else 64)
+        executed = (3.0 * 2.0 * qry.shape[0] * (hi - lo) * kpad if f16_path
+                    else 2.0 * qry.shape[0] * (hi - lo) * (4 * ((a.d + 4) // 4)))
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "phase1_hbm_traffic.json")
         if os.path.exists(tfile) and world == 1 and a.nq == 1_500_000 and a.nref == 1_500_000:
@@ -160,11 +171,13 @@ def main():
             "metric": "query cells/s end-to-end (k-NN+kernel+transfer)",
             "value": value, "unit": "query cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16" if fb["lowd_path"] == 2 else "f32",
+            "dtype": "f16" if fb["lowd_path"] in (2, 4) else "f32",
             "data": "synthetic",
             "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.kernel} kernel, "
-                                   f"{a.ncat}-class label transfer (BASELINE configs[1]); reference rows sharded over "
-                                   f"{world} GPU(s), exchange={a.exchange if world > 1 else 'none'}",
+                                   f"{a.ncat}-class label transfer (BASELINE configs[1]); {world} GPU(s) = {n_groups} query "
+                                   f"group(s) x {ref_shards} reference shard(s), exchange="
+                                   f"{a.exchange if ref_shards > 1 else 'none'}",
+                       "parallelism": f"q{n_groups}xr{ref_shards}",
                        "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
                        "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"]},
             "roofline": {"bound": "mfma", "kernel": kname,

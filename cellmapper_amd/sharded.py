@@ -1,7 +1,8 @@
 """Reference-sharded k-NN -> kernel -> label transfer across the GPUs of one node.
 
-Layout: rank r holds reference rows ``[lo_r, hi_r)`` (contiguous split) plus their label codes' full replica, and
-ALL query rows.  Per step:
+Layout (2-D): ``world = query groups x reference shards``, rank = group * shards + shard.  A rank holds the reference
+rows ``[lo, hi)`` of its shard (contiguous split), the full label-code vector, and the query rows of its group
+(pure reference sharding = one group = every rank holds ALL queries).  Per step, inside a reference-shard group:
 
 1. local exact top-k of every query against the rank's shard, with GLOBAL reference indices (``idx_offset``)
    and squared float64 distances;
@@ -69,13 +70,51 @@ class HipOps:
         return self.t.cat([x, pad], 0)
 
 
+def grid_2d(world: int, ref_shards: int | None = None):
+    """(query groups, reference shards) with ``groups * shards == world``.
+
+    The reference is always partitioned when there is more than one GPU; by default two-way, and the
+    remaining parallelism goes to the QUERY axis: query groups need no exchange at all, and a rank's shard stays large
+    enough for the filter's log-n per-query overhead to amortise.  ``ref_shards=world`` gives the
+    pure reference sharding of the north-star wording.
+    """
+    if ref_shards is None:
+        ref_shards = 2 if world % 2 == 0 else (world if world > 1 else 1)
+    ref_shards = max(1, min(world, int(ref_shards)))
+    while world % ref_shards:
+        ref_shards -= 1
+    return world // ref_shards, ref_shards
+
+
+def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int):
+    """Process groups of the 2-D layout: rank = group * ref_shards + shard.  Every rank creates every group (required by
+    torch.distributed) and gets back the one it belongs to (None when a group is the whole world or a single rank)."""
+    if world == 1 or ref_shards == 1:
+        return None
+    if n_groups == 1:
+        return None  # the exchange runs on the default (world) group
+    mine = None
+    rank = dist_mod.get_rank()
+    for g in range(n_groups):
+        ranks = list(range(g * ref_shards, (g + 1) * ref_shards))
+        pg = dist_mod.new_group(ranks=ranks)
+        if rank in ranks:
+            mine = pg
+    return mine
+
+
 def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, codes, n_cat, metric="euclidean",
-                       kernel="gaussian", epsilon=1e-8, exchange="alltoall"):
+                       kernel="gaussian", epsilon=1e-8, exchange="alltoall", group=None, ref_world=None, ref_rank=None):
     """Run one sharded step.  Returns ``(code, conf, (q_lo, q_hi), dist, idx)`` for this rank's query slice.
 
     ``dist_mod`` is ``torch.distributed`` (already initialised); ``ops`` supplies compute (HipOps in production).
+    ``qry`` holds the queries of this rank's QUERY GROUP; ``group`` / ``ref_world`` / ``ref_rank`` describe the
+    reference-shard group the exchange runs in (default: the whole world = pure reference sharding).  The bandwidth
+    statistics are always reduced over the whole world.  ``(q_lo, q_hi)`` is relative to ``qry``.
     """
-    world, rank = dist_mod.get_world_size(), dist_mod.get_rank()
+    n_all = dist_mod.get_world_size()
+    world = n_all if ref_world is None else ref_world
+    rank = dist_mod.get_rank() if ref_rank is None else ref_rank
     nq = qry.shape[0]
     per = (nq + world - 1) // world
     nq_pad = per * world
@@ -88,13 +127,13 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
         if exchange == "alltoall":
             rd = ops.empty_like_parts(world, per, k, d2p)
             ri = ops.empty_like_parts(world, per, k, gip)
-            dist_mod.all_to_all_single(rd.view(world * per, k), d2p.view(world * per, k))
-            dist_mod.all_to_all_single(ri.view(world * per, k), gip.view(world * per, k))
+            dist_mod.all_to_all_single(rd.view(world * per, k), d2p.view(world * per, k), group=group)
+            dist_mod.all_to_all_single(ri.view(world * per, k), gip.view(world * per, k), group=group)
         elif exchange == "allgather":
             gd = ops.empty_like_parts(world, nq_pad, k, d2p)
             gg = ops.empty_like_parts(world, nq_pad, k, gip)
-            dist_mod.all_gather_into_tensor(gd.view(world * nq_pad, k), d2p)
-            dist_mod.all_gather_into_tensor(gg.view(world * nq_pad, k), gip)
+            dist_mod.all_gather_into_tensor(gd.view(world * nq_pad, k), d2p, group=group)
+            dist_mod.all_gather_into_tensor(gg.view(world * nq_pad, k), gip, group=group)
             rd = gd[:, rank * per:(rank + 1) * per]
             ri = gg[:, rank * per:(rank + 1) * per]
         else:
@@ -106,12 +145,12 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
     param = None
     if kernel in ("gaussian", "scarches"):
         m = ops.moments(dist, idx)
-        if world > 1:
+        if n_all > 1:
             dist_mod.all_reduce(m)
         param = ops.param(m, "gaussian")  # mean distance
         if kernel == "scarches":
             m2 = ops.moments(dist, idx, center=param)
-            if world > 1:
+            if n_all > 1:
                 dist_mod.all_reduce(m2)
             param = ops.param(m2, "scarches")
     code, conf = ops.weights_vote(dist, idx, n_ref_total, kernel, param, codes, n_cat, epsilon)

@@ -170,6 +170,18 @@ def test_query_imputed_setter_validation():
     assert cm.query_imputed is None
 
 
+def test_grid_2d_layout():
+    from cellmapper_amd.sharded import grid_2d
+
+    assert grid_2d(1) == (1, 1) and grid_2d(2) == (1, 2) and grid_2d(4) == (2, 2) and grid_2d(8) == (4, 2)
+    assert grid_2d(8, 8) == (1, 8) and grid_2d(8, 4) == (2, 4) and grid_2d(8, 1) == (8, 1)
+    assert grid_2d(3) == (1, 3) and grid_2d(6, 4) == (2, 3)
+    for w in range(1, 17):
+        for r in (None, 1, 2, 3, 4, 8, 16):
+            g, s = grid_2d(w, r)
+            assert g * s == w and g >= 1 and s >= 1
+
+
 def test_shard_bounds_partition():
     from cellmapper_amd.sharded import shard_bounds, slice_bounds
 

@@ -60,12 +60,12 @@ class OracleOps:
         return self.t.cat([x, self.t.zeros((n - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype)], 0)
 
 
-def _worker(rank, world, port, exchange, kernel, out_dir):
+def _worker(rank, world, port, exchange, kernel, out_dir, ref_shards=None):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
 
-    from cellmapper_amd.sharded import shard_bounds, sharded_map_labels
+    from cellmapper_amd.sharded import grid_2d, make_groups, shard_bounds, sharded_map_labels
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -77,23 +77,31 @@ def _worker(rank, world, port, exchange, kernel, out_dir):
     qry = rng.standard_normal((nq, d)).astype(np.float32)
     qry[0] = ref[10]
     codes = rng.integers(0, n_cat, n_ref).astype(np.int32)
-    lo, hi = shard_bounds(n_ref, world, rank)
+    n_groups, rshards = grid_2d(world, ref_shards)
+    qgroup, ref_rank = rank // rshards, rank % rshards
+    pg = make_groups(dist, world, n_groups, rshards)
+    lo, hi = shard_bounds(n_ref, rshards, ref_rank)
+    g_lo, g_hi = shard_bounds(nq, n_groups, qgroup)
     code, conf, (q_lo, q_hi), dd, ii = sharded_map_labels(
-        OracleOps(), dist, torch.from_numpy(ref[lo:hi].copy()), lo, n_ref, torch.from_numpy(qry), k,
-        torch.from_numpy(codes), n_cat, kernel=kernel, exchange=exchange)
-    np.savez(os.path.join(out_dir, f"r{rank}.npz"), code=code.numpy(), conf=conf.numpy(), q_lo=q_lo, q_hi=q_hi,
+        OracleOps(), dist, torch.from_numpy(ref[lo:hi].copy()), lo, n_ref, torch.from_numpy(qry[g_lo:g_hi].copy()), k,
+        torch.from_numpy(codes), n_cat, kernel=kernel, exchange=exchange, group=pg, ref_world=rshards, ref_rank=ref_rank)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), code=code.numpy(), conf=conf.numpy(), q_lo=g_lo + q_lo, q_hi=g_lo + q_hi,
              dist=dd.numpy(), idx=ii.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,kernel", [("alltoall", "gaussian"), ("allgather", "scarches")])
-def test_sharded_choreography_world2(exchange, kernel, tmp_path, oracle):
+@pytest.mark.parametrize("world,ref_shards,exchange,kernel", [
+    (2, None, "alltoall", "gaussian"),    # 1 query group x 2 reference shards (pure reference sharding)
+    (2, None, "allgather", "scarches"),
+    (4, 2, "alltoall", "gaussian"),       # 2 query groups x 2 reference shards: sub-group exchange, world-wide sigma
+    (3, 3, "alltoall", "scarches"),       # odd world, ragged slices
+])
+def test_sharded_choreography(world, ref_shards, exchange, kernel, tmp_path, oracle):
     import torch.multiprocessing as mp
 
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + (0 if exchange == "alltoall" else 1)
-    mp.spawn(_worker, args=(world, port, exchange, kernel, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + world * 7 + (0 if exchange == "alltoall" else 1)
+    mp.spawn(_worker, args=(world, port, exchange, kernel, str(tmp_path), ref_shards), nprocs=world, join=True)
     rng = np.random.default_rng(0)
     n_ref, nq, d, k, n_cat = 3001, 203, 20, 12, 7
     ref = rng.standard_normal((n_ref, d)).astype(np.float32)
@@ -103,7 +111,8 @@ def test_sharded_choreography_world2(exchange, kernel, tmp_path, oracle):
     codes = rng.integers(0, n_cat, n_ref).astype(np.int32)
     full = oracle.run_path(ref, qry, k, kernel=kernel, labels=codes, n_cat=n_cat)
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
-    assert int(parts[0]["q_lo"]) == 0 and int(parts[-1]["q_hi"]) == nq and int(parts[0]["q_hi"]) == int(parts[1]["q_lo"])
+    assert int(parts[0]["q_lo"]) == 0 and int(parts[-1]["q_hi"]) == nq
+    assert all(int(parts[r]["q_hi"]) == int(parts[r + 1]["q_lo"]) for r in range(world - 1))
     idx = np.concatenate([p["idx"] for p in parts])
     dist_ = np.concatenate([p["dist"] for p in parts])
     assert np.array_equal(idx, full["idx"]), "merged global indices must equal the unsharded search"
