@@ -256,3 +256,43 @@ def test_presence_scores_match_reference():
     from cellmapper_amd import _native
     raw = _native.default_handle().presence_scores(g["yx_dist"], g["yx_idx"], n_ref)
     np.testing.assert_allclose(raw[:, 0], g["raw_all"], rtol=1e-12)
+
+
+class _SoloDist:
+    """torch.distributed stand-in for a single process (the collectives of the sharded driver are skipped at world 1)."""
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+
+@pytest.mark.parametrize("kernel", ["gaussian", "scarches", "inverse_distance"])
+def test_sharded_driver_device_ops_match_fused_pipeline(kernel):
+    """The device-tier ops the multi-GPU driver composes (squared local k-NN, merge, moments, bandwidth, weights,
+    ELL->CSR, vote) must reproduce the fused single-GPU pipeline bit for bit."""
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+    from cellmapper_amd.sharded import HipOps, shard_bounds, sharded_map_labels
+
+    rng = np.random.default_rng(12)
+    n_ref, nq, d, k, n_cat = 20000, 3000, 50, 30, 20
+    pipe = DevicePipeline(0)
+    with torch.cuda.stream(pipe.stream):
+        ref = torch.from_numpy(rng.standard_normal((n_ref, d)).astype(np.float32)).cuda()
+        qry = torch.from_numpy(rng.standard_normal((nq, d)).astype(np.float32)).cuda()
+        codes = torch.from_numpy(rng.integers(0, n_cat, n_ref).astype(np.int32)).cuda()
+        code0, conf0, d0, i0 = pipe.map_labels(ref, qry, k, codes, n_cat, kernel=kernel, want_graph=True)
+        ops = HipOps(pipe)
+        code1, conf1, (lo, hi), d1, i1 = sharded_map_labels(ops, _SoloDist, ref, 0, n_ref, qry, k, codes, n_cat, kernel=kernel)
+        # emulate two reference shards + the merge by hand, then the per-slice tail of the driver
+        parts = [pipe.knn(ref[a:b].contiguous(), qry, k, idx_offset=a, squared=True)
+                 for a, b in (shard_bounds(n_ref, 2, r) for r in range(2))]
+        dm, im = pipe.merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), k)
+        torch.cuda.synchronize()
+    assert (lo, hi) == (0, nq)
+    assert torch.equal(i1, i0) and torch.equal(d1, d0) and torch.equal(im, i0) and torch.equal(dm, d0)
+    assert torch.equal(code1, code0) and torch.equal(conf1, conf0)
