@@ -263,8 +263,17 @@ class CellMapper(PresenceMixin):
     def _map_obs_categorical(self, key: str, prediction_postfix: str, confidence_postfix: str) -> None:
         indptr, cols, vals = self._require_mapping()
         col = self.reference.obs[key]
-        # sorted unique observed values: the category order sklearn's OneHotEncoder would produce
-        categories, codes = np.unique(np.asarray(col), return_inverse=True)
+        # sorted unique OBSERVED values: the category order sklearn's OneHotEncoder would produce
+        if isinstance(col.dtype, pd.CategoricalDtype) and not col.isna().any():
+            raw = col.cat.codes.to_numpy()
+            cats = np.asarray(col.cat.categories)
+            present = np.unique(raw)
+            order = present[np.argsort(cats[present], kind="stable")]
+            remap = np.full(len(cats), -1, dtype=np.int64)
+            remap[order] = np.arange(len(order))
+            codes, categories = remap[raw], cats[order]
+        else:
+            categories, codes = np.unique(np.asarray(col), return_inverse=True)
         code, conf = _native.default_handle().label_vote(indptr, cols, vals, codes.astype(np.int32), len(categories))
         pred = pd.Series(data=categories[code], index=self.query.obs_names, dtype=col.dtype)
         self.query.obs[f"{key}_{prediction_postfix}"] = pred

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -419,6 +420,7 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
     size_t free_b = 0, total_b = 0;
     CM_HIP(h, hipMemGetInfo(&free_b, &total_b));
     size_t budget = free_b / 2;
+    if (const char *e = getenv("CELLMAP_SPMM_BUDGET_MB")) budget = (size_t)atoll(e) << 20;  // testing: force column slabs
     int64_t cw = n_out;
     size_t per_col = es * ((size_t)n_ref + (size_t)nq);
     if (per_col * (size_t)n_out > budget) {

@@ -235,6 +235,22 @@ def test_shared_neighbors_match_reference_and_scipy(hip):
     np.testing.assert_array_equal(ours.data, ref.data)
 
 
+def test_spmm_dense_column_slabs(hip, oracle, monkeypatch):
+    """Payloads wider than the device budget are processed in column slabs (hipMemcpy2D); same bits as one pass."""
+    rng = np.random.default_rng(8)
+    n_ref, nq, k, G = 3000, 700, 12, 1000
+    cols = np.sort(rng.integers(0, n_ref, (nq, k)), axis=1).astype(np.int32).ravel()
+    vals = rng.random(nq * k, dtype=np.float32)
+    indptr = np.arange(nq + 1, dtype=np.int64) * k
+    for dt in (np.float32, np.float64):
+        X = rng.random((n_ref, G)).astype(dt)
+        want = oracle.spmm_dense(indptr, cols, vals, X)
+        np.testing.assert_array_equal(hip.spmm_dense(indptr, cols, vals, X), want)
+        monkeypatch.setenv("CELLMAP_SPMM_BUDGET_MB", "4")  # 4 MB -> several 64-column-aligned slabs
+        np.testing.assert_array_equal(hip.spmm_dense(indptr, cols, vals, X), want)
+        monkeypatch.delenv("CELLMAP_SPMM_BUDGET_MB")
+
+
 def test_error_conventions(hip):
     x = np.zeros((5, 20), np.float32)
     with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
