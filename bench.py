@@ -156,9 +156,10 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS if f16_path else PEAK_F32_MFMA_TFLOPS
         kname = ("knn_cand_f16 (split-fp16 v_mfma_f32_32x32x16_f16 distance GEMM + fused top-k filter)" if f16_path
                  else "knn_cand_mfma (v_mfma_f32_32x32x2_f32 distance GEMM + fused top-k filter)")
-        # the split-fp16 kernel executes 3 MFMA products over the feature dimension padded to a multiple of 16 (+3 slots)
+        # the split-fp16 kernel executes 1-3 MFMA products over the feature dimension padded to a multiple of 16 (+3 slots)
         kpad = 128 if fb["lowd_path"] == 4 else (32 if a.d + 3 <= 32 else 64)
-        executed = (3.0 * 2.0 * qry.shape[0] * (hi - lo) * kpad if f16_path
+        nprod = max(1, fb.get("filter_products", 3))  # split products the adaptive filter ended up evaluating
+        executed = (nprod * 2.0 * qry.shape[0] * (hi - lo) * kpad if f16_path
                     else 2.0 * qry.shape[0] * (hi - lo) * (4 * ((a.d + 4) // 4)))
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "phase1_hbm_traffic.json")
@@ -179,7 +180,8 @@ def main():
                                    f"{a.exchange if ref_shards > 1 else 'none'}",
                        "parallelism": f"q{n_groups}xr{ref_shards}",
                        "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
-                       "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"]},
+                       "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"],
+                       "filter_products": fb.get("filter_products", 0)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "kernel_ms": p1,

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int d, const int *__restrict__ cand, const float *__restrict__ cthr,
                                                    int S, int Kc, int k, int metric, int form,
                                                    const float *__restrict__ qnorm, const unsigned *__restrict__ gmax,
-                                                   float c_eps, const float *__restrict__ scale3,
+                                                   float c_eps, float c_split, const float *__restrict__ scale3,
                                                    const double *__restrict__ mean, int64_t idx_offset,
                                                    int flags, void *__restrict__ out_dist,
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             }
             double sk = ((metric == CM_METRIC_COSINE) ? 2.0 * kth : kth) - qn2;
             double ymax2 = (double)__uint_as_float(gmax[0]), ymax = (double)__uint_as_float(gmax[1]);
-            double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30);
+            // c_eps: accumulation / representation error on every term; c_split: split products that were dropped
+            double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30) +
+                         (double)c_split * 2.0 * (double)qnorm[i] * ymax;
             certified = sk < (double)tau - eps;
         } else if (tau < INFINITY) {
             // low-d kernel: phase-1 value is the full direct squared distance sum (q-y)^2 in fp32; relative error
@@ -520,31 +522,37 @@ struct KnnPlan2 {
 };
 
 int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
+// candidate slack of the split-fp16 kernels by number of products evaluated (coarser filter -> wider safety margin)
+int knn_slack_level(int k, int nprod) {
+    if (nprod >= 3) return knn_slack(k);
+    if (nprod == 2) return k / 3 > 12 ? k / 3 : 12;
+    return k / 2 > 16 ? k / 2 : 16;
+}
 
 // phase-1 kernel choice: 2 = low-d VALU direct form (d <= 15), 1 = split-fp16 MFMA K <= 64 (d <= 61),
 // 3 = split-fp16 MFMA K = 128 (d <= 125), 0 = f32-input MFMA
 int phase1_path(int d, int k) {
     const char *e = getenv("CELLMAP_PHASE1");
     if (e && !strcmp(e, "f32")) return 0;
-    if (k + knn_slack(k) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
+    if (k + knn_slack_level(k, 1) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
     if (d <= 15 && !(e && !strcmp(e, "f16"))) return 2;
     if (d + cmk2::NORM_SLOTS <= 64) return 1;             // needs three spare feature slots for the norm digits
     return d <= 128 ? 3 : 0;  // the K = 128 kernel carries |y|^2 in a side block, all 128 slots hold features
 }
 bool use_f16_path(int d, int k) { return phase1_path(d, k) != 0; }
 
-cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int path, KnnPlan2 *p) {
+cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int path, int nprod, KnnPlan2 *p) {
     p->KSTEPS = path == 3 ? cmk2::KSTEPS_W : (d + cmk2::NORM_SLOTS <= 32 ? 2 : 4);
-    int slack = k / 4 > 8 ? k / 4 : 8;
-    p->Kc = k + slack;
+    p->Kc = k + ((path == 1 || path == 3) ? knn_slack_level(k, nprod) : knn_slack(k));
     const int tile_rows = path == 2 ? cmk2::BRL : cmk2::BR;
     p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d)
                          : (path == 3 ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(p->KSTEPS));
     p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
     p->lds = 2 * p->tileb + 64;
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
-    p->nq_pad = (nq + cmk2::QB - 1) / cmk2::QB * cmk2::QB;
-    p->nqb = (int)(p->nq_pad / cmk2::QB);
+    const int qb = path == 3 ? cmk2::QBW : cmk2::QB;  // queries per workgroup pass of the chosen kernel
+    p->nq_pad = (nq + qb - 1) / qb * qb;
+    p->nqb = (int)(p->nq_pad / qb);
     p->n_tiles = (int)((n_ref + tile_rows - 1) / tile_rows);
     int ncu = 256;
     hipDeviceProp_t prop;
@@ -576,10 +584,21 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     KnnPlan2 p2;
     int Kc, S;
     int64_t nq_pad;
-    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, path, &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
+    // Adaptive filter precision (split-fp16 kernels): start with the cheapest split (hi*hi only, 1/3 of the MFMA work,
+    // bound ~2^-10 |q||y|); if more than a sliver of the queries cannot be certified, redo the filter with all three
+    // products.  Exactness never depends on the level -- the certificate uses the matching bound.
+    int levels[2] = {3, 0}, n_levels = 1;
+    if (path == 1 || path == 3) {
+        const char *e = getenv("CELLMAP_FILTER_PRODUCTS");
+        int forced = e ? atoi(e) : 0;
+        if (forced >= 1 && forced <= 3) levels[0] = forced;
+        else if (!(flags & CM_KNN_FORCE_FALLBACK)) { levels[0] = 1; levels[1] = 3; n_levels = 2; }
+    }
+    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, path, levels[0], &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
     else { CM_TRY(make_plan(h, n_ref, nq, d, k, &p)); Kc = p.Kc; S = p.S; nq_pad = p.nq_pad; }
+    const int Kc_max = Kc;  // level 1 has the widest candidate list: buffers are sized for it
     float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
-    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc);
+    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc_max);
     float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad * S);
     int *flag_list = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
     double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
@@ -589,13 +608,15 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     double *d_mean = nullptr;
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
-    float c_eps;
+    float c_eps, c_split = 0.f;
+    int level_used = 3;
+    bool reranked = false;
     const int bs = 256;
     if (f16) {
         char *Rp = (char *)cm_ws_alloc(h, (size_t)p2.n_tiles * p2.tileb);
         char *Qp = (char *)cm_ws_alloc(h, (size_t)p2.nq_pad * p2.rowb);
         const int wpb = path == 3 ? cmk2::NWW : cmk2::NW;  // waves per workgroup
-        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * p2.Kc);
+        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * Kc_max);
         uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * 2 * cmk2::CL);
         if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::BRL : cmk2::BR);
@@ -637,14 +658,35 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             a.ctr = d_ctr;
             g_dbg_ctr = d_ctr;
         }
-        if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
-        else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
-        else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
         // split-fp16 error bound: f32 accumulation of 3*K+1 terms (taken at 2^-22 per term to be safe about the
         // MFMA's internal summation) + dropped lo*lo term + representation residuals
         c_eps = path == 3 ? 1.0e-4f : 5.5e-5f;  // K = 128: 385 accumulated terms
         // low-d kernel: relative bound of the fp32 direct sum (sign of c_eps selects the certificate form)
         if (path == 2) c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;
+        for (int li = 0; li < n_levels; ++li) {
+            const int nprod = levels[li];
+            level_used = nprod;
+            if (path == 1 || path == 3) { Kc = k + knn_slack_level(k, nprod); a.Kc = Kc; }
+            a.nprod = nprod;
+            // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
+            c_split = (path == 1 || path == 3) ? (nprod == 1 ? 2.0f : (nprod == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f : 0.f;
+            if (li > 0) hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+            if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
+            else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
+            else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
+            cm_mark(h, 2);
+            if (li + 1 == n_levels) break;
+            // not the last level: re-rank now and look at how many queries failed the certificate
+            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
+                               S, Kc, k, metric, form, qnorm, words, c_eps, c_split, scale3, (const double *)d_mean, idx_offset,
+                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
+            cm_mark(h, 3);
+            CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            CM_HIP(h, hipStreamSynchronize(st));
+            const int64_t nflag = h->d_nflag_pinned[0];
+            const int64_t tolerated = nq / 2000 > 64 ? nq / 2000 : 64;
+            if (nflag <= tolerated) { reranked = true; break; }
+        }
     } else {
         float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
         float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
@@ -666,7 +708,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
         c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
     }
-    cm_mark(h, 2);
+    if (!f16) cm_mark(h, 2);
     if (f16 && g_dbg_ctr) {
         unsigned long long hc[8] = {0};
         (void)hipStreamSynchronize(st);
@@ -675,11 +717,12 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                 hc[0], hc[1], hc[2], hc[3], hc[4], hc[5]);
     }
     if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
-    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                       S, Kc, k, metric, form, qnorm, words, c_eps, (path == 1 || path == 3) ? scale3 : (const float *)nullptr,
-                       (const double *)d_mean, idx_offset, flags,
-                       d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
-    cm_mark(h, 3);
+    if (!reranked)
+        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
+                           S, Kc, k, metric, form, qnorm, words, c_eps, c_split,
+                           (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
+                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
+    if (!reranked) cm_mark(h, 3);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
                        (int *)(words + 3));
@@ -688,7 +731,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = Kc;
-    h->knn_stats[2] = S;
+    h->knn_stats[2] = S + 100 * ((path == 1 || path == 3) ? level_used : 0);
     h->knn_stats[3] = path == 1 ? 2 : (path == 2 ? 3 : (path == 3 ? 4 : 1));
     return CM_OK;
 }
@@ -696,7 +739,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
 }  // namespace
 
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t /*dtype*/) {
-    int slack = k / 4 > 8 ? k / 4 : 8;
+    int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
     size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +

@@ -9,8 +9,7 @@
 // of the same order as the f32 path's; the float64 re-rank + certificate make the result exact.
 //
 // gfx950 mapping
-//   * workgroup = 4 waves, two workgroups per CU (2 waves per SIMD; a stalled workgroup -- merge/prune, barrier --
-//     leaves the matrix pipe to the other one), persistent over (query block, reference split) work items;
+//   * workgroup = 8 waves (2 per SIMD), one per CU, persistent over (512-query block, reference split) work items;
 //   * wave tile = 32 reference rows x 64 queries: two 32x32 accumulators share one A (reference) fragment; the 64
 //     queries' hi/lo fragments (B operand) stay in VGPRs for the whole pass;
 //   * |y|^2 rides in three spare feature slots as fp16 digits (exact to 2^-33), -2 and the scale are folded into
@@ -37,10 +36,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CM2_BR 128
 #endif
 #ifndef CM2_NW
-#define CM2_NW 4
+#define CM2_NW 8
 #endif
 constexpr int BR = CM2_BR;  // reference rows per LDS tile
-constexpr int NW = CM2_NW;  // waves per workgroup (two workgroups per CU when NW = 4)
+constexpr int NW = CM2_NW;  // waves per workgroup: one 8-wave workgroup per CU (512 queries share every tile fill;
+                            // measured 6-10 % faster than two 4-wave workgroups once threshold refreshes were scheduled)
 constexpr int NT = NW * 64;
 constexpr int QB = NW * 64;  // queries per workgroup pass
 constexpr int CL = 96;       // lane-private append buffer capacity (entries)
@@ -68,6 +68,8 @@ struct P1Args {
     float *cthr;           // [nq_pad][S]   (scaled units)
     uint2 *kept;           // [gridDim.x][NW][64][Kc]    per-resident-wave kept lists
     uint2 *lbuf;           // [gridDim.x][NW][64][2][CL] lane-private append buffers
+    int nprod;             // split products evaluated: 3 = hi*hi + hi*lo + lo*hi (error ~2^-21 |q||y|), 2 = drop lo(ref)*hi
+                           // (~2^-11), 1 = hi*hi only (~2^-10); the certificate in knn_rerank uses the matching bound
     int dbg;               // timing experiments only (CELLMAP_DBG): 1 = never append, 2 = skip the filter, 4 = counters
     unsigned long long *ctr;  // [8] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
 };
@@ -403,8 +405,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             if (t + 1 < t1) CM2_DMA_TILE(t + 1, (t + 1) & 1);
             const unsigned char *tile = ring + (t & 1) * TILEB;
             half8 ah[KSTEPS], al[KSTEPS];
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) al[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
             CM2_LOAD_AH(tile, 0);
-            CM2_LOAD_AL_YN(tile, 0);
+            if (a.nprod >= 3) CM2_LOAD_AL_YN(tile, 0);
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 // accumulator registers map to rows (r&3) + 8*(r>>2) + 4*hh of the sub-tile, one query per lane column
@@ -416,21 +420,25 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[0][s], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[1][s], acc1, 0, 0, 0);
                 }
+                if (a.nprod >= 2) {
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[0][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[1][s], acc1, 0, 0, 0);
+                    for (int s = 0; s < KSTEPS; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[0][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[1][s], acc1, 0, 0, 0);
+                    }
                 }
                 // the hi fragment is dead: fetch the next sub-tile's while the lo products run
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < NST) CM2_LOAD_AH(tile, st + 1);
+                if (a.nprod >= 3) {
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
+                    for (int s = 0; s < KSTEPS; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 1 < NST) CM2_LOAD_AL_YN(tile, st + 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < NST) CM2_LOAD_AL_YN(tile, st + 1);
                 // min-trees of the PREVIOUS sub-tile: independent of the MFMA chain above, issued in its shadow
                 float mp0, mp1;
                 CM2_MIN16(p0, mp0);
@@ -667,12 +675,16 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
                 for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[s], acc0, 0, 0, 0);
+                if (a.nprod >= 2) {
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[s], acc0, 0, 0, 0);
+                    for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[s], acc0, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < NST) CM2_LOAD_AH_W(tile, st + 1);
+                if (a.nprod >= 3) {
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[s], acc0, 0, 0, 0);
+                    for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[s], acc0, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < NST) CM2_LOAD_AL_W(tile, st + 1);
                 // filter the PREVIOUS sub-tile in the shadow of the chain above: value = |y|^2 - 2 q.y
