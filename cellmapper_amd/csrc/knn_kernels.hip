@@ -548,7 +548,7 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d)
                          : (path == 3 ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(p->KSTEPS));
     p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
-    p->lds = 2 * p->tileb + 64;
+    p->lds = (path == 1 ? cmk2::RING : 2) * p->tileb + 64;   // knn_cand_f16 keeps a 3-deep tile ring
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
     const int qb = path == 3 ? cmk2::QBW : cmk2::QB;  // queries per workgroup pass of the chosen kernel
     p->nq_pad = (nq + qb - 1) / qb * qb;
@@ -653,8 +653,8 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         g_dbg_ctr = nullptr;
         if (a.dbg & 4) {
             static unsigned long long *d_ctr = nullptr;
-            if (!d_ctr) (void)hipMalloc((void **)&d_ctr, 64);
-            (void)hipMemsetAsync(d_ctr, 0, 64, st);
+            if (!d_ctr) (void)hipMalloc((void **)&d_ctr, 128);
+            (void)hipMemsetAsync(d_ctr, 0, 128, st);
             a.ctr = d_ctr;
             g_dbg_ctr = d_ctr;
         }
@@ -710,11 +710,11 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     }
     if (!f16) cm_mark(h, 2);
     if (f16 && g_dbg_ctr) {
-        unsigned long long hc[8] = {0};
+        unsigned long long hc[16] = {0};
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(hc, g_dbg_ctr, 64, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu\n",
-                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5]);
+        (void)hipMemcpy(hc, g_dbg_ctr, 128, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu event_cycles=%llu barrier_cycles=%llu dma_wait_cycles=%llu mfma_cluster_cycles=%llu\n",
+                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9]);
     }
     if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
     if (!reranked)

@@ -43,7 +43,8 @@ constexpr int NW = CM2_NW;  // waves per workgroup: one 8-wave workgroup per CU 
                             // measured 6-10 % faster than two 4-wave workgroups once threshold refreshes were scheduled)
 constexpr int NT = NW * 64;
 constexpr int QB = NW * 64;  // queries per workgroup pass
-constexpr int CL = 96;       // lane-private append buffer capacity (entries)
+constexpr int CL = 128;      // lane-private append buffer capacity (entries)
+constexpr int RING = 4;      // LDS tile buffers of knn_cand_f16: tile t+1 has landed while tile t is computed (see the kernel)
 
 __host__ __device__ constexpr int row_bytes(int KSTEPS) { return KSTEPS * 16 * 2 * 2; }  // hi + lo halves
 __host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes(KSTEPS); }
@@ -71,7 +72,7 @@ struct P1Args {
     int nprod;             // split products evaluated: 3 = hi*hi + hi*lo + lo*hi (error ~2^-21 |q||y|), 2 = drop lo(ref)*hi
                            // (~2^-11), 1 = hi*hi only (~2^-10); the certificate in knn_rerank uses the matching bound
     int dbg;               // timing experiments only (CELLMAP_DBG): 1 = never append, 2 = skip the filter, 4 = counters
-    unsigned long long *ctr;  // [8] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
+    unsigned long long *ctr;  // [16] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
 };
 
 __device__ __forceinline__ uint2 ld_fresh(const uint2 *p) {
@@ -226,7 +227,8 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
     {                                                                                                          \
         const bool pass0_ = (M0) < thr[0], pass1_ = (M1) < thr[1];                                             \
         if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
-            if (a.dbg & 4) ++c_br;                                                                             \
+            unsigned long long te0_ = 0;                                                                       \
+            if (a.dbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                    \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
                 const f32x16 &acc = j ? (P1) : (P0);                                                           \
                 if (j ? pass1_ : pass0_) {                                                                     \
@@ -260,34 +262,91 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
                 }                                                                                              \
                 if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                 \
             }                                                                                                  \
+            if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                     \
         }                                                                                                      \
     }
-// Scheduled threshold refresh.  All waves of the workgroup reach this point at the same tile, so nobody waits at
-// the next barrier for a straggler (overflow-triggered merges in CM2_FILTER are the rare exception).  With refreshes
-// after 2, 4, 8, ... tiles a query appends ~K' entries per doubling of scanned rows.
-#define CM2_REFRESH(T, T0)                                                                                     \
-    if ((T) == next_refresh && !(a.dbg & 3)) {                                                                 \
-        next_refresh = (T0) + 2 * ((T) - (T0) + 1) - 1;                                                        \
+// Append-only filter of the MFMA kernels: the logs are merged at ONE place per tile (CM2_REFRESH_T), so this path is a
+// handful of instructions and the (large) merge code exists once in the kernel instead of once per unrolled sub-tile.
+// A lane appends at most 16 entries per sub-tile and log; CM2_REFRESH_T keeps every log at most CL - 16*NST full.
+#define CM2_FILTER_A(P0, P1, M0, M1, RB)                                                                       \
+    {                                                                                                          \
+        const bool pass0_ = (M0) < thr[0], pass1_ = (M1) < thr[1];                                             \
+        if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
+            unsigned long long te0_ = 0;                                                                       \
+            if (a.dbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                    \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+                const f32x16 &acc = j ? (P1) : (P0);                                                           \
+                if (__ballot(j ? pass1_ : pass0_) != 0ull) {                                                   \
+                    /* Typically ONE value in ONE lane passes.  All 16 compares are issued back to back into    \
+                       wave masks (SGPR pairs); the search for the non-empty ones is scalar code, so the common \
+                       case costs no VALU->SALU->branch round trip per register. */                             \
+                    uint2 *mybuf_ = wlbuf + (size_t)((j * 32 + c) * 2 + hh) * CL;                              \
+                    const float tj_ = thr[j];                                                                  \
+                    int cj_ = cnt[j];                                                                          \
+                    unsigned long long bm_[16];                                                                \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) bm_[e] = __ballot(acc[e] < tj_);            \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+                        if ((bm_[4 * g] | bm_[4 * g + 1] | bm_[4 * g + 2] | bm_[4 * g + 3]) != 0ull) {         \
+                            _Pragma("unroll") for (int e = 4 * g; e < 4 * g + 4; ++e) {                        \
+                                if (bm_[e] != 0ull) {                                                          \
+                                    if (acc[e] < tj_) {                                                        \
+                                        mybuf_[cj_] = make_uint2(__float_as_uint(acc[e]),                      \
+                                                                 (unsigned)((RB) + (e & 3) + 8 * (e >> 2)));   \
+                                        ++cj_;                                                                 \
+                                    }                                                                          \
+                                }                                                                              \
+                            }                                                                                  \
+                        }                                                                                      \
+                    }                                                                                          \
+                    cnt[j] = cj_;                                                                              \
+                }                                                                                              \
+            }                                                                                                  \
+            if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                     \
+        }                                                                                                      \
+    }
+// Merge the logs of every query whose lanes hold more than LIM_ entries (runtime loop over the accumulators: one copy
+// of the merge code).
+#define CM2_MERGE_PASS(LIM_)                                                                                   \
+    {                                                                                                          \
         unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                           \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
-            unsigned long long need = __ballot(cnt[j] > 0);                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* own appends visible to own L2 reads */             \
+        _Pragma("unroll 1") for (int j = 0; j < NJ_; ++j) {                                                    \
+            int cj_ = j ? cnt[1] : cnt[0], kj_ = j ? keptn[1] : keptn[0];                                      \
+            float tj_ = j ? thr[1] : thr[0];                                                                   \
+            unsigned long long need = __ballot(cj_ > (LIM_));                                                  \
             need = (need | (need >> 32)) & 0xffffffffull;                                                      \
             while (need) {                                                                                     \
                 const int ql_ = __ffsll((long long)need) - 1;                                                  \
                 need &= need - 1;                                                                              \
                 const int wq = j * 32 + ql_;                                                                   \
-                const int n0 = __shfl(cnt[j], ql_), n1 = __shfl(cnt[j], ql_ + 32), nk = __shfl(keptn[j], ql_); \
-                float tq = __shfl(thr[j], ql_);                                                                \
+                const int n0 = __shfl(cj_, ql_), n1 = __shfl(cj_, ql_ + 32), nk = __shfl(kj_, ql_);            \
+                float tq = __shfl(tj_, ql_);                                                                   \
                 uint2 *kq = wkept + (size_t)wq * a.Kc;                                                         \
                 int nn = wave_merge_prune(nullptr, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,                  \
                                           wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
-                if (c == ql_) { cnt[j] = 0; keptn[j] = nn; thr[j] = tq; }                                      \
+                if (c == ql_) { cj_ = 0; kj_ = nn; tj_ = tq; }                                                 \
                 if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                                   \
             }                                                                                                  \
+            if (j) { cnt[1] = cj_; keptn[1] = kj_; thr[1] = tj_; }                                             \
+            else { cnt[0] = cj_; keptn[0] = kj_; thr[0] = tj_; }                                               \
         }                                                                                                      \
         if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                         \
     }
+// End of tile T.  Scheduled threshold refresh: all waves of the workgroup merge at the same tile, so nobody waits at
+// the next barrier for a straggler; with refreshes after 2, 4, 8, ... tiles a query appends ~K' entries per doubling
+// of scanned rows.  In between, a log that could overflow during the next tile (more than FULL_ entries) is merged
+// on the spot (rare).
+#define CM2_REFRESH_T(T, T0, FULL_)                                                                            \
+    if (!(a.dbg & 3)) {                                                                                        \
+        const bool sched_ = (T) == next_refresh;                                                               \
+        if (sched_ || __ballot(cnt[0] > (FULL_) || cnt[1] > (FULL_)) != 0ull) {                                \
+            if (sched_) next_refresh = (T0) + 2 * ((T) - (T0) + 1) - 1;                                        \
+            const int lim_ = sched_ ? 0 : (FULL_);                                                             \
+            CM2_MERGE_PASS(lim_)                                                                               \
+        }                                                                                                      \
+    }
+// low-d kernel: emergency merges happen inside CM2_FILTER (a 512-row tile can append 256 entries per lane)
+#define CM2_REFRESH(T, T0) CM2_REFRESH_T(T, T0, CL)
 // Final merge of a work item: emit K' candidate rows (-1 padded) and the threshold of every query of the wave.
 #define CM2_FINAL()                                                                                            \
     {                                                                                                          \
@@ -309,9 +368,53 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
 
 #define CM2_AS1 __attribute__((address_space(1)))
 #define CM2_AS3 __attribute__((address_space(3)))
+// 16-byte LDS read the compiler does not see as an LDS access (see knn_cand_f16), and the matching explicit wait: the
+// fragments are passed through the wait as in/out operands so that no use can be scheduled above it.
+#define CM2_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory")
+// Same, reading from ((a ^ x) + tb) + off (x uniform in an SGPR, tb in a VGPR: one constant-bus operand).  The swizzled granule addresses of one row differ by an XOR, so a lane keeps
+// ONE row address and forms each fragment address inside the asm (v_xad_u32), where the compiler cannot hoist it into a
+// long-lived register per fragment.
+#define CM2_DSR128X(dst, a, x, tb, off)                                                                        \
+    {                                                                                                          \
+        unsigned tmp_;                                                                                         \
+        asm volatile("v_xad_u32 %1, %2, %3, %4\n\tds_read_b128 %0, %1 offset:%5"                              \
+                     : "=&v"(dst), "=&v"(tmp_)                                                                 \
+                     : "v"(a), "s"(x), "v"(tb), "i"(off)                                                       \
+                     : "memory");                                                                              \
+    }
+// Wait until at most CNT LDS reads issued AFTER the fragments f are still outstanding (LDS returns in order; other
+// lgkm traffic outstanding at the same time only makes the wait more conservative).
+template <int CNT, int N>
+__device__ __forceinline__ void wait_lds(half8 (&f)[N]) {
+    static_assert(N == 2 || N == 4 || N == 8, "fragment count");
+    static_assert(CNT >= 0 && CNT <= 15, "lgkmcnt is a 4-bit counter");
+    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "i"(CNT));
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "i"(CNT));
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+                     : "i"(CNT));
+}
 
-template <int KSTEPS>
+// Step I (0..15) of the two 16-value min trees of CM2_MIN16 (P0 -> m[14], P1 -> m[15]), so that the tree can be dealt
+// out over the gaps of an MFMA chain.  I is a compile-time constant after unrolling.
+__device__ __forceinline__ void min_step(int I, const f32x16 &P0, const f32x16 &P1, float (&m)[16]) {
+    if (I < 5) m[I] = vmin3(P0[3 * I], P0[3 * I + 1], P0[3 * I + 2]);
+    else if (I < 10) m[I] = vmin3(P1[3 * (I - 5)], P1[3 * (I - 5) + 1], P1[3 * (I - 5) + 2]);
+    else if (I == 10) m[10] = vmin3(m[0], m[1], m[2]);
+    else if (I == 11) m[11] = vmin3(m[3], m[4], P0[15]);
+    else if (I == 12) m[12] = vmin3(m[5], m[6], m[7]);
+    else if (I == 13) m[13] = vmin3(m[8], m[9], P1[15]);
+    else if (I == 14) m[14] = vmin3(m[10], m[11], m[0]);
+    else m[15] = vmin3(m[12], m[13], m[5]);
+}
+
+// NP = number of split products evaluated: 3 = hi*hi + hi*lo(query) + lo(ref)*hi (needs the lo halves of the reference
+// rows), 2 = hi*hi + hi*lo(query), 1 = hi*hi.  For NP < 3 the lo fragments' registers double-buffer the hi fragments.
+template <int KSTEPS, int NP>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
+    constexpr bool LO3 = NP == 3;
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = row_bytes(KSTEPS);
     constexpr int GRAN = ROWB / 16;        // granules per row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
@@ -321,30 +424,36 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
 
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *ring = smem;                                            // [2][TILEB]
+    unsigned char *ring = smem;                                            // [RING][TILEB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     uint2 *wsc = nullptr;
     uint2 *wkept = a.kept + (size_t(blockIdx.x) * NW + wave) * 64 * a.Kc;
     uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NW + wave) * 64 * 2 * CL;
+    const unsigned ldsbase = (unsigned)(uintptr_t)(CM2_AS3 unsigned char *)ring;
 
     // Asynchronous tile staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4), no VGPRs, no ds_write pass.
     // The tile image in global memory is byte-for-byte the LDS image (rows pre-swizzled by prep_rows_f16), so every
     // wave-instruction copies one contiguous KiB.  Wave w moves pieces w, w+NW, ...
 #define CM2_DMA_TILE(t_, buf_)                                                                                  \
     {                                                                                                           \
-        const char *gsrc_ = a.R + (size_t)(t_) * TILEB + lane * 16;                                             \
-        unsigned char *ldst_ = ring + (buf_) * TILEB;                                                           \
-        _Pragma("unroll") for (int q_ = 0; q_ < (NCHUNK + NW - 1) / NW; ++q_) {                                 \
-            const int piece_ = wave + q_ * NW;                                                                  \
-            if (piece_ < NCHUNK)                                                                                \
-                __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + piece_ * 1024),                 \
-                                                 (CM2_AS3 void *)(ldst_ + piece_ * 1024), 16, 0, 0);            \
-        }                                                                                                       \
+        const char *gsrc_ = a.R + (size_t)(t_) * TILEB;               /* uniform: scalar base + one 32-bit VGPR */ \
+        unsigned char *ldst_ = ring + (buf_) * TILEB + wave * 1024;                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < NCHUNK / NW; ++q_)                                              \
+            __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + q_ * (NW * 1024) + dma_voff),       \
+                                             (CM2_AS3 void *)(ldst_ + q_ * (NW * 1024)), 16, 0, 0);             \
     }
+#define CM2_DMA_PIECE(t_, buf_, q_)                                                                             \
+    __builtin_amdgcn_global_load_lds(                                                                           \
+        (const CM2_AS1 void *)(a.R + (size_t)(t_) * TILEB + (q_) * (NW * 1024) + dma_voff),                     \
+        (CM2_AS3 void *)(ring + (buf_) * TILEB + wave * 1024 + (q_) * (NW * 1024)), 16, 0, 0)
+    static_assert(NCHUNK % NW == 0, "every wave copies the same number of 1-KiB pieces");
+    constexpr int NPIECE = NCHUNK / NW;    // DMA pieces per wave and tile
+    static_assert(NPIECE <= BR / 32, "one DMA piece per sub-tile");
+    const unsigned dma_voff = wave * 1024 + lane * 16;
 
-    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
     const int n_work = a.nqb * a.S;
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
@@ -364,13 +473,27 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 ql[j][s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
             }
         }
+        // Touch the query fragments here: the compiler places its vmcnt wait for the loads above at this first use
+        // instead of in front of the first MFMA of the tile loop, where it would also wait for the tile prefetch.
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            asm volatile("" ::"v"(qh[0][s]), "v"(qh[1][s]), "v"(ql[0][s]), "v"(ql[1][s]));
         const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
         float thr[2] = {thr_init, thr_init};
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
         int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
 
+        // Ring protocol (RING = 4 buffers, tile t lives in buffer t % 4).  At the top of tile t every wave waits for
+        // its own DMA pieces of tile t+1, then the workgroup barrier makes tile t+1 complete for everyone and tells
+        // that everyone is done with tile t-1.  Tile t itself was complete one barrier earlier, so the fragments of
+        // its first sub-tile are requested BEFORE the barrier (end of tile t-1): the MFMA chain runs through the
+        // barrier without an LDS-latency bubble.  NP = 3 issues the DMA of tile t+2 at the top of tile t; NP < 3
+        // spreads the pieces of tile t+3 over the sub-tiles of tile t (buffer of tile t-1), so that the wait at the
+        // top of tile t+1 (for tile t+2, issued a whole tile earlier) may leave them in flight.
         __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
-        if (t0 < t1) CM2_DMA_TILE(t0, t0 & 1);
+        if (t0 < t1) CM2_DMA_TILE(t0, t0 % RING);
+        if (t0 + 1 < t1) CM2_DMA_TILE(t0 + 1, (t0 + 1) % RING);
+        if (!LO3 && t0 + 2 < t1) CM2_DMA_TILE(t0 + 2, (t0 + 2) % RING);
 
         // Software pipeline: the filter of sub-tile i-1 (VALU) is issued in the shadow of sub-tile i's MFMA chain.
         f32x16 p0, p1;          // accumulators of the previous sub-tile, waiting to be filtered (+inf = nothing pending)
@@ -378,91 +501,150 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         for (int e = 0; e < 16; ++e) { p0[e] = INFINITY; p1[e] = INFINITY; }
         int prbase = 0;         // first reference row (+4*hh) of the previous sub-tile
 
-        // A-operand fragments and row norms of one 32-row sub-tile (conflict-free swizzled ds_read_b128)
-#define CM2_LOAD_AH(TILE, ST)                                                                                  \
+        // A-operand fragments of one 32-row sub-tile: conflict-free swizzled ds_read_b128, written as inline asm.
+        // The compiler cannot tell the in-flight LDS-DMA of the NEXT tile from reads of the CURRENT one and puts
+        // s_waitcnt vmcnt(0) in front of the first MFMA if it sees the reads, which serialises the prefetch; the asm
+        // reads are invisible to that analysis and are waited for explicitly (CM2_WAIT_LDS) before their first use.
+#define CM2_LOAD_AH(F, TB, ST)                                                                                 \
     {                                                                                                          \
-        const int r_ = (ST) * 32 + c;                                                                          \
-        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
-        const int f_ = swz(r_, KSTEPS);                                                                        \
         _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
-            ah[s] = *reinterpret_cast<const half8 *>(rowp_ + (((2 * s + hh)) ^ f_) * 16);                      \
+            CM2_DSR128X(F[s], arow, 32 * s, TB, (ST) * 32 * ROWB);                                             \
     }
-#define CM2_LOAD_AL_YN(TILE, ST)                                                                               \
+#define CM2_LOAD_AL(F, TB, ST)                                                                                 \
     {                                                                                                          \
-        const int r_ = (ST) * 32 + c;                                                                          \
-        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
-        const int f_ = swz(r_, KSTEPS);                                                                        \
         _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
-            al[s] = *reinterpret_cast<const half8 *>(rowp_ + ((GRAN / 2 + 2 * s + hh) ^ f_) * 16);             \
+            CM2_DSR128X(F[s], arow, (GRAN / 2) * 16 + 32 * s, TB, (ST) * 32 * ROWB);                           \
     }
+        // granule (2s+hh) of the hi half sits at (2s+hh)^f = (hh^f) ^ 2s, the lo half at ... ^ GRAN/2 (f < GRAN, the
+        // swizzle repeats every 32 rows): one row address per lane, fragment = address ^ constant
+        const unsigned arow = c * ROWB + ((hh ^ swz(c, KSTEPS)) * 16);
 
         int next_refresh = t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
-        for (int t = t0; t < t1; ++t) {
-            // this wave's DMA pieces of tile t (issued one tile ago) have landed; after the barrier everyone's have,
-            // and every wave is done reading tile t-1, whose buffer the next DMA overwrites.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 1 < t1) CM2_DMA_TILE(t + 1, (t + 1) & 1);
-            const unsigned char *tile = ring + (t & 1) * TILEB;
-            half8 ah[KSTEPS], al[KSTEPS];
+        half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) al[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            CM2_LOAD_AH(tile, 0);
-            if (a.nprod >= 3) CM2_LOAD_AL_YN(tile, 0);
+        for (int s = 0; s < KSTEPS; ++s) { ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0}; al[s] = ah[s]; }
+        if (t0 < t1) {   // first tile: nothing to overlap with
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both prologue tiles (simplest; once per work item)
+            __builtin_amdgcn_s_barrier();
+            const unsigned tile0 = ldsbase + (t0 % RING) * TILEB;
+            CM2_LOAD_AH(ah, tile0, 0);
+            if (LO3) CM2_LOAD_AL(al, tile0, 0);
+        }
+        for (int t = t0; t < t1; ++t) {
+            unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (t > t0) {   // (the first tile synchronised above)
+                // own pieces of tile t+1 have landed; NP < 3: those of tile t+2 (issued during tile t-1) may be in
+                // flight -- loads complete in order, stores in between only make the wait more conservative
+                if (!LO3 && t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
+                __builtin_amdgcn_s_barrier();
+                if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
+            }
+            if (LO3 && t + 2 < t1) CM2_DMA_TILE(t + 2, (t + 2) % RING);   // NP < 3: one piece per sub-tile, below
+            const unsigned tile = ldsbase + (t % RING) * TILEB;
+            const unsigned tile_n = ldsbase + ((t + 1) % RING) * TILEB;
+            const bool more = t + 1 < t1;   // uniform: prefetch the next tile's first fragments at the last sub-tile
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 // accumulator registers map to rows (r&3) + 8*(r>>2) + 4*hh of the sub-tile, one query per lane column
                 f32x16 acc0, acc1;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+                // fragments of the next sub-tile: st+1 of this tile, or sub-tile 0 of the next one
+                const unsigned ntile = (st + 1 < NST) ? tile : tile_n;
+                const int nst = (st + 1 < NST) ? st + 1 : 0;
+                const bool pre = (st + 1 < NST) || more;
+                float mm[16];
+                (void)pre;
+                if constexpr (LO3) {
+                    wait_lds<KSTEPS>(ah);   // the lo fragments of this sub-tile may still be in flight
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[0][s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[1][s], acc1, 0, 0, 0);
-                }
-                if (a.nprod >= 2) {
+                    for (int s = 0; s < KSTEPS; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[0][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[1][s], acc1, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int s = 0; s < KSTEPS; ++s) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[0][s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[1][s], acc1, 0, 0, 0);
                     }
-                }
-                // the hi fragment is dead: fetch the next sub-tile's while the lo products run
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < NST) CM2_LOAD_AH(tile, st + 1);
-                if (a.nprod >= 3) {
+                    // the hi fragment is dead: fetch the next sub-tile's while the lo products run
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pre) {
+                        CM2_LOAD_AH(ah, ntile, nst);
+                        wait_lds<KSTEPS>(al);
+                    } else {
+                        wait_lds<0>(al);
+                    }
 #pragma unroll
                     for (int s = 0; s < KSTEPS; ++s) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (st + 1 < NST) CM2_LOAD_AL_YN(tile, st + 1);
+                    if (pre) CM2_LOAD_AL(al, ntile, nst);
+                } else {
+                    // Hand-placed stream: after every MFMA of the hi*hi chain one gap's worth of the other work of this
+                    // sub-tile -- a fragment read for the next sub-tile, two or four steps of the PREVIOUS sub-tile's
+                    // min trees, one DMA piece of tile t+2 -- so that a wave paces the matrix pipe on its own and the
+                    // two waves of a SIMD mesh MFMA by MFMA, whatever their relative phase.
+                    half8(&cur)[KSTEPS] = (st & 1) ? al : ah;
+                    half8(&nxt)[KSTEPS] = (st & 1) ? ah : al;
+                    constexpr int NM = 2 * KSTEPS, PER = 16 / NM;
+                    wait_lds<0>(cur);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const int s = i >> 1;
+                        if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[1][s], acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // (at the last sub-tile of the last tile this reads a stale buffer; the result is never used)
+                        if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+#pragma unroll
+                        for (int jj = 0; jj < PER; ++jj) min_step(i * PER + jj, p0, p1, mm);
+                        if (i == NM - 1 && st < NPIECE) {
+                            if (t + 3 < t1) CM2_DMA_PIECE(t + 3, (t + 3) % RING, st);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (NP == 2) {
+#pragma unroll
+                        for (int s = 0; s < KSTEPS; ++s) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s], acc1, 0, 0, 0);
+                        }
+                    }
                 }
-                // min-trees of the PREVIOUS sub-tile: independent of the MFMA chain above, issued in its shadow
                 float mp0, mp1;
-                CM2_MIN16(p0, mp0);
-                CM2_MIN16(p1, mp1);
-                if (!(a.dbg & 2)) CM2_FILTER(p0, p1, mp0, mp1, prbase);
+                if constexpr (LO3) {   // min-trees of the PREVIOUS sub-tile, issued in the shadow of the chain above
+                    CM2_MIN16(p0, mp0);
+                    CM2_MIN16(p1, mp1);
+                } else {
+                    mp0 = mm[14];
+                    mp1 = mm[15];
+                }
+                if (!(a.dbg & 2)) CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
                 p0 = acc0;
                 p1 = acc1;
                 prbase = t * BR + st * 32 + 4 * hh;
             }
-            CM2_REFRESH(t, t0);
+            CM2_REFRESH_T(t, t0, CL - 16 * NST);
         }
         if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
             float mp0, mp1;
             CM2_MIN16(p0, mp0);
             CM2_MIN16(p1, mp1);
-            CM2_FILTER(p0, p1, mp0, mp1, prbase);
+            CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
         }
         if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
 #undef CM2_LOAD_AH
-#undef CM2_LOAD_AL_YN
+#undef CM2_LOAD_AL
 
         CM2_FINAL();
     }
 #undef CM2_DMA_TILE
+#undef CM2_DMA_PIECE
     if ((a.dbg & 4) && lane == 0) {
         atomicAdd(&a.ctr[0], c_br);
         atomicAdd(&a.ctr[1], c_app);
@@ -470,6 +652,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         atomicAdd(&a.ctr[3], c_prcyc);
         atomicAdd(&a.ctr[4], __builtin_amdgcn_s_memtime() - c_t0);
         atomicAdd(&a.ctr[5], 1ull);
+        atomicAdd(&a.ctr[6], c_evcyc);
+        atomicAdd(&a.ctr[7], c_barcyc);
+        atomicAdd(&a.ctr[8], c_dmacyc);
+        atomicAdd(&a.ctr[9], c_clus);
     }
 }
 
@@ -498,7 +684,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     uint2 *wkept = a.kept + (size_t(blockIdx.x) * NW + wave) * 64 * a.Kc;
     uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NW + wave) * 64 * 2 * CL;
     const float *Qf = reinterpret_cast<const float *>(a.Q);
-    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     (void)wsc;
 
     const int n_work = a.nqb * a.S;
@@ -561,7 +747,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
 #undef CM2_DMA_TILE_L
         CM2_FINAL();
     }
-    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc;
+    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc; (void)c_evcyc; (void)c_barcyc; (void)c_dmacyc; (void)c_clus;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -577,7 +763,7 @@ constexpr int QBW = NWW * 32;     // queries per workgroup pass
 constexpr int KSTEPS_W = 8;
 __host__ __device__ constexpr int wide_tile_bytes() { return BR * row_bytes(KSTEPS_W) + 1024; }
 
-template <int KSTEPS>
+template <int KSTEPS, bool LO3>
 __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = row_bytes(KSTEPS);
@@ -594,7 +780,7 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
     uint2 *wsc = nullptr;
     uint2 *wkept = a.kept + (size_t(blockIdx.x) * NWW + wave) * 64 * a.Kc;
     uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NWW + wave) * 64 * 2 * CL;
-    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0;
+    unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     (void)wsc;
 
 #define CM2_DMA_TILE_W(t_, buf_)                                                                                \
@@ -608,27 +794,27 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
                                                  (CM2_AS3 void *)(ldst_ + piece_ * 1024), 16, 0, 0);            \
         }                                                                                                       \
     }
-#define CM2_LOAD_AH_W(TILE, ST)                                                                                \
+    // LDS reads as inline asm + explicit waits, see knn_cand_f16
+#define CM2_LOAD_AH_W(F, TB, ST)                                                                               \
     {                                                                                                          \
-        const int r_ = (ST) * 32 + c;                                                                          \
-        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
-        const int f_ = swz(r_, KSTEPS);                                                                        \
         _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
-            ah[s] = *reinterpret_cast<const half8 *>(rowp_ + (((2 * s + hh)) ^ f_) * 16);                      \
+            CM2_DSR128X(F[s], arow, 32 * s, TB, (ST) * 32 * ROWB);                                             \
     }
-#define CM2_LOAD_AL_W(TILE, ST)                                                                                \
+#define CM2_LOAD_AL_W(F, TB, ST)                                                                               \
     {                                                                                                          \
-        const int r_ = (ST) * 32 + c;                                                                          \
-        const unsigned char *rowp_ = (TILE) + r_ * ROWB;                                                       \
-        const int f_ = swz(r_, KSTEPS);                                                                        \
         _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
-            al[s] = *reinterpret_cast<const half8 *>(rowp_ + ((GRAN / 2 + 2 * s + hh) ^ f_) * 16);             \
-        const float *yp_ = reinterpret_cast<const float *>((TILE) + BR * ROWB) + (ST) * 32 + 4 * hh;           \
-        y0 = *reinterpret_cast<const f32x4 *>(yp_);                                                            \
-        y1 = *reinterpret_cast<const f32x4 *>(yp_ + 8);                                                        \
-        y2 = *reinterpret_cast<const f32x4 *>(yp_ + 16);                                                       \
-        y3 = *reinterpret_cast<const f32x4 *>(yp_ + 24);                                                       \
+            CM2_DSR128X(F[s], arow, (GRAN / 2) * 16 + 32 * s, TB, (ST) * 32 * ROWB);                           \
     }
+#define CM2_LOAD_YN_W(TB, ST)                                                                                  \
+    {                                                                                                          \
+        CM2_DSR128X(y0, yrow, 0, TB, (ST) * 128);                                                              \
+        CM2_DSR128X(y1, yrow, 0, TB, (ST) * 128 + 32);                                                         \
+        CM2_DSR128X(y2, yrow, 0, TB, (ST) * 128 + 64);                                                         \
+        CM2_DSR128X(y3, yrow, 0, TB, (ST) * 128 + 96);                                                         \
+    }
+    const unsigned ldsbase = (unsigned)(uintptr_t)(CM2_AS3 unsigned char *)ring;
+    const unsigned arow = c * ROWB + ((hh ^ swz(c, KSTEPS)) * 16);   // see knn_cand_f16
+    const unsigned yrow = BR * ROWB + 16 * hh;   // |y|^2 side block: rows 4*hh + {0..3} + 8*i of a sub-tile
 
     const int n_work = a.nqb * a.S;
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
@@ -645,6 +831,8 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
                 ql[s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
             }
         }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[s]), "v"(ql[s]));  // see knn_cand_f16
         // slot 1 of the per-lane state is inert (threshold -inf): the shared macros iterate over two accumulators
         float thr[2] = {INFINITY, -INFINITY};
         int cnt[2] = {0, 0};
@@ -661,32 +849,58 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (t + 1 < t1) CM2_DMA_TILE_W(t + 1, (t + 1) & 1);
-            const unsigned char *tile = ring + (t & 1) * TILEB;
-            half8 ah[KSTEPS], al[KSTEPS];
+            const unsigned tile = ldsbase + (t & 1) * TILEB;
+            half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
             f32x4 y0, y1, y2, y3;
-            CM2_LOAD_AH_W(tile, 0);
-            CM2_LOAD_AL_W(tile, 0);
+            CM2_LOAD_AH_W(ah, tile, 0);
+            if (LO3) CM2_LOAD_AL_W(al, tile, 0);
+            CM2_LOAD_YN_W(tile, 0);
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 f32x16 acc0, cy;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { cy[e] = y0[e]; cy[4 + e] = y1[e]; cy[8 + e] = y2[e]; cy[12 + e] = y3[e]; }
-#pragma unroll
                 for (int e = 0; e < 16; ++e) acc0[e] = 0.f;
+                if constexpr (LO3) {
+                    wait_lds<KSTEPS + 4>(ah);   // behind them: this sub-tile's lo fragments and |y|^2
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[s], acc0, 0, 0, 0);
-                if (a.nprod >= 2) {
+                    for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[s], acc0, 0, 0, 0);
 #pragma unroll
                     for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[s], acc0, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < NST) CM2_LOAD_AH_W(tile, st + 1);
-                if (a.nprod >= 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 1 < NST) {
+                        CM2_LOAD_AH_W(ah, tile, st + 1);
+                        wait_lds<KSTEPS>(al);
+                    } else {
+                        wait_lds<0>(al);
+                    }
+                    asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cy[e] = y0[e]; cy[4 + e] = y1[e]; cy[8 + e] = y2[e]; cy[12 + e] = y3[e]; }
 #pragma unroll
                     for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[s], acc0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st + 1 < NST) {
+                        CM2_LOAD_AL_W(al, tile, st + 1);
+                        CM2_LOAD_YN_W(tile, st + 1);
+                    }
+                } else {
+                    half8(&cur)[KSTEPS] = (st & 1) ? al : ah;
+                    half8(&nxt)[KSTEPS] = (st & 1) ? ah : al;
+                    wait_lds<0>(cur);
+                    asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { cy[e] = y0[e]; cy[4 + e] = y1[e]; cy[8 + e] = y2[e]; cy[12 + e] = y3[e]; }
+                    if (st + 1 < NST) {   // requested before this sub-tile's chain is issued
+                        CM2_LOAD_AH_W(nxt, tile, st + 1);
+                        CM2_LOAD_YN_W(tile, st + 1);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[s], acc0, 0, 0, 0);
+                    if (a.nprod >= 2) {
+#pragma unroll
+                        for (int s = 0; s < KSTEPS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[s], acc0, 0, 0, 0);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < NST) CM2_LOAD_AL_W(tile, st + 1);
                 // filter the PREVIOUS sub-tile in the shadow of the chain above: value = |y|^2 - 2 q.y
                 f32x16 pv;
 #pragma unroll
@@ -694,12 +908,12 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
                 float mp0;
                 CM2_MIN16(pv, mp0);
                 const float mp1 = INFINITY;
-                CM2_FILTER(pv, pv, mp0, mp1, prbase);
+                CM2_FILTER_A(pv, pv, mp0, mp1, prbase);
                 p0 = acc0;
                 py = cy;
                 prbase = t * BR + st * 32 + 4 * hh;
             }
-            CM2_REFRESH(t, t0);
+            CM2_REFRESH_T(t, t0, CL - 16 * NST);
         }
         {
             f32x16 pv;
@@ -708,14 +922,15 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
             float mp0;
             CM2_MIN16(pv, mp0);
             const float mp1 = INFINITY;
-            CM2_FILTER(pv, pv, mp0, mp1, prbase);
+            CM2_FILTER_A(pv, pv, mp0, mp1, prbase);
         }
         CM2_FINAL();
     }
 #undef CM2_DMA_TILE_W
 #undef CM2_LOAD_AH_W
 #undef CM2_LOAD_AL_W
-    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc;
+#undef CM2_LOAD_YN_W
+    (void)c_br; (void)c_app; (void)c_pr; (void)c_prcyc; (void)c_evcyc; (void)c_barcyc; (void)c_dmacyc; (void)c_clus;
 }
 
 }  // namespace cmk2

@@ -2,9 +2,9 @@
 #include "cm_internal.h"
 #include "knn_phase1_f16.h"
 
-template <int KSTEPS>
+template <int KSTEPS, int NP>
 static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    auto kern = cmk2::knn_cand_f16<KSTEPS>;
+    auto kern = cmk2::knn_cand_f16<KSTEPS, NP>;
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
     CM_HIP(h, hipGetLastError());
@@ -13,8 +13,12 @@ static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1A
 
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
     switch (KSTEPS) {
-    case 2: return launch_f16<2>(h, grid, lds, a);
-    case 4: return launch_f16<4>(h, grid, lds, a);
+#define CM_F16_CASE(ks_)                                                                \
+    case ks_:                                                                           \
+        return a.nprod >= 3 ? launch_f16<ks_, 3>(h, grid, lds, a)                       \
+                            : (a.nprod == 2 ? launch_f16<ks_, 2>(h, grid, lds, a) : launch_f16<ks_, 1>(h, grid, lds, a));
+        CM_F16_CASE(2) CM_F16_CASE(4)
+#undef CM_F16_CASE
     }
     CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d", KSTEPS);
 }
@@ -38,10 +42,15 @@ cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk
     CM_FAIL(h, CM_E_INTERNAL, "phase1/lowd: no instantiation for D=%d", D);
 }
 
-cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    auto kern = cmk2::knn_cand_f16w<cmk2::KSTEPS_W>;
+template <bool LO3>
+static cm_status launch_f16w(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    auto kern = cmk2::knn_cand_f16w<cmk2::KSTEPS_W, LO3>;
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NTW), lds, h->stream, a);
     CM_HIP(h, hipGetLastError());
     return CM_OK;
+}
+
+cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    return a.nprod >= 3 ? launch_f16w<true>(h, grid, lds, a) : launch_f16w<false>(h, grid, lds, a);
 }
