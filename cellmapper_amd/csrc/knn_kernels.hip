@@ -29,6 +29,10 @@ constexpr int RR_DMAX = 260;
 constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
 constexpr int FB_CAP = 2048;    // fallback collection capacity per query
 constexpr int FB_BLOCKS = 1024;
+constexpr int FBS_SLICES = 512;  // sliced fallback: reference slices scanned in parallel per flagged query ...
+constexpr int FBS_NQ = 1024;     // ... for the first FBS_NQ flagged queries (the rest: one workgroup per query)
+constexpr int FBS_FY = 8;
+constexpr int FBS_QG = 4;       // flagged queries served by one staged chunk of reference rows
 
 int pick_kp(int d) {
     for (int kp : kSupportedKP)
@@ -401,13 +405,14 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
                                                            int64_t idx_offset, int flags, const int *__restrict__ flag_list,
                                                            const int *__restrict__ flag_cnt,
                                                            const double *__restrict__ bound, void *__restrict__ out_dist,
-                                                           int64_t *__restrict__ out_idx, int *__restrict__ overflow) {
+                                                           int64_t *__restrict__ out_idx, int *__restrict__ overflow,
+                                                           int f_start) {
     __shared__ double s_q[RR_DMAX];
     __shared__ double s_v[FB_CAP];
     __shared__ int s_i[FB_CAP];
     __shared__ int s_n;
     const int nf = *flag_cnt;
-    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+    for (int f = f_start + blockIdx.x; f < nf; f += gridDim.x) {
         const int64_t i = flag_list[f];
         __syncthreads();
         for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
@@ -426,6 +431,101 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
         __syncthreads();
         int m = s_n;
         if (m > FB_CAP) { m = FB_CAP; if (threadIdx.x == 0) atomicExch(overflow, 1); }
+        for (int s = threadIdx.x; s < m; s += blockDim.x) {
+            double v = s_v[s];
+            int id = s_i[s];
+            int rk = 0;
+            for (int j = 0; j < m; ++j) rk += pair_before(s_v[j], s_i[j], v, id) ? 1 : 0;
+            if (rk < k) {
+                double o = v;
+                if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
+                if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+                else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
+                out_idx[i * k + rk] = (int64_t)id + idx_offset;
+            }
+        }
+    }
+}
+
+// Sliced variant for the first FBS_NQ flagged queries.  One workgroup per query (above) needs ~50 ms for a 1.5M-row
+// reference, whatever the number of flagged queries; here workgroup (x, y) scans reference slice x for the flagged
+// queries y, y + gridDim.y, ... and appends the rows within the bound to the query's global candidate list;
+// knn_fallback_rank then ranks each list exactly as knn_exact_fallback does.  Same arithmetic (pair_value), same
+// (value, index) order, same overflow rule.
+template <typename T>
+__global__ __launch_bounds__(256) void knn_fallback_scan(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry,
+                                                         int d, int metric, int form, const int *__restrict__ flag_list,
+                                                         const int *__restrict__ flag_cnt, const double *__restrict__ bound,
+                                                         int *__restrict__ gcount, double *__restrict__ gv,
+                                                         int *__restrict__ gi, int rc) {
+    // Rows are staged through LDS in chunks of rc rows (coalesced copy; one thread per row afterwards, which keeps
+    // pair_value's sequential summation order) and every staged chunk serves FBS_QG flagged queries.
+    extern __shared__ __align__(16) unsigned char fbs_smem[];
+    T *s_rows = reinterpret_cast<T *>(fbs_smem);  // [rc][d]
+    __shared__ double s_q[FBS_QG][RR_DMAX];
+    int nf = *flag_cnt;
+    if (nf > FBS_NQ) nf = FBS_NQ;
+    const int64_t per = (n_ref + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n_ref ? lo + per : n_ref;
+    for (int f0 = blockIdx.y * FBS_QG; f0 < nf; f0 += gridDim.y * FBS_QG) {
+        const int ng = nf - f0 < FBS_QG ? nf - f0 : FBS_QG;
+        __syncthreads();
+        for (int t = threadIdx.x; t < ng * d; t += blockDim.x) {
+            const int g = t / d, c = t - g * d;
+            s_q[g][c] = (double)qry[(int64_t)flag_list[f0 + g] * d + c];
+        }
+        __syncthreads();
+        double xn[FBS_QG], b[FBS_QG];
+#pragma unroll
+        for (int g = 0; g < FBS_QG; ++g) {
+            xn[g] = 0.0;
+            b[g] = -1.0;
+            if (g < ng) {
+                for (int c = 0; c < d; ++c) xn[g] = fma(s_q[g][c], s_q[g][c], xn[g]);
+                b[g] = bound[flag_list[f0 + g]];
+            }
+        }
+        for (int64_t base = lo; base < hi; base += rc) {
+            const int nr = hi - base < rc ? (int)(hi - base) : rc;
+            __syncthreads();
+            for (int t = threadIdx.x; t < nr * d; t += blockDim.x) s_rows[t] = ref[base * d + t];
+            __syncthreads();
+            for (int r = threadIdx.x; r < nr; r += blockDim.x) {
+#pragma unroll
+                for (int g = 0; g < FBS_QG; ++g) {
+                    if (g < ng) {
+                        const double v = pair_value<T>(s_q[g], xn[g], s_rows + (size_t)r * d, d, metric, form);
+                        if (v <= b[g]) {
+                            const int pos = atomicAdd(&gcount[f0 + g], 1);
+                            if (pos < FB_CAP) {
+                                gv[(size_t)(f0 + g) * FB_CAP + pos] = v;
+                                gi[(size_t)(f0 + g) * FB_CAP + pos] = (int)(base + r);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int64_t idx_offset, int flags,
+                                                         const int *__restrict__ flag_list, const int *__restrict__ flag_cnt,
+                                                         const int *__restrict__ gcount, const double *__restrict__ gv,
+                                                         const int *__restrict__ gi, void *__restrict__ out_dist,
+                                                         int64_t *__restrict__ out_idx, int *__restrict__ overflow) {
+    __shared__ double s_v[FB_CAP];
+    __shared__ int s_i[FB_CAP];
+    int nf = *flag_cnt;
+    if (nf > FBS_NQ) nf = FBS_NQ;
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int64_t i = flag_list[f];
+        int m = gcount[f];
+        if (m > FB_CAP) { m = FB_CAP; if (threadIdx.x == 0) atomicExch(overflow, 1); }
+        __syncthreads();
+        for (int s = threadIdx.x; s < m; s += blockDim.x) { s_v[s] = gv[(size_t)f * FB_CAP + s]; s_i[s] = gi[(size_t)f * FB_CAP + s]; }
+        __syncthreads();
         for (int s = threadIdx.x; s < m; s += blockDim.x) {
             double v = s_v[s];
             int id = s_i[s];
@@ -524,6 +624,7 @@ struct KnnPlan2 {
 int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
 // candidate slack of the split-fp16 kernels by number of products evaluated (coarser filter -> wider safety margin)
 int knn_slack_level(int k, int nprod) {
+    if (const char *e = getenv("CELLMAP_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 256) return v; }  // tuning only
     if (nprod >= 3) return knn_slack(k);
     if (nprod == 2) return k / 3 > 12 ? k / 3 : 12;
     return k / 2 > 16 ? k / 2 : 16;
@@ -603,7 +704,11 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     int *flag_list = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
     double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
     unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
-    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);                       // sliced exact fallback: candidate lists
+    double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
+    int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
+    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words || !fb_count || !fb_v || !fb_i)
+        CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     float *scale3 = reinterpret_cast<float *>(words + 8);
     double *d_mean = nullptr;
     cm_mark(h, 0);
@@ -723,9 +828,22 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                            (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
                            flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
     if (!reranked) cm_mark(h, 3);
+    hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
+    {
+        int rc = (int)(52 * 1024 / ((size_t)d * sizeof(T)));   // rows per staged chunk
+        rc = rc >= 256 ? 256 : (rc >= 32 ? rc / 32 * 32 : (rc < 1 ? 1 : rc));
+        const size_t fb_lds = (size_t)rc * d * sizeof(T);
+        auto scan = knn_fallback_scan<T>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds));
+        hipLaunchKernelGGL(scan, dim3(FBS_SLICES, FBS_FY), dim3(256), fb_lds, st, d_ref, n_ref, d_qry, d, metric, form, flag_list,
+                           (const int *)(words + 2), bound, fb_count, fb_v, fb_i, rc);
+    }
+    hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_list,
+                       (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
+                       d_out_idx, (int *)(words + 3));
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
-                       (int *)(words + 3));
+                       (int *)(words + 3), FBS_NQ);
     CM_HIP(h, hipGetLastError());
     cm_mark(h, 4);
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
@@ -743,7 +861,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
     size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
-               cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096;
+               cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;

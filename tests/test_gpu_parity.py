@@ -197,6 +197,26 @@ def test_knn_forced_fallback_and_duplicates(hip, oracle):
     assert hip.knn_stats()["fallback_queries"] >= 1
 
 
+def test_exact_fallback_sliced_and_per_query_paths(oracle):
+    """CM_KNN_FORCE_FALLBACK sends every query through the fp64 exact scan: the first 1024 flagged queries take the
+    sliced scan + rank kernels, the rest one workgroup per query -- both must reproduce the oracle bit for bit."""
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+
+    rng = np.random.default_rng(17)
+    ref = rng.standard_normal((5000, 24)).astype(np.float32)
+    ref[40:60] = ref[40]
+    qry = rng.standard_normal((1300, 24)).astype(np.float32)
+    qry[7] = ref[40]
+    pipe = DevicePipeline(0)
+    with torch.cuda.stream(pipe.stream):
+        dist, idx = pipe.knn(torch.from_numpy(ref).cuda(), torch.from_numpy(qry).cuda(), 12, force_fallback=True)
+        torch.cuda.synchronize()
+    assert pipe.h.knn_stats()["fallback_queries"] == 1300
+    od, oi = oracle.knn_euclidean(ref, qry, 12)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
+
+
 def test_cosine_matches_oracle(hip, oracle):
     rng = np.random.default_rng(11)
     ref = rng.standard_normal((6000, 50)).astype(np.float32)
