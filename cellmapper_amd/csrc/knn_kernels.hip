@@ -166,9 +166,12 @@ __global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__res
 template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
                               const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
-                              float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block) {
+                              float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only) {
     // yn_block != 0 (K = 128 kernel): no norm slots; the tile image ends with a block of 128 floats sc^2|y|^2
-    const int ROWB = cmk2::row_bytes(KSTEPS), GRAN = ROWB / 16, TILEB = cmk2::tile_bytes(KSTEPS) + (yn_block ? 1024 : 0);
+    // hi_only != 0 (reference image of filter levels 1/2): rows hold the hi halves only
+    const int GRAN = cmk2::row_bytes(KSTEPS) / 16;
+    const int ROWB = (is_ref && hi_only) ? KSTEPS * 32 : cmk2::row_bytes(KSTEPS);
+    const int TILEB = cmk2::BR * ROWB + (yn_block ? 1024 : 0);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float yn_f = 0.f;
     if (i < n_pad) {
@@ -176,7 +179,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
         const int64_t tile = i / cmk2::BR;
         const int r = (int)(i - tile * cmk2::BR);
         char *rowp = is_ref ? P + tile * TILEB + (size_t)r * ROWB : P + i * (size_t)ROWB;
-        const int f = is_ref ? cmk2::swz(r, KSTEPS) : 0;
+        const int f = is_ref ? cmk2::swz_b(r, ROWB) : 0;
         double nscale = 1.0;
         const T *x = X + i * d;
         double s2 = 0.0;  // squared norm of the centred (cosine: normalised, then centred) row
@@ -226,7 +229,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                 lo[e] = l;
             }
             *reinterpret_cast<cmk2::half8 *>(rowp + ((g ^ f) * 16)) = hi;
-            *reinterpret_cast<cmk2::half8 *>(rowp + (((GRAN / 2 + g) ^ f) * 16)) = lo;
+            if (!(is_ref && hi_only)) *reinterpret_cast<cmk2::half8 *>(rowp + (((GRAN / 2 + g) ^ f) * 16)) = lo;
         }
         yn_f = (i < n) ? (float)s2 : 0.f;
         if (yn_block && is_ref) {
@@ -718,6 +721,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     bool reranked = false;
     const int bs = 256;
     if (f16) {
+        int img_hi_only = 0;   // layout of the reference tile image currently in Rp
         char *Rp = (char *)cm_ws_alloc(h, (size_t)p2.n_tiles * p2.tileb);
         char *Qp = (char *)cm_ws_alloc(h, (size_t)p2.nq_pad * p2.rowb);
         const int wpb = path == 3 ? cmk2::NWW : cmk2::NW;  // waves per workgroup
@@ -741,10 +745,18 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                                p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp));
         } else {
             hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
+            // reference image in the layout the first level reads (levels 1/2 of the K <= 64 kernel: hi-only rows); rebuilt
+            // inside the level loop if the filter escalates to level 3
+            img_hi_only = (path == 1 && levels[0] < 3) ? 1 : 0;
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words, path == 3);
+                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
+                               path == 3, img_hi_only);
+            if (path == 1) {
+                p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, img_hi_only != 0);
+                p2.lds = cmk2::RING * p2.tileb + 64;
+            }
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3);
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0);
         }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
@@ -776,6 +788,19 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
             c_split = (path == 1 || path == 3) ? (nprod == 1 ? 2.0f : (nprod == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f : 0.f;
             if (li > 0) hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+            if (path == 1 || path == 3) {
+                const int hi_only = (path == 1 && nprod < 3) ? 1 : 0;
+                if (hi_only != img_hi_only) {   // (re)build the reference tile image in the layout this level reads
+                    hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref,
+                                       d, p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr,
+                                       words, path == 3, hi_only);
+                    img_hi_only = hi_only;
+                    if (path == 1) {
+                        p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, hi_only != 0);
+                        p2.lds = cmk2::RING * p2.tileb + 64;
+                    }
+                }
+            }
             if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
             else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
             else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));

@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CM2_NW
 #define CM2_NW 8
 #endif
+#ifndef CM2_EXP
+#define CM2_EXP 0  // timing experiments only (scripts/exp14.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
+#endif
 constexpr int BR = CM2_BR;  // reference rows per LDS tile
 constexpr int NW = CM2_NW;  // waves per workgroup: one 8-wave workgroup per CU (512 queries share every tile fill;
                             // measured 6-10 % faster than two 4-wave workgroups once threshold refreshes were scheduled)
@@ -52,9 +55,14 @@ __host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes
 // the three constants), so it is summed by the hi*hi MFMA chain itself -- no accumulator initialisation, no extra reads.
 constexpr int NORM_SLOTS = 3;
 // XOR applied to a row's 16-byte granule index (row stride is a power of two: spread rows over the 16 LDS slots)
-__host__ __device__ constexpr int swz(int row, int KSTEPS) {
-    return KSTEPS >= 4 ? (row & 15) : ((row >> 1) & 7);  // KSTEPS=2: 128-byte rows, two rows per 256-byte bank row
+__host__ __device__ constexpr int swz_b(int row, int rowb) {   // by row size: the index of the row's 256-byte bank row
+    return rowb >= 256 ? (row & 15) : (rowb == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3));
 }
+__host__ __device__ constexpr int swz(int row, int KSTEPS) { return swz_b(row, row_bytes(KSTEPS)); }
+// Filter levels 1 and 2 never touch the lo halves of the reference rows: they run on a hi-only tile image (half the
+// LDS-DMA traffic and LDS footprint).  Level 3 uses the full [hi | lo] rows.
+__host__ __device__ constexpr int img_row_bytes(int KSTEPS, bool hi_only) { return hi_only ? KSTEPS * 32 : row_bytes(KSTEPS); }
+__host__ __device__ constexpr int img_tile_bytes(int KSTEPS, bool hi_only) { return BR * img_row_bytes(KSTEPS, hi_only); }
 __host__ inline size_t lds_bytes(int KSTEPS, int scratch_entries) {
     return 2 * size_t(tile_bytes(KSTEPS)) + size_t(NW) * scratch_entries * 8 + 64;
 }
@@ -416,9 +424,9 @@ template <int KSTEPS, int NP>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr bool LO3 = NP == 3;
     constexpr int K = KSTEPS * 16;
-    constexpr int ROWB = row_bytes(KSTEPS);
-    constexpr int GRAN = ROWB / 16;        // granules per row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
-    constexpr int TILEB = tile_bytes(KSTEPS);
+    constexpr int ROWB = img_row_bytes(KSTEPS, !LO3);
+    constexpr int GRAN = row_bytes(KSTEPS) / 16;   // granules of a full row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
+    constexpr int TILEB = img_tile_bytes(KSTEPS, !LO3);
     constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     }
         // granule (2s+hh) of the hi half sits at (2s+hh)^f = (hh^f) ^ 2s, the lo half at ... ^ GRAN/2 (f < GRAN, the
         // swizzle repeats every 32 rows): one row address per lane, fragment = address ^ constant
-        const unsigned arow = c * ROWB + ((hh ^ swz(c, KSTEPS)) * 16);
+        const unsigned arow = c * ROWB + ((hh ^ swz_b(c, ROWB)) * 16);
 
         int next_refresh = t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
         half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 if (!LO3 && t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPIECE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
-                __builtin_amdgcn_s_barrier();
+                if (!(CM2_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
             }
             if (LO3 && t + 2 < t1) CM2_DMA_TILE(t + 2, (t + 2) % RING);   // NP < 3: one piece per sub-tile, below
@@ -556,6 +564,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 const int nst = (st + 1 < NST) ? st + 1 : 0;
                 const bool pre = (st + 1 < NST) || more;
                 float mm[16];
+                if (CM2_EXP & 8) { _Pragma("unroll") for (int e = 0; e < 16; ++e) mm[e] = p0[e]; }
                 (void)pre;
                 if constexpr (LO3) {
                     wait_lds<KSTEPS>(ah);   // the lo fragments of this sub-tile may still be in flight
@@ -600,10 +609,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                         else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         // (at the last sub-tile of the last tile this reads a stale buffer; the result is never used)
-                        if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+                        if (i < KSTEPS && !(CM2_EXP & 4)) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
 #pragma unroll
-                        for (int jj = 0; jj < PER; ++jj) min_step(i * PER + jj, p0, p1, mm);
-                        if (i == NM - 1 && st < NPIECE) {
+                        for (int jj = 0; jj < PER; ++jj)
+                            if (!(CM2_EXP & 8) || i * PER + jj >= 14) min_step(i * PER + jj, p0, p1, mm);
+                        if (i == NM - 1 && st < NPIECE && !(CM2_EXP & 1)) {
                             if (t + 3 < t1) CM2_DMA_PIECE(t + 3, (t + 3) % RING, st);
                         }
                         __builtin_amdgcn_sched_barrier(0);
