@@ -652,7 +652,7 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d)
                          : (path == 3 ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(p->KSTEPS));
     p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
-    p->lds = (path == 1 ? cmk2::RING : 2) * p->tileb + 64;   // knn_cand_f16 keeps a 3-deep tile ring
+    p->lds = (path == 1 ? cmk2::ring_depth(false) : 2) * p->tileb + 64;   // knn_cand_f16: see ring_depth (set per level)
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
     const int qb = path == 3 ? cmk2::QBW : cmk2::QB;  // queries per workgroup pass of the chosen kernel
     p->nq_pad = (nq + qb - 1) / qb * qb;
@@ -753,7 +753,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                                path == 3, img_hi_only);
             if (path == 1) {
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, img_hi_only != 0);
-                p2.lds = cmk2::RING * p2.tileb + 64;
+                p2.lds = cmk2::ring_depth(img_hi_only != 0) * p2.tileb + 64;
             }
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
                                p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0);
@@ -797,7 +797,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                     img_hi_only = hi_only;
                     if (path == 1) {
                         p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, hi_only != 0);
-                        p2.lds = cmk2::RING * p2.tileb + 64;
+                        p2.lds = cmk2::ring_depth(hi_only != 0) * p2.tileb + 64;
                     }
                 }
             }

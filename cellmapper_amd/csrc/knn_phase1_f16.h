@@ -47,7 +47,9 @@ constexpr int NW = CM2_NW;  // waves per workgroup: one 8-wave workgroup per CU 
 constexpr int NT = NW * 64;
 constexpr int QB = NW * 64;  // queries per workgroup pass
 constexpr int CL = 128;      // lane-private append buffer capacity (entries)
-constexpr int RING = 4;      // LDS tile buffers of knn_cand_f16: tile t+1 has landed while tile t is computed (see the kernel)
+// LDS tile buffers of knn_cand_f16 (tile t+1 has landed while tile t is computed, see the kernel): 4 full 32-KB tiles
+// at level 3, 8 hi-only 16-KB tiles at levels 1/2
+__host__ __device__ constexpr int ring_depth(bool hi_only) { return hi_only ? 8 : 4; }
 
 __host__ __device__ constexpr int row_bytes(int KSTEPS) { return KSTEPS * 16 * 2 * 2; }  // hi + lo halves
 __host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes(KSTEPS); }
@@ -427,6 +429,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int ROWB = img_row_bytes(KSTEPS, !LO3);
     constexpr int GRAN = row_bytes(KSTEPS) / 16;   // granules of a full row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
     constexpr int TILEB = img_tile_bytes(KSTEPS, !LO3);
+    constexpr int RING = ring_depth(!LO3);
+    constexpr int AHEAD = LO3 ? 2 : RING - 1;   // the DMA of tile t + AHEAD is issued during tile t
     constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
@@ -491,17 +495,17 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
         int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
 
-        // Ring protocol (RING = 4 buffers, tile t lives in buffer t % 4).  At the top of tile t every wave waits for
-        // its own DMA pieces of tile t+1, then the workgroup barrier makes tile t+1 complete for everyone and tells
-        // that everyone is done with tile t-1.  Tile t itself was complete one barrier earlier, so the fragments of
-        // its first sub-tile are requested BEFORE the barrier (end of tile t-1): the MFMA chain runs through the
-        // barrier without an LDS-latency bubble.  NP = 3 issues the DMA of tile t+2 at the top of tile t; NP < 3
-        // spreads the pieces of tile t+3 over the sub-tiles of tile t (buffer of tile t-1), so that the wait at the
-        // top of tile t+1 (for tile t+2, issued a whole tile earlier) may leave them in flight.
+        // Ring protocol (tile t lives in buffer t % RING).  At the top of tile t every wave waits for its own DMA pieces
+        // of tile t+1, then the workgroup barrier makes tile t+1 complete for everyone and tells that everyone is done
+        // with tile t-1.  Tile t itself was complete one barrier earlier, so the fragments of its first sub-tile are
+        // requested BEFORE the barrier (end of tile t-1): the MFMA chain runs through the barrier without an
+        // LDS-latency bubble.  NP = 3 issues the DMA of tile t+2 at the top of tile t; NP < 3 spreads the pieces of
+        // tile t+AHEAD (buffer of tile t-1) over the sub-tiles of tile t, so the wait at a tile boundary is a counted
+        // vmcnt that leaves the pieces of the AHEAD-2 youngest tiles in flight.
         __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
-        if (t0 < t1) CM2_DMA_TILE(t0, t0 % RING);
-        if (t0 + 1 < t1) CM2_DMA_TILE(t0 + 1, (t0 + 1) % RING);
-        if (!LO3 && t0 + 2 < t1) CM2_DMA_TILE(t0 + 2, (t0 + 2) % RING);
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u)
+            if (t0 + u < t1) CM2_DMA_TILE(t0 + u, (t0 + u) % RING);
 
         // Software pipeline: the filter of sub-tile i-1 (VALU) is issued in the shadow of sub-tile i's MFMA chain.
         f32x16 p0, p1;          // accumulators of the previous sub-tile, waiting to be filtered (+inf = nothing pending)
@@ -541,10 +545,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0) {   // (the first tile synchronised above)
-                // own pieces of tile t+1 have landed; NP < 3: those of tile t+2 (issued during tile t-1) may be in
+                // own pieces of tile t+1 have landed; NP < 3: those of younger tiles may be in
                 // flight -- loads complete in order, stores in between only make the wait more conservative
-                if (!LO3 && t + 2 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NPIECE) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!LO3 && t + AHEAD - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (conservative in the tail of a work item)
                 if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
                 if (!(CM2_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 } else {
                     // Hand-placed stream: after every MFMA of the hi*hi chain one gap's worth of the other work of this
                     // sub-tile -- a fragment read for the next sub-tile, two or four steps of the PREVIOUS sub-tile's
-                    // min trees, one DMA piece of tile t+2 -- so that a wave paces the matrix pipe on its own and the
+                    // min trees, one DMA piece of tile t+AHEAD -- so that a wave paces the matrix pipe on its own and the
                     // two waves of a SIMD mesh MFMA by MFMA, whatever their relative phase.
                     half8(&cur)[KSTEPS] = (st & 1) ? al : ah;
                     half8(&nxt)[KSTEPS] = (st & 1) ? ah : al;
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                         for (int jj = 0; jj < PER; ++jj)
                             if (!(CM2_EXP & 8) || i * PER + jj >= 14) min_step(i * PER + jj, p0, p1, mm);
                         if (i == NM - 1 && st < NPIECE && !(CM2_EXP & 1)) {
-                            if (t + 3 < t1) CM2_DMA_PIECE(t + 3, (t + 3) % RING, st);
+                            if (t + AHEAD < t1) CM2_DMA_PIECE(t + AHEAD, (t + AHEAD) % RING, st);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
