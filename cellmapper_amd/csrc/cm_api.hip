@@ -482,3 +482,46 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- diagnostics --------------------------
+// Raw v_mfma_f32_32x32x16_f16 problems, one wave each: D = A(32x16) * B(16x32) + C(32x32).  Used by the tests to pin
+// the instruction's accumulation arithmetic (the rounding model behind the phase-1 certificate).
+namespace {
+typedef _Float16 dbg_half8 __attribute__((ext_vector_type(8)));
+typedef float dbg_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void debug_mfma_f16(const _Float16 *__restrict__ A, const _Float16 *__restrict__ B,
+                                                     const float *__restrict__ C, float *__restrict__ D, int chain) {
+    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+    const int64_t p = blockIdx.x;
+    dbg_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = C[p * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + c];
+    for (int s = 0; s < chain; ++s) {   // chain > 1: consecutive k-steps accumulate into the same registers
+        dbg_half8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = A[((p * chain + s) * 32 + c) * 16 + 8 * hh + e];      // A[row c][k = 8 hh + e]
+            b[e] = B[((p * chain + s) * 16 + 8 * hh + e) * 32 + c];      // B[k = 8 hh + e][col c]
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D[p * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + c] = acc[r];
+}
+}  // namespace
+
+cm_status cm_debug_mfma_f16(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
+                            int32_t chain) {
+    if (!h) return CM_E_INVALID;
+    if (n < 1 || chain < 1) CM_FAIL(h, CM_E_INVALID, "debug mfma: bad shape");
+    CM_TRY(begin_call(h, 0));
+    DevBuf da, db, dc, dd;
+    const size_t na = (size_t)n * chain * 512 * 2, nc = (size_t)n * 1024 * 4;
+    CM_TRY(da.alloc(h, na)); CM_TRY(db.alloc(h, na)); CM_TRY(dc.alloc(h, nc)); CM_TRY(dd.alloc(h, nc));
+    CM_TRY(h2d(h, da.p, a, na)); CM_TRY(h2d(h, db.p, b, na)); CM_TRY(h2d(h, dc.p, c, nc));
+    hipLaunchKernelGGL(debug_mfma_f16, dim3((unsigned)n), dim3(64), 0, h->stream, da.as<_Float16>(), db.as<_Float16>(),
+                       dc.as<float>(), dd.as<float>(), (int)chain);
+    CM_HIP(h, hipGetLastError());
+    CM_TRY(d2h(h, d, dd.p, nc));
+    return sync(h);
+}

@@ -372,10 +372,16 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                 for (int c = 0; c < d; ++c) { double v = q[c] * ns - (mean ? mean[c] : 0.0); qn2 = fma(v, v, qn2); }
             }
             double sk = ((metric == CM_METRIC_COSINE) ? 2.0 * kth : kth) - qn2;
-            double ymax2 = (double)__uint_as_float(gmax[0]), ymax = (double)__uint_as_float(gmax[1]);
+            double ymax = (double)__uint_as_float(gmax[1]);
+            // Only a non-candidate with true value <= s_k could invalidate the result; such a row lies within the k-th
+            // candidate's distance of the query, so |y'| <= |q'| + sqrt(D_k): the filter error that matters is bounded
+            // with that norm instead of the global maximum (much tighter for queries near the centre of the data).
+            const double qn = (double)qnorm[i];
+            const double dk = sqrt(fmax(sk + qn2, 0.0)) * (1.0 + 1e-7);
+            if (qn + dk < ymax) ymax = qn + dk;
+            const double ymax2 = ymax * ymax;
             // c_eps: accumulation / representation error on every term; c_split: split products that were dropped
-            double eps = (double)c_eps * (ymax2 + 2.0 * (double)qnorm[i] * ymax + 1e-30) +
-                         (double)c_split * 2.0 * (double)qnorm[i] * ymax;
+            double eps = (double)c_eps * (ymax2 + 2.0 * qn * ymax + 1e-30) + (double)c_split * 2.0 * qn * ymax;
             certified = sk < (double)tau - eps;
         } else if (tau < INFINITY) {
             // low-d kernel: phase-1 value is the full direct squared distance sum (q-y)^2 in fp32; relative error
@@ -775,9 +781,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             a.ctr = d_ctr;
             g_dbg_ctr = d_ctr;
         }
-        // split-fp16 error bound: f32 accumulation of 3*K+1 terms (taken at 2^-22 per term to be safe about the
-        // MFMA's internal summation) + dropped lo*lo term + representation residuals
-        c_eps = path == 3 ? 1.0e-4f : 5.5e-5f;  // K = 128: 385 accumulated terms
+        c_eps = 0.f;  // split-fp16 kernels: set per level below
         // low-d kernel: relative bound of the fp32 direct sum (sign of c_eps selects the certificate form)
         if (path == 2) c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;
         for (int li = 0; li < n_levels; ++li) {
@@ -787,6 +791,19 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             a.nprod = nprod;
             // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
             c_split = (path == 1 || path == 3) ? (nprod == 1 ? 2.0f : (nprod == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f : 0.f;
+            if (path == 1 || path == 3) {
+                // Error of the products that ARE evaluated, relative to |y'|^2 + 2|q'||y'|:
+                //  * accumulation: one v_mfma_f32_32x32x16_f16 returns C + sum of 16 exact products with an error of at most
+                //    16*2^-24*max|product| (alignment of the addends, truncated below 2^-24 of the largest one in each
+                //    half of 8) + 2*2^-24*(|C| + sum|products|) (roundings when the halves and C are combined).  Over a
+                //    chain of n instructions: (16 + 2n)*2^-24*(sum of all magnitudes).  This model of the instruction is
+                //    validated on the device by tests/test_gpu_parity.py::test_mfma_f16_accumulation_bound (observed
+                //    maximum 8*2^-24 at n = 24); the certificate uses TWICE the bound.
+                //  * representation: dropped lo*lo product and the residuals of the two-term splits (3*2^-22), fp32
+                //    rounding of the centred, scaled coordinates (2*2^-24), times 1.01 for the second-order terms.
+                const int n_instr = p2.KSTEPS * nprod + (path == 3 ? 1 : 0);   // K = 128 kernel: + the fp32 add of |y|^2
+                c_eps = 2.0f * (float)(16 + 2 * n_instr) * 5.9604645e-8f + 8.4e-7f;
+            }
             if (li > 0) hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
             if (path == 1 || path == 3) {
                 const int hi_only = (path == 1 && nprod < 3) ? 1 : 0;

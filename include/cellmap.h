@@ -203,6 +203,13 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
                             const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code, float *d_out_conf,
                             double *d_out_dist, int64_t *d_out_idx);
 
+/* ---------------------------------------------------------------- diagnostics -----------------------
+ * n independent products D = A*B + C on one v_mfma_f32_32x32x16_f16 chain each (chain k-steps of 16): a fp16 bits
+ * [n, chain, 32, 16] row-major, b fp16 bits [n, chain, 16, 32], c / d float32 [n, 32, 32].  Test aid: pins the
+ * accumulation arithmetic the phase-1 error bound assumes (no reference counterpart). */
+cm_status cm_debug_mfma_f16(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
+                            int32_t chain);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,8 @@ def main():
     ap.add_argument("--d", type=int, default=2); ap.add_argument("--k", type=int, default=90)
     ap.add_argument("--uniform", type=float, default=2000.0); ap.add_argument("--self", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--clusters", type=int, default=0, help="draw rows from this many Gaussian clusters (centres N(0, spread^2))")
+    ap.add_argument("--spread", type=float, default=5.0); ap.add_argument("--sigma", type=float, default=1.0)
     a = ap.parse_args()
     import torch
     from cellmapper_amd.device import DevicePipeline
@@ -16,6 +18,11 @@ def main():
     g = torch.Generator(device=pipe.device); g.manual_seed(0)
     mk = (lambda n: torch.rand((n, a.d), generator=g, device=pipe.device) * a.uniform) if a.uniform > 0 else \
          (lambda n: torch.randn((n, a.d), generator=g, device=pipe.device))
+    if a.clusters > 0:
+        cen = torch.randn((a.clusters, a.d), generator=g, device=pipe.device) * a.spread
+        def mk(n):
+            lab = torch.randint(0, a.clusters, (n,), generator=g, device=pipe.device)
+            return cen[lab] + torch.randn((n, a.d), generator=g, device=pipe.device) * a.sigma
     ref = mk(a.nref); qry = ref if a.self else mk(a.nq)
     for _ in range(a.reps):
         dist, idx = pipe.knn(ref, qry, a.k)

@@ -217,6 +217,50 @@ def test_exact_fallback_sliced_and_per_query_paths(oracle):
     assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
 
 
+def test_mfma_f16_accumulation_bound(hip):
+    """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
+    an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
+    that).  Check the model on this device: random operands over a wide exponent range and designed cases (tiny addends
+    next to a large one, cancellation)."""
+    import ctypes as C
+
+    def run(a, b, c, chain):
+        d = np.empty_like(c)
+        hip.call("cm_debug_mfma_f16", a.view(np.uint16).ctypes.data_as(C.c_void_p),
+                 b.view(np.uint16).ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                 d.ctypes.data_as(C.c_void_p), c.shape[0], chain)
+        return d
+
+    def check(a, b, c, chain):
+        d = run(a, b, c, chain)
+        a64, b64, c64 = a.astype(np.float64), b.astype(np.float64), c.astype(np.float64)
+        exact = c64 + np.einsum("nsik,nskj->nij", a64, b64)  # products of fp16 are exact in float64
+        mag = np.abs(c64) + np.einsum("nsik,nskj->nij", np.abs(a64), np.abs(b64))
+        err = np.abs(d.astype(np.float64) - exact)
+        ok = err <= (16 + 2 * chain) * 2.0 ** -24 * mag + 1e-300
+        assert ok.all(), (chain, float((err / np.maximum(mag, 1e-300)).max() / 2.0 ** -24))
+
+    rng = np.random.default_rng(7)
+    for chain in (1, 4, 8, 12, 25):
+        for spread in (0, 3, 8):
+            n = 64
+            a = (rng.standard_normal((n, chain, 32, 16)) * np.exp2(rng.integers(-spread, spread + 1, (n, chain, 32, 16)))).astype(np.float16)
+            b = (rng.standard_normal((n, chain, 16, 32)) * np.exp2(rng.integers(-spread, spread + 1, (n, chain, 16, 32)))).astype(np.float16)
+            c = (rng.standard_normal((n, 32, 32)) * np.exp2(rng.integers(-4, 8, (n, 32, 32)))).astype(np.float32)
+            check(a, b, c, chain)
+    # designed: one addend of 1.0 (as C or as a product) and fifteen / sixteen of 2^-s; -1 + 1 + 2^-s
+    S = list(range(10, 30))
+    n = len(S)
+    a = np.zeros((n, 1, 32, 16), np.float16); b = np.zeros((n, 1, 16, 32), np.float16)
+    for t, s in enumerate(S):
+        a[t, 0] = np.float16(2.0 ** -(s // 2)); b[t, 0] = np.float16(2.0 ** -(s - s // 2))
+    check(a, b, np.ones((n, 32, 32), np.float32), 1)
+    a2, b2 = a.copy(), b.copy()
+    a2[:, 0, :, 0] = 1.0; b2[:, 0, 0, :] = 1.0
+    check(a2, b2, np.zeros((n, 32, 32), np.float32), 1)
+    check(a2, b2, -np.ones((n, 32, 32), np.float32), 1)
+
+
 def test_cosine_matches_oracle(hip, oracle):
     rng = np.random.default_rng(11)
     ref = rng.standard_normal((6000, 50)).astype(np.float32)
