@@ -3,6 +3,7 @@
 //
 // Reference interface replaced: Neighbors.compute_neighbors, sklearn branch, /root/reference/src/cellmapper/model/
 // knn.py:428-440 (sklearn.neighbors.NearestNeighbors(...).fit(xrep).kneighbors(yrep)).
+#include <algorithm>
 #include "cm_internal.h"
 #include "knn_phase1.h"
 #include "knn_phase1_f16.h"
@@ -166,7 +167,8 @@ __global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__res
 template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
                               const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
-                              float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only) {
+                              float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only,
+                              const int *__restrict__ rowmap) {
     // yn_block != 0 (K = 128 kernel): no norm slots; the tile image ends with a block of 128 floats sc^2|y|^2
     // hi_only != 0 (reference image of filter levels 1/2): rows hold the hi halves only
     const int GRAN = cmk2::row_bytes(KSTEPS) / 16;
@@ -181,7 +183,8 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
         char *rowp = is_ref ? P + tile * TILEB + (size_t)r * ROWB : P + i * (size_t)ROWB;
         const int f = is_ref ? cmk2::swz_b(r, ROWB) : 0;
         double nscale = 1.0;
-        const T *x = X + i * d;
+        // rowmap (queries only): prepare row i from source row rowmap[i] (query subsets of the staged search)
+        const T *x = X + ((rowmap && i < n) ? (int64_t)rowmap[i] : i) * d;
         double s2 = 0.0;  // squared norm of the centred (cosine: normalised, then centred) row
         if (i < n) {
             if (metric == CM_METRIC_COSINE) {
@@ -252,12 +255,15 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
 // X [n,d] -> float32 rows [n_pad][d] for the low-d kernel (cosine: normalised); padded reference rows are +inf.
 template <typename T>
 __global__ void prep_rows_lowd(const T *__restrict__ X, int64_t n, int d, int64_t n_pad, int is_ref, int metric,
-                               float *__restrict__ P) {
+                               float *__restrict__ P, int dpad, const int *__restrict__ rowmap) {
+    // dpad >= d: row stride of the prepared image (extra columns are zero on both sides); rowmap: prepare row i from
+    // source row rowmap[i] (query subsets of the staged search)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    float *out = P + i * d;
+    float *out = P + i * dpad;
+    for (int c = d; c < dpad; ++c) out[c] = 0.f;
     if (i < n) {
-        const T *x = X + i * d;
+        const T *x = X + (rowmap ? (int64_t)rowmap[i] : i) * d;
         double nscale = 1.0;
         if (metric == CM_METRIC_COSINE) {
             double s = 0.0;
@@ -317,16 +323,26 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    const double *__restrict__ mean, int64_t idx_offset,
                                                    int flags, void *__restrict__ out_dist,
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
-                                                   int *__restrict__ flag_cnt, double *__restrict__ bound) {
+                                                   int *__restrict__ flag_cnt, double *__restrict__ bound,
+                                                   const int *__restrict__ qmap, int pilot_kc) {
+    // qmap != nullptr: the nq rows of cand / cthr / qnorm belong to the query SUBSET qmap[0..nq) (staged search);
+    // the query row, the outputs, the bound and the flag entry use the original index io.
+    // pilot_kc > 0 (pilot of the staged search): a small sample runs with many reference splits, whose union of
+    // candidate lists certifies far more easily than the single list of pilot_kc candidates the full run will keep.
+    // The flag then answers "would a single list of pilot_kc candidates have been certified?": the threshold is
+    // emulated by the exact value of the pilot_kc-th best candidate of the union, less the filter error.
     __shared__ double s_q[4][RR_DMAX];
     __shared__ double s_v[4][RR_NCMAX];
     __shared__ int s_i[4][RR_NCMAX];
     __shared__ double s_kth[4];
+    __shared__ double s_kc[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= nq) return;
+    if (lane == 0) s_kc[w] = INFINITY;
+    const int64_t io = qmap ? (int64_t)qmap[i] : i;
     double *q = s_q[w];
-    for (int c = lane; c < d; c += 64) q[c] = (double)qry[i * d + c];
+    for (int c = lane; c < d; c += 64) q[c] = (double)qry[io * d + c];
     __builtin_amdgcn_wave_barrier();
     double xn = 0.0;
     for (int c = 0; c < d; ++c) xn = fma(q[c], q[c], xn);
@@ -348,11 +364,12 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (rk < k) {
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
-            if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
-            else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
-            out_idx[i * k + rk] = (int64_t)id + idx_offset;
+            if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
+            else reinterpret_cast<double *>(out_dist)[io * k + rk] = o;
+            out_idx[io * k + rk] = (int64_t)id + idx_offset;
             if (rk == k - 1) s_kth[w] = v;
         }
+        if (pilot_kc > 0 && rk == pilot_kc - 1) s_kc[w] = v;
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
@@ -382,7 +399,12 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             const double ymax2 = ymax * ymax;
             // c_eps: accumulation / representation error on every term; c_split: split products that were dropped
             double eps = (double)c_eps * (ymax2 + 2.0 * qn * ymax + 1e-30) + (double)c_split * 2.0 * qn * ymax;
-            certified = sk < (double)tau - eps;
+            double tau_d = (double)tau;
+            if (pilot_kc > 0) {
+                const double vkc = s_kc[w];
+                tau_d = vkc < INFINITY ? ((metric == CM_METRIC_COSINE) ? 2.0 * vkc : vkc) - qn2 - eps : INFINITY;
+            }
+            certified = sk < tau_d - eps;
         } else if (tau < INFINITY) {
             // low-d kernel: phase-1 value is the full direct squared distance sum (q-y)^2 in fp32; relative error
             // -c_eps, plus the rounding of float64 inputs to fp32 (2^-24 * max|coordinate| per coordinate)
@@ -398,8 +420,8 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         }
         if (!certified || (flags & CM_KNN_FORCE_FALLBACK)) {
             int pos = atomicAdd(flag_cnt, 1);
-            flag_list[pos] = (int)i;
-            bound[i] = kth;
+            flag_list[pos] = (int)io;
+            bound[io] = kth;
         }
     }
 }
@@ -631,6 +653,8 @@ struct KnnPlan2 {
 };
 
 int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
+// row stride of the direct-difference (VALU) kernel: d itself up to 15, else padded to the instantiated widths
+int lowd_dpad(int d) { return d <= 15 ? d : (d + 3) / 4 * 4; }
 // candidate slack of the split-fp16 kernels by number of products evaluated (coarser filter -> wider safety margin)
 int knn_slack_level(int k, int nprod) {
     if (const char *e = getenv("CELLMAP_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 256) return v; }  // tuning only
@@ -644,6 +668,7 @@ int knn_slack_level(int k, int nprod) {
 int phase1_path(int d, int k) {
     const char *e = getenv("CELLMAP_PHASE1");
     if (e && !strcmp(e, "f32")) return 0;
+    if (e && !strcmp(e, "direct") && d <= 64) return 2;   // diagnostics: the VALU direct-difference kernel for any d <= 64
     if (k + knn_slack_level(k, 1) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
     if (d <= 15 && !(e && !strcmp(e, "f16"))) return 2;
     if (d + cmk2::NORM_SLOTS <= 64) return 1;             // needs three spare feature slots for the norm digits
@@ -654,10 +679,11 @@ bool use_f16_path(int d, int k) { return phase1_path(d, k) != 0; }
 cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int path, int nprod, KnnPlan2 *p) {
     p->KSTEPS = path == 3 ? cmk2::KSTEPS_W : (d + cmk2::NORM_SLOTS <= 32 ? 2 : 4);
     p->Kc = k + ((path == 1 || path == 3) ? knn_slack_level(k, nprod) : knn_slack(k));
-    const int tile_rows = path == 2 ? cmk2::BRL : cmk2::BR;
-    p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(d)
+    const int dl = lowd_dpad(d);   // path 2: row stride of the direct-difference kernel
+    const int tile_rows = path == 2 ? cmk2::lowd_rows(dl) : cmk2::BR;
+    p->tileb = path == 2 ? (size_t)cmk2::lowd_tile_bytes(dl)
                          : (path == 3 ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(p->KSTEPS));
-    p->rowb = path == 2 ? (size_t)d * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
+    p->rowb = path == 2 ? (size_t)dl * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
     p->lds = (path == 1 ? cmk2::ring_depth(false) : 2) * p->tileb + 64;   // knn_cand_f16: see ring_depth (set per level)
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
     const int qb = path == 3 ? cmk2::QBW : cmk2::QB;  // queries per workgroup pass of the chosen kernel
@@ -671,7 +697,7 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     int S = 1;
     if (p->nqb < resident) {
         S = (resident + p->nqb - 1) / p->nqb;
-        if (S > 8) S = 8;
+        if (S > 16) S = 16;
         if (S > p->n_tiles) S = p->n_tiles;
         while (S > 1 && S * p->Kc > RR_NCMAX) --S;
         if (S < 1) S = 1;
@@ -684,11 +710,227 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     return CM_OK;
 }
 
+__global__ void strided_rows(int *__restrict__ out, int n, int64_t stride) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)(i * stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Staged exact search for d <= 61 (split-fp16 MFMA kernel family).  The filter only has to be good enough to be
+// certified, so the search climbs a ladder of filters of increasing precision and cost, and only the queries that fail
+// the certificate of one stage go to the next:
+//   level 1: hi*hi split product (1/3 of the MFMA work, error ~2^-10 |q'||y'|)
+//   level 3: three split products (error ~5e-6 |q'||y'|)
+//   level 4: direct-difference fp32 filter on the VALU (relative error (d+4)*2^-23 -- immune to the cancellation in
+//            |y|^2 - 2q.y that tight, off-centre clusters cause; ~15x the cost of level 1)
+//   then the exact float64 scan for whatever is left.
+// A pilot on a strided sample of the queries estimates the failure rate of the cheap levels and picks the level the
+// whole set starts at.  Every stage writes exact results for the queries it certifies; exactness never depends on the
+// path taken.  Host synchronisations: one per stage (flag counter).
+template <typename T>
+cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
+                         int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
+    hipStream_t st = h->stream;
+    const int bs = 256;
+    const int dl = lowd_dpad(d);   // row stride of the direct kernel
+    const bool have_direct = d >= 16 && dl <= 64;
+    const int dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
+    int forced = getenv("CELLMAP_FILTER_PRODUCTS") ? atoi(getenv("CELLMAP_FILTER_PRODUCTS")) : 0;
+    if (forced < 1 || forced > 4 || (forced == 4 && !have_direct)) forced = 0;
+
+    KnnPlan2 pf;   // plan of the full query set at level 1 (widest candidate lists): sizes the buffers
+    CM_TRY(make_plan2(h, n_ref, nq, d, k, 1, 1, &pf));
+    const int Kc_max = pf.Kc;
+    const int64_t nq_pad = pf.nq_pad;
+    // subsets may use more reference splits than the full set: rows of the candidate buffers
+    const int64_t cand_rows = std::max<int64_t>(nq_pad * pf.S, nq_pad + (int64_t)cmk2::QB * 512);
+    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
+    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * cand_rows * Kc_max);
+    float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * cand_rows);
+    int *flag_a = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
+    int *flag_b = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
+    const int n_pilot = nq >= 32768 ? 2048 : 0;
+    int *sample = (int *)cm_ws_alloc(h, sizeof(int) * 4096);
+    double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
+    unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
+    int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);
+    double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
+    int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
+    char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * cmk2::tile_bytes(pf.KSTEPS > 2 ? pf.KSTEPS : 4));  // 256 B per row: any image
+    char *Qp = (char *)cm_ws_alloc(h, (size_t)nq_pad * 256);
+    uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * Kc_max);
+    uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
+    double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
+    double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
+    if (!qnorm || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
+        !Qp || !kept || !lbuf || !cpart || !d_mean)
+        CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    if (pf.grid > 320) CM_FAIL(h, CM_E_INTERNAL, "k-NN: unexpected resident workgroup count %d", pf.grid);
+    float *scale3 = reinterpret_cast<float *>(words + 8);
+    cm_mark(h, 0);
+    hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
+    // centre at the reference mean (translation leaves every distance unchanged), common power-of-two scale
+    hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
+    hipLaunchKernelGGL(colmean_final, dim3(1), dim3(64), 0, st, cpart, n_ref, d, d_mean);
+    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, (const double *)d_mean, words);
+    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, (const double *)d_mean, words);
+    hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
+    CM_HIP(h, hipGetLastError());
+
+    g_dbg_ctr = nullptr;
+    unsigned long long *d_ctr = nullptr;
+    if (dbg & 4) {
+        static unsigned long long *s_ctr = nullptr;
+        if (!s_ctr) (void)hipMalloc((void **)&s_ctr, 128);
+        (void)hipMemsetAsync(s_ctr, 0, 128, st);
+        d_ctr = s_ctr;
+        g_dbg_ctr = s_ctr;
+    }
+
+    int img = -1;          // reference image currently in Rp: 0 full [hi|lo] tiles, 1 hi-only tiles, 2 direct (fp32 rows)
+    int last_Kc = Kc_max, last_S = 1;
+    // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
+    auto run_stage = [&](int level, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
+        KnnPlan2 p2;
+        CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : 1, level == 4 ? 3 : level, &p2));
+        const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
+        const int64_t nref_pad = (int64_t)p2.n_tiles * cmk2::BR;   // (the direct kernel's 128-row tiles have the same count)
+        if (img != want) {
+            if (want == 2)
+                hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                                   nref_pad, 1, metric, reinterpret_cast<float *>(Rp), dl, (const int *)nullptr);
+            else
+                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                                   p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words, 0,
+                                   want, (const int *)nullptr);
+            img = want;
+        }
+        if (level == 4) {
+            hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
+                               p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp), dl, qmap);
+        } else {
+            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, 0, 0,
+                               qmap);
+            p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
+            p2.lds = cmk2::ring_depth(want == 1) * p2.tileb + 64;
+        }
+        if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
+        cmk2::P1Args a;
+        a.Q = reinterpret_cast<const _Float16 *>(Qp);
+        a.R = Rp;
+        a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
+        a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
+        a.nprod = level == 4 ? 3 : level;
+        a.dbg = dbg; a.ctr = d_ctr;
+        last_Kc = p2.Kc; last_S = p2.S;
+        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+        if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
+        else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
+        if (marks) cm_mark(h, 2);
+        if (!rerank) return CM_OK;
+        const int pilot_kc = pilot ? p2.Kc : 0;
+        float c_eps, c_split = 0.f;
+        if (level == 4) {
+            c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;   // relative bound of the fp32 direct sum (knn_rerank)
+        } else {
+            // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
+            c_split = (level == 1 ? 2.0f : (level == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f;
+            // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
+            c_eps = 2.0f * (float)(16 + 2 * p2.KSTEPS * level) * 5.9604645e-8f + 8.4e-7f;
+        }
+        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
+                           p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
+                           level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
+                           idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc);
+        CM_HIP(h, hipGetLastError());
+        if (marks) cm_mark(h, 3);
+        return CM_OK;
+    };
+    auto read_flags = [&](int64_t *n) -> cm_status {
+        CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(h, hipStreamSynchronize(st));
+        *n = h->d_nflag_pinned[0];
+        return CM_OK;
+    };
+
+    // ---- choose the level the whole set starts at
+    int start = 1;
+    if (forced) start = forced;
+    else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
+    else if (n_pilot > 0 && !(dbg & 3)) {
+        hipLaunchKernelGGL(strided_rows, dim3((n_pilot + 255) / 256), dim3(256), 0, st, sample, n_pilot, nq / n_pilot);
+        int64_t nf = 0;
+        CM_TRY(run_stage(1, sample, n_pilot, flag_b, true, false, true));
+        CM_TRY(read_flags(&nf));
+        if (nf * 2 > n_pilot) {   // level 1 would fail for more than half: not worth its time
+            CM_TRY(run_stage(3, sample, n_pilot, flag_b, true, false, true));
+            CM_TRY(read_flags(&nf));
+            start = (have_direct && nf * 5 > (int64_t)n_pilot * 4) ? 4 : 3;
+        }
+    }
+    cm_mark(h, 1);   // (pilot and common preparation are accounted as "prep")
+
+    // ---- the ladder
+    const int *qmap = nullptr;
+    int64_t nsub = nq;
+    int *flag_out = flag_a;
+    int level = start, main_Kc = Kc_max, main_S = 1;
+    for (int stage = 0;; ++stage) {
+        CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
+        if (stage == 0) { main_Kc = last_Kc; main_S = last_S; }
+        if (dbg & 3) break;   // timing experiments: phase 1 only
+        const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0 : (level < 3 ? 3 : (level == 3 && have_direct ? 4 : 0));
+        if (!next) break;
+        int64_t nf = 0;
+        CM_TRY(read_flags(&nf));
+        if (nf <= 64) break;      // the sliced exact scan is cheaper than another stage for a handful of queries
+        qmap = flag_out;
+        nsub = nf;
+        flag_out = flag_out == flag_a ? flag_b : flag_a;
+        level = next;
+    }
+    if (g_dbg_ctr) {
+        unsigned long long hc[16] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hc, g_dbg_ctr, 128, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu event_cycles=%llu barrier_cycles=%llu dma_wait_cycles=%llu mfma_cluster_cycles=%llu\n",
+                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9]);
+    }
+    if (dbg & 3) return CM_OK;
+
+    // ---- exact float64 scan for the queries no stage could certify
+    hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
+    {
+        int rc = (int)(52 * 1024 / ((size_t)d * sizeof(T)));   // rows per staged chunk
+        rc = rc >= 256 ? 256 : (rc >= 32 ? rc / 32 * 32 : (rc < 1 ? 1 : rc));
+        const size_t fb_lds = (size_t)rc * d * sizeof(T);
+        auto scan = knn_fallback_scan<T>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds));
+        hipLaunchKernelGGL(scan, dim3(FBS_SLICES, FBS_FY), dim3(256), fb_lds, st, d_ref, n_ref, d_qry, d, metric, form, flag_out,
+                           (const int *)(words + 2), bound, fb_count, fb_v, fb_i, rc);
+    }
+    hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_out,
+                       (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
+                       d_out_idx, (int *)(words + 3));
+    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
+                       idx_offset, flags, flag_out, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
+                       (int *)(words + 3), FBS_NQ);
+    CM_HIP(h, hipGetLastError());
+    cm_mark(h, 4);
+    CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    h->knn_stats[1] = main_Kc;
+    h->knn_stats[2] = main_S + 100 * start;
+    h->knn_stats[3] = 2;
+    return CM_OK;
+}
+
 template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int path = phase1_path(d, k);
+    if (path == 1) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     const bool f16 = path != 0;  // either of the persistent-workgroup kernels (split-fp16 MFMA or low-d VALU)
     KnnPlan p;
     KnnPlan2 p2;
@@ -734,7 +976,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * Kc_max);
         uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * 2 * cmk2::CL);
         if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-        int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::BRL : cmk2::BR);
+        int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::lowd_rows(lowd_dpad(d)) : cmk2::BR);
         if (path == 1 || path == 3) {  // centre at the reference mean (translation leaves every distance unchanged)
             double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
             d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
@@ -746,9 +988,9 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, (const double *)d_mean, words);
         if (path == 2) {
             hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               nref_pad, 1, metric, reinterpret_cast<float *>(Rp));
+                               nref_pad, 1, metric, reinterpret_cast<float *>(Rp), lowd_dpad(d), (const int *)nullptr);
             hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp));
+                               p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp), lowd_dpad(d), (const int *)nullptr);
         } else {
             hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
             // reference image in the layout the first level reads (levels 1/2 of the K <= 64 kernel: hi-only rows); rebuilt
@@ -756,13 +998,14 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             img_hi_only = (path == 1 && levels[0] < 3) ? 1 : 0;
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
-                               path == 3, img_hi_only);
+                               path == 3, img_hi_only, (const int *)nullptr);
             if (path == 1) {
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, img_hi_only != 0);
                 p2.lds = cmk2::ring_depth(img_hi_only != 0) * p2.tileb + 64;
             }
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0);
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0,
+                               (const int *)nullptr);
         }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
@@ -810,7 +1053,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                 if (hi_only != img_hi_only) {   // (re)build the reference tile image in the layout this level reads
                     hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref,
                                        d, p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr,
-                                       words, path == 3, hi_only);
+                                       words, path == 3, hi_only, (const int *)nullptr);
                     img_hi_only = hi_only;
                     if (path == 1) {
                         p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, hi_only != 0);
@@ -818,7 +1061,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                     }
                 }
             }
-            if (path == 2) CM_TRY(cm_p1lowd_launch(h, d, p2.grid, p2.lds, a));
+            if (path == 2) CM_TRY(cm_p1lowd_launch(h, lowd_dpad(d), p2.grid, p2.lds, a));
             else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
             else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
             cm_mark(h, 2);
@@ -826,7 +1069,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             // not the last level: re-rank now and look at how many queries failed the certificate
             hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                                S, Kc, k, metric, form, qnorm, words, c_eps, c_split, scale3, (const double *)d_mean, idx_offset,
-                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
+                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0);
             cm_mark(h, 3);
             CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             CM_HIP(h, hipStreamSynchronize(st));
@@ -868,7 +1111,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                            S, Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
-                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound);
+                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0);
     if (!reranked) cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
@@ -902,13 +1145,17 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
-    size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 8 * Kc) + cm_align(4 * nq_pad * 8) +
+    size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
-        b += cm_align((size_t)n_tiles * (cmk2::tile_bytes(KSTEPS) + 1024) + 65536) + cm_align((size_t)nq_pad * cmk2::row_bytes(KSTEPS));
+        size_t tileb = (size_t)cmk2::tile_bytes(KSTEPS > 4 ? KSTEPS : 4) + 1024;   // any tile image of the staged search: <= 256 B per row
+        b += cm_align((size_t)n_tiles * tileb + 65536) + cm_align((size_t)nq_pad * (KSTEPS > 4 ? cmk2::row_bytes(KSTEPS) : 256));
         b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * Kc) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * 2 * cmk2::CL);
+        // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
+        b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
+             cm_align(4 * (nq + 1)) + 65536;
     } else {
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;

@@ -681,14 +681,16 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 // (~(D+2)*2^-24), so the certificate in knn_rerank stays tight.  Same workgroup geometry, lane <-> (query, row)
 // mapping, candidate logs, merges and refresh schedule as knn_cand_f16; reference rows are plain [row][D] floats in
 // 512-row tiles copied by LDS-DMA, read back as half-wave broadcasts.
-constexpr int BRL = 512;  // reference rows per tile of the low-d kernel
-__host__ __device__ constexpr int lowd_tile_bytes(int D) { return BRL * D * 4; }
+constexpr int BRL = 512;  // reference rows per tile of the low-d kernel (d <= 15); wider rows use 128-row tiles
+__host__ __device__ constexpr int lowd_rows(int D) { return D <= 15 ? BRL : 128; }
+__host__ __device__ constexpr int lowd_tile_bytes(int D) { return lowd_rows(D) * D * 4; }
 
 template <int D>
 __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     constexpr int TILEB = lowd_tile_bytes(D);
     constexpr int NCHUNK = TILEB / 1024;
-    constexpr int NST = BRL / 32;
+    constexpr int BRLD = lowd_rows(D);   // rows per tile
+    constexpr int NST = BRLD / 32;
     constexpr int NJ_ = 2;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;  // [2][TILEB]
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
                 float mp0, mp1;
                 CM2_MIN16(acc0, mp0);
                 CM2_MIN16(acc1, mp1);
-                const int rbase = t * BRL + st * 32 + 4 * hh;
+                const int rbase = t * BRLD + st * 32 + 4 * hh;
                 CM2_FILTER(acc0, acc1, mp0, mp1, rbase);
             }
             CM2_REFRESH(t, t0);

@@ -23,6 +23,8 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
     CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d", KSTEPS);
 }
 
+cm_status cm_p1direct_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
+
 template <int D>
 static cm_status launch_lowd(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
     auto kern = cmk2::knn_cand_lowd<D>;
@@ -39,6 +41,7 @@ cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk
         CM_LD_CASE(9) CM_LD_CASE(10) CM_LD_CASE(11) CM_LD_CASE(12) CM_LD_CASE(13) CM_LD_CASE(14) CM_LD_CASE(15)
 #undef CM_LD_CASE
     }
+    if (D >= 16) return cm_p1direct_launch(h, D, grid, lds, a);   // padded widths 16..64: knn_phase1_direct_inst.hip
     CM_FAIL(h, CM_E_INTERNAL, "phase1/lowd: no instantiation for D=%d", D);
 }
 
