@@ -825,6 +825,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.dbg = dbg; a.ctr = d_ctr;
         last_Kc = p2.Kc; last_S = p2.S;
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+        if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
         if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
         else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
         if (marks) cm_mark(h, 2);
@@ -856,8 +857,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
 
     // ---- choose the level the whole set starts at
     int start = 1;
+    const bool hinted = h->staged_hint_level == 1 && h->staged_hint_d == d && h->staged_hint_k == k &&
+                        h->staged_hint_metric == metric && !getenv("CELLMAP_NO_HINT");
     if (forced) start = forced;
     else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
+    else if (hinted) start = 1;   // level 1 certified most queries last time: no pilot
     else if (n_pilot > 0 && !(dbg & 3)) {
         hipLaunchKernelGGL(strided_rows, dim3((n_pilot + 255) / 256), dim3(256), 0, st, sample, n_pilot, nq / n_pilot);
         int64_t nf = 0;
@@ -869,7 +873,6 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             start = (have_direct && nf * 5 > (int64_t)n_pilot * 4) ? 4 : 3;
         }
     }
-    cm_mark(h, 1);   // (pilot and common preparation are accounted as "prep")
 
     // ---- the ladder
     const int *qmap = nullptr;
@@ -884,6 +887,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (!next) break;
         int64_t nf = 0;
         CM_TRY(read_flags(&nf));
+        if (stage == 0 && !forced) {   // remember whether the cheapest level is worth starting with next time
+            const bool good = level == 1 && nf * 2 <= nsub;
+            h->staged_hint_level = good ? 1 : 0;
+            h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
+        }
         if (nf <= 64) break;      // the sliced exact scan is cheaper than another stage for a handful of queries
         qmap = flag_out;
         nsub = nf;

@@ -217,6 +217,24 @@ def test_exact_fallback_sliced_and_per_query_paths(oracle):
     assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("sigma", [1.0, 0.2, 0.02])
+def test_staged_search_on_clustered_embeddings(hip, oracle, sigma):
+    """Tight, off-centre clusters are the hard case of the |y|^2 - 2q.y filter (cancellation): the staged search must
+    climb from the split-fp16 levels to the direct-difference level / exact scan and stay bit-exact.  nq >= 32768 so
+    that the pilot picks the start level."""
+    rng = np.random.default_rng(23)
+    d, k, n_ref, nq = 50, 15, 12000, 32768
+    cen = rng.standard_normal((12, d)) * 5.0
+    ref = (cen[rng.integers(0, 12, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 12, nq)] + sigma * rng.standard_normal((nq, d))).astype(np.float32)
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od), st
+    if sigma <= 0.2:
+        assert st["filter_products"] >= 3, st   # the hi*hi level cannot certify these: the pilot must skip it
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
