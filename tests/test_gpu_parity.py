@@ -235,6 +235,31 @@ def test_staged_search_on_clustered_embeddings(hip, oracle, sigma):
         assert st["filter_products"] >= 3, st   # the hi*hi level cannot certify these: the pilot must skip it
 
 
+def test_staged_search_float64_and_cosine_clusters(hip, oracle):
+    """Same hard case without the pilot (nq < 32768: the ladder starts at level 1 and escalates subsets): float64
+    Euclidean input (bit-exact) and float32 cosine (sklearn's float32 GEMM semantics: tie-aware comparison)."""
+    rng = np.random.default_rng(29)
+    d, k, n_ref, nq = 40, 12, 9000, 3000
+    cen = rng.standard_normal((8, d)) * 4.0
+    ref = cen[rng.integers(0, 8, n_ref)] + 0.05 * rng.standard_normal((n_ref, d))
+    qry = cen[rng.integers(0, 8, nq)] + 0.05 * rng.standard_normal((nq, d))
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert dist.dtype == np.float64 and np.array_equal(idx, oi) and np.array_equal(dist, od), hip.knn_stats()
+    # cosine: clusters wide enough that the float32 GEMM of the reference semantics still resolves the neighbours
+    ref = cen[rng.integers(0, 8, n_ref)] + 1.0 * rng.standard_normal((n_ref, d))
+    qry = cen[rng.integers(0, 8, nq)] + 1.0 * rng.standard_normal((nq, d))
+    r32, q32 = ref.astype(np.float32), qry.astype(np.float32)
+    dist, idx = hip.knn(r32, q32, k, metric="cosine")
+    od, oi = oracle.knn_cosine(r32, q32, k)
+    assert_knn_parity(dist, idx, od, oi, r32, q32, "cosine")
+    # and against an exact float64 evaluation of the same definition (no float32 GEMM noise): identical neighbour sets
+    rn = ref.astype(np.float32).astype(np.float64); qn = qry.astype(np.float32).astype(np.float64)
+    rn /= np.linalg.norm(rn, axis=1, keepdims=True); qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    ex = np.argsort(1.0 - qn[:200] @ rn.T, axis=1, kind="stable")[:, :k]
+    assert all(set(ex[i]) == set(idx[i]) for i in range(200))
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
