@@ -168,14 +168,17 @@ template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
                               const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
                               float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only,
-                              const int *__restrict__ rowmap) {
+                              const int *__restrict__ rowmap, float *__restrict__ rowlo) {
+    // rowlo (queries): |lo part of the row| in input units -- the certificate of filter level 1 bounds the dropped
+    // lo(query)*hi(ref) product with the query's ACTUAL lo norm (typically a third of the worst case 2^-11 |q'|);
+    // reference rows: gmax[5] = max over rows of |lo part| / |row| (same purpose, dropped hi(query)*lo(ref)).
     // yn_block != 0 (K = 128 kernel): no norm slots; the tile image ends with a block of 128 floats sc^2|y|^2
     // hi_only != 0 (reference image of filter levels 1/2): rows hold the hi halves only
     const int GRAN = cmk2::row_bytes(KSTEPS) / 16;
     const int ROWB = (is_ref && hi_only) ? KSTEPS * 32 : cmk2::row_bytes(KSTEPS);
     const int TILEB = cmk2::BR * ROWB + (yn_block ? 1024 : 0);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float yn_f = 0.f;
+    float yn_f = 0.f, lo_ratio = 0.f;
     if (i < n_pad) {
         const float sc = scale3[0];
         const int64_t tile = i / cmk2::BR;
@@ -213,6 +216,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
             slot[0] = 0x1p15f; slot[1] = 0x1p4f; slot[2] = 0x1p-7f;
         }
         const float mul = (is_ref ? -2.0f : 1.0f) * sc;
+        double lo2 = 0.0;   // squared norm of the lo parts (scaled units)
         for (int g = 0; g < GRAN / 2; ++g) {
             cmk2::half8 hi, lo;
 #pragma unroll
@@ -224,6 +228,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                         float v = (float)((double)x[c] * nscale - mean[c]) * mul;
                         h = (_Float16)v;
                         l = (_Float16)(v - (float)h);
+                        lo2 = fma((double)(float)l, (double)(float)l, lo2);
                     }
                 } else if (!yn_block && c < d + cmk2::NORM_SLOTS) {
                     h = (_Float16)slot[c - d];
@@ -241,13 +246,16 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
             if (r == 0) for (int e = cmk2::BR; e < 256; ++e) ynp[e] = 0.f;
         }
         if (rownorm && i < n) rownorm[i] = sqrtf(yn_f) * 1.0000002f;
+        if (rowlo && i < n) rowlo[i] = (float)(sqrt(lo2) / (double)sc) * 1.000001f;
+        if (is_ref && i < n && s2 > 0.0) lo_ratio = (float)(sqrt(lo2) / (2.0 * (double)sc * sqrt(s2))) * 1.000001f;
     }
     if (is_ref && gmax) {
-        float m = yn_f;
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float m = yn_f, lr = lo_ratio;
+        for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); lr = fmaxf(lr, __shfl_xor(lr, o)); }
         if ((threadIdx.x & 63) == 0) {
             atomicMax(&gmax[0], __float_as_uint(m * 1.0000002f));
             atomicMax(&gmax[1], __float_as_uint(sqrtf(m) * 1.0000002f));
+            atomicMax(&gmax[5], __float_as_uint(lr));
         }
     }
 }
@@ -324,7 +332,8 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int flags, void *__restrict__ out_dist,
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
                                                    int *__restrict__ flag_cnt, double *__restrict__ bound,
-                                                   const int *__restrict__ qmap, int pilot_kc) {
+                                                   const int *__restrict__ qmap, int pilot_kc,
+                                                   const float *__restrict__ qlo, int level) {
     // qmap != nullptr: the nq rows of cand / cthr / qnorm belong to the query SUBSET qmap[0..nq) (staged search);
     // the query row, the outputs, the bound and the flag entry use the original index io.
     // pilot_kc > 0 (pilot of the staged search): a small sample runs with many reference splits, whose union of
@@ -398,7 +407,15 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             if (qn + dk < ymax) ymax = qn + dk;
             const double ymax2 = ymax * ymax;
             // c_eps: accumulation / representation error on every term; c_split: split products that were dropped
-            double eps = (double)c_eps * (ymax2 + 2.0 * qn * ymax + 1e-30) + (double)c_split * 2.0 * qn * ymax;
+            double eps = (double)c_eps * (ymax2 + 2.0 * qn * ymax + 1e-30);
+            if (qlo) {
+                // dropped split products with the ACTUAL lo norms (Cauchy-Schwarz): level 1 drops lo(q).hi(y) and
+                // hi(q).lo(y), level 2 only the latter; |hi(.)| <= (1 + 2^-11)|.|; gmax[5] = max |lo(y')| / |y'|
+                const double rho_y = (double)__uint_as_float(gmax[5]);
+                eps += 2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qn * rho_y : 0.0));
+            } else {
+                eps += (double)c_split * 2.0 * qn * ymax;
+            }
             double tau_d = (double)tau;
             if (pilot_kc > 0) {
                 const double vkc = s_kc[w];
@@ -745,6 +762,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // subsets may use more reference splits than the full set: rows of the candidate buffers
     const int64_t cand_rows = std::max<int64_t>(nq_pad * pf.S, nq_pad + (int64_t)cmk2::QB * 512);
     float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
+    float *qlo = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);   // |lo part| of every prepared query row
     int *cand = (int *)cm_ws_alloc(h, sizeof(int) * cand_rows * Kc_max);
     float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * cand_rows);
     int *flag_a = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
@@ -762,7 +780,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
     double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
-    if (!qnorm || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
+    if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
         !Qp || !kept || !lbuf || !cpart || !d_mean)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     if (pf.grid > 320) CM_FAIL(h, CM_E_INTERNAL, "k-NN: unexpected resident workgroup count %d", pf.grid);
@@ -802,7 +820,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             else
                 hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                    p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words, 0,
-                                   want, (const int *)nullptr);
+                                   want, (const int *)nullptr, (float *)nullptr);
             img = want;
         }
         if (level == 4) {
@@ -811,7 +829,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         } else {
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
                                p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, 0, 0,
-                               qmap);
+                               qmap, qlo);
             p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
             p2.lds = cmk2::ring_depth(want == 1) * p2.tileb + 64;
         }
@@ -843,7 +861,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
                            p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
-                           idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc);
+                           idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
+                           level == 4 ? (const float *)nullptr : (const float *)qlo, level);
         CM_HIP(h, hipGetLastError());
         if (marks) cm_mark(h, 3);
         return CM_OK;
@@ -1006,14 +1025,14 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             img_hi_only = (path == 1 && levels[0] < 3) ? 1 : 0;
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
-                               path == 3, img_hi_only, (const int *)nullptr);
+                               path == 3, img_hi_only, (const int *)nullptr, (float *)nullptr);
             if (path == 1) {
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, img_hi_only != 0);
                 p2.lds = cmk2::ring_depth(img_hi_only != 0) * p2.tileb + 64;
             }
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
                                p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0,
-                               (const int *)nullptr);
+                               (const int *)nullptr, (float *)nullptr);
         }
         CM_HIP(h, hipGetLastError());
         cm_mark(h, 1);
@@ -1061,7 +1080,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                 if (hi_only != img_hi_only) {   // (re)build the reference tile image in the layout this level reads
                     hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref,
                                        d, p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr,
-                                       words, path == 3, hi_only, (const int *)nullptr);
+                                       words, path == 3, hi_only, (const int *)nullptr, (float *)nullptr);
                     img_hi_only = hi_only;
                     if (path == 1) {
                         p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, hi_only != 0);
@@ -1077,7 +1096,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             // not the last level: re-rank now and look at how many queries failed the certificate
             hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                                S, Kc, k, metric, form, qnorm, words, c_eps, c_split, scale3, (const double *)d_mean, idx_offset,
-                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0);
+                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0);
             cm_mark(h, 3);
             CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             CM_HIP(h, hipStreamSynchronize(st));
@@ -1119,7 +1138,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                            S, Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
-                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0);
+                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0);
     if (!reranked) cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
@@ -1153,7 +1172,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
-    size_t b = 256 * 1024 + cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
+    size_t b = 256 * 1024 + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
