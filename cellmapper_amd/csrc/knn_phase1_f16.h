@@ -430,7 +430,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int GRAN = row_bytes(KSTEPS) / 16;   // granules of a full row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
     constexpr int TILEB = img_tile_bytes(KSTEPS, !LO3);
     constexpr int RING = ring_depth(!LO3);
-    constexpr int AHEAD = LO3 ? 2 : RING - 1;   // the DMA of tile t + AHEAD is issued during tile t
+    constexpr int AHEAD = RING - 1;   // the DMA pieces of tile t + AHEAD are issued during tile t
     constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     uint2 *wsc = nullptr;
+    (void)wsc;
     uint2 *wkept = a.kept + (size_t(blockIdx.x) * NW + wave) * 64 * a.Kc;
     uint2 *wlbuf = a.lbuf + (size_t(blockIdx.x) * NW + wave) * 64 * 2 * CL;
     const unsigned ldsbase = (unsigned)(uintptr_t)(CM2_AS3 unsigned char *)ring;
@@ -499,9 +500,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         // of tile t+1, then the workgroup barrier makes tile t+1 complete for everyone and tells that everyone is done
         // with tile t-1.  Tile t itself was complete one barrier earlier, so the fragments of its first sub-tile are
         // requested BEFORE the barrier (end of tile t-1): the MFMA chain runs through the barrier without an
-        // LDS-latency bubble.  NP = 3 issues the DMA of tile t+2 at the top of tile t; NP < 3 spreads the pieces of
-        // tile t+AHEAD (buffer of tile t-1) over the sub-tiles of tile t, so the wait at a tile boundary is a counted
-        // vmcnt that leaves the pieces of the AHEAD-2 youngest tiles in flight.
+        // LDS-latency bubble.  The DMA pieces of tile t+AHEAD (buffer of tile t-1) are spread over the sub-tiles of
+        // tile t, so the wait at a tile boundary is a counted vmcnt that leaves the pieces of the AHEAD-2 youngest
+        // tiles in flight.
         __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
@@ -522,11 +523,6 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
             CM2_DSR128X(F[s], arow, 32 * s, TB, (ST) * 32 * ROWB);                                             \
     }
-#define CM2_LOAD_AL(F, TB, ST)                                                                                 \
-    {                                                                                                          \
-        _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s)                                                     \
-            CM2_DSR128X(F[s], arow, (GRAN / 2) * 16 + 32 * s, TB, (ST) * 32 * ROWB);                           \
-    }
         // granule (2s+hh) of the hi half sits at (2s+hh)^f = (hh^f) ^ 2s, the lo half at ... ^ GRAN/2 (f < GRAN, the
         // swizzle repeats every 32 rows): one row address per lane, fragment = address ^ constant
         const unsigned arow = c * ROWB + ((hh ^ swz_b(c, ROWB)) * 16);
@@ -540,20 +536,18 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             __builtin_amdgcn_s_barrier();
             const unsigned tile0 = ldsbase + (t0 % RING) * TILEB;
             CM2_LOAD_AH(ah, tile0, 0);
-            if (LO3) CM2_LOAD_AL(al, tile0, 0);
         }
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0) {   // (the first tile synchronised above)
                 // own pieces of tile t+1 have landed; NP < 3: those of younger tiles may be in
                 // flight -- loads complete in order, stores in between only make the wait more conservative
-                if (!LO3 && t + AHEAD - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
+                if (t + AHEAD - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (conservative in the tail of a work item)
                 if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
                 if (!(CM2_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
             }
-            if (LO3 && t + 2 < t1) CM2_DMA_TILE(t + 2, (t + 2) % RING);   // NP < 3: one piece per sub-tile, below
             const unsigned tile = ldsbase + (t % RING) * TILEB;
             const unsigned tile_n = ldsbase + ((t + 1) % RING) * TILEB;
             const bool more = t + 1 < t1;   // uniform: prefetch the next tile's first fragments at the last sub-tile
@@ -570,74 +564,57 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 float mm[16];
                 if (CM2_EXP & 8) { _Pragma("unroll") for (int e = 0; e < 16; ++e) mm[e] = p0[e]; }
                 (void)pre;
-                if constexpr (LO3) {
-                    wait_lds<KSTEPS>(ah);   // the lo fragments of this sub-tile may still be in flight
-#pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[0][s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], qh[1][s], acc1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[0][s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], ql[1][s], acc1, 0, 0, 0);
-                    }
-                    // the hi fragment is dead: fetch the next sub-tile's while the lo products run
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pre) {
-                        CM2_LOAD_AH(ah, ntile, nst);
-                        wait_lds<KSTEPS>(al);
-                    } else {
-                        wait_lds<0>(al);
-                    }
-#pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pre) CM2_LOAD_AL(al, ntile, nst);
-                } else {
-                    // Hand-placed stream: after every MFMA of the hi*hi chain one gap's worth of the other work of this
-                    // sub-tile -- a fragment read for the next sub-tile, two or four steps of the PREVIOUS sub-tile's
-                    // min trees, one DMA piece of tile t+AHEAD -- so that a wave paces the matrix pipe on its own and the
-                    // two waves of a SIMD mesh MFMA by MFMA, whatever their relative phase.
-                    half8(&cur)[KSTEPS] = (st & 1) ? al : ah;
-                    half8(&nxt)[KSTEPS] = (st & 1) ? ah : al;
-                    constexpr int NM = 2 * KSTEPS, PER = 16 / NM;
+                // Hand-placed stream: after every MFMA of the chain one gap's worth of the other work of this sub-tile --
+                // a fragment read, one or more steps of the PREVIOUS sub-tile's min trees, one DMA piece of tile
+                // t+AHEAD -- so that a wave paces the matrix pipe on its own and the two waves of a SIMD mesh MFMA by
+                // MFMA, whatever their relative phase.  Chain order: hi*hi, hi(ref)*lo(query), lo(ref)*hi(query).
+                //   NP < 3: the hi fragments are double-buffered (ah / al registers): those of the next sub-tile are read
+                //           in the first KSTEPS gaps.
+                //   NP = 3: the lo fragments of THIS sub-tile are read in the first KSTEPS gaps (they are needed from MFMA
+                //           4*KSTEPS on), the hi fragments of the NEXT sub-tile in the gaps after the last MFMA that reads
+                //           the current ones.
+                // (At the last sub-tile of the last tile the next-sub-tile reads hit a stale buffer; never used.)
+                {
+                    constexpr int NM1 = 2 * KSTEPS;            // MFMAs per split product
+                    constexpr int NMT = NM1 * NP;              // MFMAs of the whole chain
+                    constexpr int PER = (16 + (NMT < 16 ? NMT : 16) - 1) / (NMT < 16 ? NMT : 16);   // min-tree steps per gap
+                    half8(&cur)[KSTEPS] = (!LO3 && (st & 1)) ? al : ah;
+                    half8(&nxt)[KSTEPS] = (!LO3 && (st & 1)) ? ah : al;
                     wait_lds<0>(cur);
 #pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        const int s = i >> 1;
-                        if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[1][s], acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
+                    for (int i = 0; i < NMT; ++i) {
+                        const int pr = i / NM1, s = (i % NM1) >> 1, jq = i & 1;
+                        if (LO3 && i == 2 * NM1) wait_lds<0>(al);
+                        if (pr == 2) {
+                            if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
+                        } else if (pr == 1) {
+                            if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s], acc0, 0, 0, 0);
+                        } else {
+                            if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[1][s], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
-                        // (at the last sub-tile of the last tile this reads a stale buffer; the result is never used)
-                        if (i < KSTEPS && !(CM2_EXP & 4)) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+                        if (!(CM2_EXP & 4)) {
+                            if (LO3) {
+                                if (i < KSTEPS) CM2_DSR128X(al[i], arow, (GRAN / 2) * 16 + 32 * i, tile, st * 32 * ROWB);
+                                if (i >= 2 * NM1 && i < 2 * NM1 + KSTEPS)
+                                    CM2_DSR128X(ah[i - 2 * NM1], arow, 32 * (i - 2 * NM1), ntile, nst * 32 * ROWB);
+                            } else {
+                                if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+                            }
+                        }
 #pragma unroll
                         for (int jj = 0; jj < PER; ++jj)
-                            if (!(CM2_EXP & 8) || i * PER + jj >= 14) min_step(i * PER + jj, p0, p1, mm);
-                        if (i == NM - 1 && st < NPIECE && !(CM2_EXP & 1)) {
+                            if (i * PER + jj < 16 && (!(CM2_EXP & 8) || i * PER + jj >= 14)) min_step(i * PER + jj, p0, p1, mm);
+                        if (i == NMT - 1 && st < NPIECE && !(CM2_EXP & 1)) {
                             if (t + AHEAD < t1) CM2_DMA_PIECE(t + AHEAD, (t + AHEAD) % RING, st);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (NP == 2) {
-#pragma unroll
-                        for (int s = 0; s < KSTEPS; ++s) {
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s], acc1, 0, 0, 0);
-                        }
-                    }
                 }
-                float mp0, mp1;
-                if constexpr (LO3) {   // min-trees of the PREVIOUS sub-tile, issued in the shadow of the chain above
-                    CM2_MIN16(p0, mp0);
-                    CM2_MIN16(p1, mp1);
-                } else {
-                    mp0 = mm[14];
-                    mp1 = mm[15];
-                }
+                float mp0 = mm[14], mp1 = mm[15];
                 if (!(a.dbg & 2)) CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
                 p0 = acc0;
                 p1 = acc1;
@@ -653,7 +630,6 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         }
         if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
 #undef CM2_LOAD_AH
-#undef CM2_LOAD_AL
 
         CM2_FINAL();
     }
