@@ -21,16 +21,25 @@ def short(name):
     return name
 
 
-def counters(path, kernel_sub):
-    """sum of each counter over the dispatches of kernels whose name contains kernel_sub -> {counter: value}, n_dispatch"""
-    out, disp = {}, set()
+def counters(path, kernel_sub, largest_only=False):
+    """sum of each counter over the dispatches of kernels whose name contains kernel_sub -> {counter: value}, n_dispatch.
+    largest_only: keep the dispatch with the largest value only (the main launch; the staged search's pilot launches the
+    same kernel on a 2 048-query sample first) and report n_dispatch = 1."""
+    per = {}
     with open(path) as f:
         for r in csv.DictReader(f):
             if kernel_sub not in r["Kernel_Name"]:
                 continue
-            disp.add(r["Dispatch_Id"])
-            out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    return out, len(disp)
+            d = per.setdefault(r["Dispatch_Id"], {})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    if largest_only and per:
+        best = max(per.values(), key=lambda d: sum(d.values()))
+        return dict(best), 1
+    out = {}
+    for d in per.values():
+        for k, v in d.items():
+            out[k] = out.get(k, 0.0) + v
+    return out, len(per)
 
 
 def kernel_ms(trace_csv, kernel_sub):
@@ -75,8 +84,8 @@ def main():
     # ---- PMC passes
     mf, n1 = counters(one(os.path.join(a.src, "pmc_mfma", "**", "*counter_collection.csv")), a.kernel)
     ld, n2 = counters(one(os.path.join(a.src, "pmc_lds", "**", "*counter_collection.csv")), a.kernel)
-    fk, n3 = counters(one(os.path.join(a.src, "pmc_fetch_knn", "**", "*counter_collection.csv")), a.kernel)
-    wk, n4 = counters(one(os.path.join(a.src, "pmc_write_knn", "**", "*counter_collection.csv")), a.kernel)
+    fk, n3 = counters(one(os.path.join(a.src, "pmc_fetch_knn", "**", "*counter_collection.csv")), a.kernel, True)
+    wk, n4 = counters(one(os.path.join(a.src, "pmc_write_knn", "**", "*counter_collection.csv")), a.kernel, True)
     kms = kernel_ms(one(os.path.join(a.src, "pmc_mfma", "**", "*kernel_trace.csv")), a.kernel)
     t_ms = sum(kms)
     gui = mf["GRBM_GUI_ACTIVE"] / 8.0
@@ -89,7 +98,8 @@ def main():
     with open(os.path.join(P, f"{a.tag}_pmc_counters.md"), "w") as f:
         f.write("# rocprofv3 --pmc passes (round 1, final kernels), counters in separate passes\n\n")
         f.write(f"## {a.kernel} (phase 1 of the k-NN, config 2: 1.5 M x 1.5 M x d=50; `bench.py --steps 1 --warmup 0`: "
-                f"{n1} launch(es) of the kernel in the pass, summed)\n\n")
+                f"{n1} launch(es) of the kernel in the pass -- the pilot on a 2 048-query sample and the main launch -- summed; "
+                "FETCH/WRITE: main launch only)\n\n")
         f.write(f"Pass `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` (kernel time in this run "
                 f"{t_ms:.1f} ms):\n\n")
         for k in sorted(mf):
@@ -106,8 +116,8 @@ def main():
         f.write(f"HBM-side traffic (separate passes, per launch): FETCH_SIZE = {fetch_kb:.6g} KB, WRITE_SIZE = {write_kb:.6g} KB. "
                 f"With the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports half of a wide coalesced stream: x2) => "
                 f"reads ~{reads/1e9:.0f} GB, writes {writes/1e9:.1f} GB per launch. Algorithmic bytes of the launch are 0.8 GB "
-                "(prepared rows once + candidate lists); the rest are re-reads of the 384 MB reference image by the query blocks "
-                "(each block streams every tile; about half are served by the XCD's L2) and the append logs. The kernel is "
+                "(prepared rows once + candidate lists); the rest are re-reads of the 192 MB hi-only reference image by the query blocks "
+                "(each block streams every tile; most are served by L2 / Infinity Cache) and the append logs. The kernel is "
                 "MFMA-issue-bound, not HBM-bound.\n\n")
         if sf:
             f.write("## spmm_wide<float,4> (A2: mapping matrix x dense payload; nq=200 000, n_ref=400 000, G=20 000, k=30; "
