@@ -39,7 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CM2_NW 8
 #endif
 #ifndef CM2_EXP
-#define CM2_EXP 0  // timing experiments only (scripts/exp14.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
+#define CM2_EXP 0  // timing experiments only (scripts/ablate_skeleton.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
 #endif
 constexpr int BR = CM2_BR;  // reference rows per LDS tile
 constexpr int NW = CM2_NW;  // waves per workgroup: one 8-wave workgroup per CU (512 queries share every tile fill;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# skeleton (no appends) timing of the level-1 kernel with parts of the hot loop compiled out (CM2_EXP variants in ab/)
+# skeleton (no appends) timing of the level-1 kernel with parts of the hot loop compiled out (variants: scripts/build_ablation_variants.sh)
 for x in 0 1 2 4 8 15 0; do
 CELLMAP_HIP_LIB=$GRAFT_REPO_ROOT/ab/libexp_$x.so CELLMAP_FILTER_PRODUCTS=1 CELLMAP_DBG=5 timeout -k 10 100 python scripts/bench_knn.py --nq 750000 --nref 1500000 --d 50 --k 30 --uniform 0 --reps 2 2>&1 | grep -E "cellmap dbg|stage_ms" | tail -2 | python -c "
 import sys,json,re
