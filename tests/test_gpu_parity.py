@@ -260,6 +260,25 @@ def test_staged_search_float64_and_cosine_clusters(hip, oracle):
     assert all(set(ex[i]) == set(idx[i]) for i in range(200))
 
 
+def test_staged_search_stale_level_hint_is_harmless(hip, oracle):
+    """The handle remembers that the hi*hi level certified (almost) everything on the previous call and then skips the
+    pilot.  A following call on data where that level fails must still be exact (it only wastes the first pass), and a
+    third call must have dropped the hint."""
+    rng = np.random.default_rng(31)
+    d, k = 50, 10
+    easy_r = rng.standard_normal((20000, d)).astype(np.float32)
+    easy_q = rng.standard_normal((32768, d)).astype(np.float32)
+    hip.knn(easy_r, easy_q, k)                      # sets the hint (level 1 works on standard-normal rows)
+    cen = rng.standard_normal((10, d)) * 6.0
+    hard_r = (cen[rng.integers(0, 10, 15000)] + 0.05 * rng.standard_normal((15000, d))).astype(np.float32)
+    hard_q = (cen[rng.integers(0, 10, 32768)] + 0.05 * rng.standard_normal((32768, d))).astype(np.float32)
+    od, oi = oracle.knn_euclidean(hard_r, hard_q, k)
+    for _ in range(2):                               # first call: stale hint; second: pilot again
+        dist, idx = hip.knn(hard_r, hard_q, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), hip.knn_stats()
+    assert hip.knn_stats()["filter_products"] >= 3
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
