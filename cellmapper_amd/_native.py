@@ -37,6 +37,7 @@ EXPORTS = [
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
+    "cm_ingest_distances",
 ]
 
 
@@ -224,6 +225,21 @@ class Handle:
         self.call("cm_shared_neighbors", _ptr(yx), _ptr(xx), _ptr(yy), _ptr(xy), nq, nr, k, tid, _ptr(indptr), _ptr(cols),
                   _ptr(vals), nnz.value, C.byref(nnz))
         return indptr, cols, vals
+
+    def ingest_distances(self, indptr, indices, data, n: int, include_self):
+        """Square CSR distance matrix -> padded (indices int64, distances float64) [n, kmax] (utils.py:129-219)."""
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        indices = np.ascontiguousarray(indices, np.int32)
+        data = np.ascontiguousarray(data, np.float64)
+        mode = -1 if include_self is None else (1 if include_self else 0)
+        km = C.c_int32(0)
+        self.call("cm_ingest_distances", _ptr(indptr), _ptr(indices), _ptr(data), int(n), mode, 0, None, None, C.byref(km))
+        idx = np.empty((int(n), km.value), np.int64)
+        dist = np.empty((int(n), km.value), np.float64)
+        if idx.size:
+            self.call("cm_ingest_distances", _ptr(indptr), _ptr(indices), _ptr(data), int(n), mode, km.value, _ptr(idx),
+                      _ptr(dist), C.byref(km))
+        return idx, dist
 
     def presence_scores(self, dist, idx, n_ref: int, group=None, n_groups: int = 0):
         """Raw presence scores [n_ref, n_groups + 1] (column 0: all query cells)."""

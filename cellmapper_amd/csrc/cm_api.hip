@@ -483,6 +483,35 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
 
 }  // extern "C"
 
+// ---------------------------------------------------------------- precomputed-distance ingest ----------
+cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_t *indices, const double *data, int64_t n,
+                              int32_t include_self, int32_t kmax, int64_t *out_idx, double *out_dist, int32_t *out_kmax) {
+    if (!h) return CM_E_INVALID;
+    if (n < 0 || include_self < -1 || include_self > 1 || !indptr || !out_kmax) CM_FAIL(h, CM_E_INVALID, "precomputed distances: bad arguments");
+    CM_TRY(begin_call(h, 0));
+    const int64_t nnz = n > 0 ? indptr[n] : 0;
+    DevBuf dp, dc, dv, dl, dk, oi, od;
+    CM_TRY(dp.alloc(h, 8 * ((size_t)n + 1))); CM_TRY(dc.alloc(h, 4 * (size_t)nnz)); CM_TRY(dl.alloc(h, 4 * (size_t)n)); CM_TRY(dk.alloc(h, 16));
+    CM_TRY(h2d(h, dp.p, indptr, 8 * ((size_t)n + 1)));
+    CM_TRY(h2d(h, dc.p, indices, 4 * (size_t)nnz));
+    CM_HIP(h, hipMemsetAsync(dk.p, 0, 16, h->stream));
+    CM_TRY(cm_ingest_count_run(h, dp.as<int64_t>(), dc.as<int32_t>(), n, include_self, dl.as<int>(), dk.as<int>()));
+    int km = 0;
+    CM_TRY(d2h(h, &km, dk.p, 4));
+    CM_TRY(sync(h));
+    *out_kmax = km;
+    if (!out_idx || !out_dist) return CM_OK;          // first call: size query
+    if (kmax != km) CM_FAIL(h, CM_E_INVALID, "precomputed distances: output buffers sized for %d columns, need %d", kmax, km);
+    if (n == 0 || km == 0) return CM_OK;
+    CM_TRY(dv.alloc(h, 8 * (size_t)nnz)); CM_TRY(oi.alloc(h, 8 * (size_t)n * km)); CM_TRY(od.alloc(h, 8 * (size_t)n * km));
+    CM_TRY(h2d(h, dv.p, data, 8 * (size_t)nnz));
+    CM_TRY(cm_ingest_fill_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<double>(), n, include_self, km, oi.as<int64_t>(),
+                              od.as<double>()));
+    CM_TRY(d2h(h, out_idx, oi.p, 8 * (size_t)n * km));
+    CM_TRY(d2h(h, out_dist, od.p, 8 * (size_t)n * km));
+    return sync(h);
+}
+
 // ---------------------------------------------------------------- diagnostics --------------------------
 // Raw v_mfma_f32_32x32x16_f16 problems, one wave each: D = A(32x16) * B(16x32) + C(32x32).  Used by the tests to pin
 // the instruction's accumulation arithmetic (the rounding model behind the phase-1 certificate).

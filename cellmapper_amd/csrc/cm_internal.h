@@ -75,6 +75,10 @@ cm_status cm_ell_to_csr_run(cm_handle_t h, const int32_t *d_cols, const float *d
                             const int32_t *d_cnt, int64_t nq, int32_t k, int64_t *d_indptr, int32_t *d_out_cols,
                             float *d_out_vals, double *d_out_conn);
 size_t cm_scan_ws_bytes(int64_t n);
+cm_status cm_ingest_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, int64_t n, int include_self,
+                              int *d_rowlen, int *d_kmax);
+cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
+                             int include_self, int kmax, int64_t *d_out_idx, double *d_out_dist);
 cm_status cm_presence_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
                           const double *d_param, const int32_t *d_group, int32_t n_groups, double *d_out);
 cm_status cm_csr_normalize_run(cm_handle_t h, const int64_t *d_indptr, const double *d_data, int64_t nq, float *d_out);

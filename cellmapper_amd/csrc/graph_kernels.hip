@@ -562,3 +562,109 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
                                int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
     return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, d_out_cols, d_out_vals);
 }
+
+// ------------------------------------------------------------------ T1: precomputed-distance ingest --
+// Square CSR distance matrix (adata.obsp['distances']) -> padded (indices, distances) rows with -1 / inf padding
+// (reference utils.py:129-219: two Python loops over all cells).  include_self: -1 keep as stored, 0 drop the
+// diagonal entry, 1 append (self, 0.0) when the row has no diagonal entry.  A row whose distances are already
+// non-decreasing keeps its stored order; otherwise it is sorted by distance (ties: stored position -- the reference's
+// np.argsort leaves tie order unspecified).
+namespace {
+constexpr int IG_MAX = 1024;   // longest row (+1) the in-LDS sort handles
+
+__global__ void ingest_count(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n,
+                             int include_self, int *__restrict__ rowlen, int *__restrict__ kmax) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int len = 0;
+    if (i < n) {
+        const int64_t lo = indptr[i], hi = indptr[i + 1];
+        len = (int)(hi - lo);
+        if (include_self >= 0) {
+            bool has = false;
+            for (int64_t p = lo; p < hi; ++p) has = has || indices[p] == (int32_t)i;
+            if (include_self == 1 && !has) ++len;
+            if (include_self == 0 && has) {   // every diagonal entry is dropped (duplicates are not canonical CSR, but legal)
+                int c = 0;
+                for (int64_t p = lo; p < hi; ++p) c += indices[p] == (int32_t)i;
+                len -= c;
+            }
+        }
+        rowlen[i] = len;
+    }
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(kmax, len);
+}
+
+__global__ __launch_bounds__(256) void ingest_fill(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                   const double *__restrict__ data, int64_t n, int include_self, int kmax,
+                                                   int64_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+    __shared__ double s_d[4][IG_MAX];
+    __shared__ int s_c[4][IG_MAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n) return;
+    const int64_t lo = indptr[i], hi = indptr[i + 1];
+    // gather (stable compaction of the kept entries, wave-wide)
+    int m = 0;
+    for (int64_t base = lo; base < hi; base += 64) {
+        const int64_t p = base + lane;
+        const bool in = p < hi;
+        const int c = in ? indices[p] : 0;
+        const bool keep = in && !(include_self == 0 && c == (int32_t)i);
+        const unsigned long long b = __ballot(keep);
+        if (keep) {
+            const int pos = m + __popcll(b & ((1ull << lane) - 1ull));
+            s_d[w][pos] = data[p];
+            s_c[w][pos] = c;
+        }
+        m += __popcll(b);
+    }
+    if (include_self == 1) {
+        bool has = false;
+        for (int s = lane; s < m; s += 64) has = has || s_c[w][s] == (int32_t)i;
+        if (__ballot(has) == 0ull) {
+            if (lane == 0) { s_d[w][m] = 0.0; s_c[w][m] = (int)i; }
+            ++m;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // already non-decreasing?  (np.all(np.diff(d) >= 0): a NaN difference counts as unsorted)
+    bool bad = false;
+    for (int s = lane; s + 1 < m; s += 64) bad = bad || !(s_d[w][s + 1] - s_d[w][s] >= 0.0);
+    const bool sorted = __ballot(bad) == 0ull;
+    int64_t *oi = out_idx + i * (int64_t)kmax;
+    double *od = out_dist + i * (int64_t)kmax;
+    for (int s = lane; s < m; s += 64) {
+        const double v = s_d[w][s];
+        int rk = s;
+        if (!sorted) {
+            rk = 0;
+            for (int j = 0; j < m; ++j) {
+                const double u = s_d[w][j];
+                rk += (u < v || (u == v && j < s)) ? 1 : 0;
+            }
+        }
+        oi[rk] = s_c[w][s];
+        od[rk] = v;
+    }
+    for (int s = m + lane; s < kmax; s += 64) { oi[s] = -1; od[s] = INFINITY; }
+}
+}  // namespace
+
+cm_status cm_ingest_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, int64_t n, int include_self,
+                              int *d_rowlen, int *d_kmax) {
+    if (n > 0) hipLaunchKernelGGL(ingest_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_indptr, d_indices,
+                                  n, include_self, d_rowlen, d_kmax);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
+                             int include_self, int kmax, int64_t *d_out_idx, double *d_out_dist) {
+    if (kmax + 1 > IG_MAX) CM_FAIL(h, CM_E_UNSUPPORTED, "precomputed distances: a row has %d entries (maximum %d)", kmax, IG_MAX - 1);
+    if (n > 0 && kmax > 0)
+        hipLaunchKernelGGL(ingest_fill, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_indices, d_data, n,
+                           include_self, kmax, d_out_idx, d_out_dist);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}

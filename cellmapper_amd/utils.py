@@ -53,48 +53,14 @@ def extract_neighbors_from_distances(distances_matrix, include_self: bool | None
     """Square sparse distance matrix (``adata.obsp['distances']``) -> padded ``(indices, distances)`` arrays
     with ``-1`` / ``inf`` padding, rows sorted by distance (contract of reference utils.py:129-219).
 
-    Vectorised over the CSR arrays instead of looping over cells in Python.
+    Runs on the GPU (``cm_ingest_distances``: one wave per row, in-LDS stable rank sort for rows that are not already
+    sorted) instead of two Python loops over all cells; the argument checks mirror the reference's.
     """
     if not issparse(distances_matrix):
         raise TypeError("Distances matrix must be a sparse matrix")
     if distances_matrix.shape[0] != distances_matrix.shape[1]:
         raise ValueError(f"Square distance matrix required (got {distances_matrix.shape})")
     m = csr_matrix(distances_matrix)
-    n = m.shape[0]
-    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(m.indptr))
-    cols = m.indices.astype(np.int64)
-    vals = m.data.astype(np.float64)
-    order0 = np.arange(len(rows))
-    is_self = rows == cols
-    if include_self is False:
-        keep = ~is_self
-        rows, cols, vals, order0 = rows[keep], cols[keep], vals[keep], order0[keep]
-    elif include_self is True:
-        has_self = np.zeros(n, bool)
-        has_self[rows[is_self]] = True
-        add = np.nonzero(~has_self)[0]
-        rows = np.concatenate([rows, add])
-        cols = np.concatenate([cols, add])
-        vals = np.concatenate([vals, np.zeros(len(add))])
-        order0 = np.concatenate([order0, np.full(len(add), np.iinfo(np.int64).max)])  # appended last, as upstream
-    counts = np.bincount(rows, minlength=n)
-    kmax = int(counts.max()) if len(counts) and len(rows) else 0
-    indices = np.full((n, kmax), -1, dtype=np.int64)
-    distances = np.full((n, kmax), np.inf, dtype=np.float64)
-    if len(rows):
-        # rows already non-decreasing in stored order keep that order; otherwise a stable sort by distance
-        order = np.lexsort((order0, rows))
-        rows, cols, vals = rows[order], cols[order], vals[order]
-        start = np.concatenate([[0], np.cumsum(counts)[:-1]])
-        pos = np.arange(len(rows)) - start[rows]
-        unsorted_rows = np.zeros(n, bool)
-        bad = (np.diff(vals) < 0) & (np.diff(rows) == 0)
-        unsorted_rows[rows[1:][bad]] = True
-        if unsorted_rows.any():
-            sel = unsorted_rows[rows]
-            sub = np.nonzero(sel)[0]
-            o2 = np.lexsort((vals[sub], rows[sub]))  # argsort by distance within the row
-            cols[sub], vals[sub] = cols[sub][o2], vals[sub][o2]
-        indices[rows, pos] = cols
-        distances[rows, pos] = vals
-    return indices, distances
+    from . import _native
+
+    return _native.default_handle().ingest_distances(m.indptr, m.indices, m.data, m.shape[0], include_self)

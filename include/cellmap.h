@@ -203,6 +203,18 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
                             const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code, float *d_out_conf,
                             double *d_out_dist, int64_t *d_out_idx);
 
+/* ------------------------------------------------- precomputed-distance ingest ----
+ * Replaces extract_neighbors_from_distances (utils.py:129-219; called from knn.py:296-337 via
+ * CellMapper.load_precomputed_distances, cellmapper.py:493-532): square CSR distance matrix [n, n] (int64 indptr,
+ * int32 column indices, float64 data) -> padded rows int64 indices / float64 distances [n, kmax] with -1 / inf padding.
+ * include_self: -1 = None (keep rows as stored), 0 = False (drop diagonal entries), 1 = True (append (i, 0.0) to rows
+ * without a diagonal entry).  Rows whose distances are non-decreasing keep their stored order, others are sorted by
+ * distance (ties by stored position).  Call once with out_idx = out_dist = NULL to obtain *out_kmax (the longest row
+ * after the include_self rule), then with buffers of kmax = *out_kmax columns.  Rows longer than 1023 entries:
+ * CM_E_UNSUPPORTED. */
+cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_t *indices, const double *data, int64_t n,
+                              int32_t include_self, int32_t kmax, int64_t *out_idx, double *out_dist, int32_t *out_kmax);
+
 /* ---------------------------------------------------------------- diagnostics -----------------------
  * n independent products D = A*B + C on one v_mfma_f32_32x32x16_f16 chain each (chain k-steps of 16): a fp16 bits
  * [n, chain, 32, 16] row-major, b fp16 bits [n, chain, 16, 32], c / d float32 [n, 32, 32].  Test aid: pins the

@@ -296,3 +296,46 @@ def test_sharded_driver_device_ops_match_fused_pipeline(kernel):
     assert (lo, hi) == (0, nq)
     assert torch.equal(i1, i0) and torch.equal(d1, d0) and torch.equal(im, i0) and torch.equal(dm, d0)
     assert torch.equal(code1, code0) and torch.equal(conf1, conf0)
+
+
+@pytest.mark.parametrize("inc,tag", [(None, "none"), (True, "true"), (False, "false")])
+def test_precomputed_distance_ingest_matches_reference(inc, tag):
+    """cm_ingest_distances (through cellmapper_amd.utils) vs the reference's padded arrays (utils.py:129-219)."""
+    from cellmapper_amd.utils import extract_neighbors_from_distances
+
+    g = load_golden("padded_graph")
+    idx, dist = extract_neighbors_from_distances(golden_csr(g, "dm"), include_self=inc)
+    assert idx.dtype == np.int64 and dist.dtype == np.float64
+    assert np.array_equal(dist, g[f"dist_{tag}"])
+    assert np.array_equal(idx, g[f"idx_{tag}"])
+
+
+def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
+    """Ragged rows, unsorted rows with ties, empty rows, explicit diagonal entries, a long row: GPU == oracle."""
+    from cellmapper_amd.utils import extract_neighbors_from_distances
+
+    rng = np.random.default_rng(41)
+    n = 3000
+    lens = rng.integers(0, 40, n)
+    lens[7] = 900                                   # a long row (limit: 1023 entries)
+    lens[11] = 0
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([rng.choice(n, l, replace=False) for l in lens]) if lens.sum() else np.zeros(0, int)
+    vals = np.round(rng.random(len(rows)) * 8) / 4  # many ties
+    sel = rng.random(n) < 0.5                       # half of the rows stored sorted by distance
+    m = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    m.sort_indices()
+    for i in np.nonzero(sel)[0]:
+        lo, hi = m.indptr[i], m.indptr[i + 1]
+        o = np.argsort(m.data[lo:hi], kind="stable")
+        m.data[lo:hi], m.indices[lo:hi] = m.data[lo:hi][o], m.indices[lo:hi][o]
+    m.has_sorted_indices = False
+    for inc in (None, True, False):
+        gi, gd = extract_neighbors_from_distances(m, include_self=inc)
+        oi, od = oracle.extract_neighbors_from_distances(m, include_self=inc)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), inc
+    gi, gd = extract_neighbors_from_distances(sp.csr_matrix((4, 4)))
+    assert gi.shape == (4, 0) and gd.shape == (4, 0)
+    big = sp.csr_matrix((np.ones(1500), (np.zeros(1500, int), np.arange(1500))), shape=(1500, 1500))
+    with pytest.raises(NotImplementedError):
+        extract_neighbors_from_distances(big)

@@ -113,3 +113,24 @@ def test_oracle_errors(oracle):
         oracle.kernel_weights(np.full((2, 2), np.inf), np.full((2, 2), -1), "gaussian")
     with pytest.raises(ValueError):
         oracle.knn_euclidean(np.zeros((3, 20), np.float32), np.zeros((2, 20), np.float32), 4)
+
+
+@pytest.mark.parametrize("inc,tag", [(None, "none"), (True, "true"), (False, "false")])
+def test_oracle_precomputed_distance_ingest_matches_reference(oracle, inc, tag):
+    """oracle.extract_neighbors_from_distances vs the padded arrays the reference produced (utils.py:129-219)."""
+    g = load_golden("padded_graph")
+    idx, dist = oracle.extract_neighbors_from_distances(golden_csr(g, "dm"), include_self=inc)
+    assert idx.dtype == np.int64 and dist.dtype == np.float64
+    assert np.array_equal(dist, g[f"dist_{tag}"])
+    assert np.array_equal(idx, g[f"idx_{tag}"])
+
+
+def test_oracle_precomputed_distance_ingest_edge_cases(oracle):
+    import scipy.sparse as sp
+
+    idx, dist = oracle.extract_neighbors_from_distances(sp.csr_matrix((4, 4)))
+    assert idx.shape == (4, 0) and dist.shape == (4, 0)
+    m = sp.csr_matrix(np.array([[0, 2.0, 1.0], [np.inf, 0, 0], [0, 0, 0]]))
+    idx, dist = oracle.extract_neighbors_from_distances(m, include_self=True)
+    assert idx[0].tolist() == [0, 2, 1] and dist[0].tolist() == [0.0, 1.0, 2.0]
+    assert np.isinf(dist[1]).sum() >= 1
