@@ -37,7 +37,7 @@ EXPORTS = [
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
-    "cm_ingest_distances",
+    "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
 ]
 
 
@@ -240,6 +240,20 @@ class Handle:
             self.call("cm_ingest_distances", _ptr(indptr), _ptr(indices), _ptr(data), int(n), mode, km.value, _ptr(idx),
                       _ptr(dist), C.byref(km))
         return idx, dist
+
+    def expression_metrics(self, orig, imputed, method: str, group=None, n_groups: int = 0):
+        """Per-gene agreement [n_groups + 1, G] float32 (row 0: all cells) -- evaluate.py:236-323."""
+        mid = {"pearson": 0, "rmse": 1, "js": 2, "jensen-shannon": 2}[method]
+        orig = np.ascontiguousarray(orig, np.float32)
+        imputed = np.ascontiguousarray(imputed, np.float32)
+        if orig.shape != imputed.shape or orig.ndim != 2:
+            raise ValueError(f"Expression arrays must share a 2-D shape (got {orig.shape} and {imputed.shape}).")
+        grp = None if group is None else np.ascontiguousarray(group, np.int32)
+        ng = int(n_groups) if grp is not None else 0
+        out = np.empty((ng + 1, orig.shape[1]), np.float32)
+        self.call("cm_expression_metrics", _ptr(orig), _ptr(imputed), orig.shape[0], orig.shape[1], _ptr(grp), ng, mid,
+                  _ptr(out))
+        return out
 
     def presence_scores(self, dist, idx, n_ref: int, group=None, n_groups: int = 0):
         """Raw presence scores [n_ref, n_groups + 1] (column 0: all query cells)."""

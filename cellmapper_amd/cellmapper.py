@@ -16,7 +16,7 @@ import pandas as pd
 from scipy.sparse import csr_matrix, issparse
 
 from . import _native
-from .evaluate import PresenceMixin
+from .evaluate import ExpressionEvaluationMixin, PresenceMixin
 from .knn import Neighbors
 from .logging import logger
 from .utils import create_imputed_anndata, get_n_comps
@@ -24,7 +24,7 @@ from .utils import create_imputed_anndata, get_n_comps
 _KERNEL_METHODS = ("gaussian", "scarches", "inverse_distance", "random", "equal")
 
 
-class CellMapper(PresenceMixin):
+class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
     """Mapping of labels, embeddings, and expression values between reference and query datasets."""
 
     def __init__(self, query, reference=None) -> None:

@@ -668,3 +668,132 @@ cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
+
+// ------------------------------------------------------------------ E1: expression-transfer evaluation --
+// Per-gene agreement between measured and imputed expression (reference evaluate.py:236-323 loops over genes in
+// Python calling scipy per gene): Pearson r, RMSE of the z-scored vectors, Jensen-Shannon distance (base 10), over
+// all cells or over the cells of one group.  Inputs are row-major float32 [n, G]; a thread owns one gene (coalesced
+// row reads), a workgroup a chunk of rows; per-chunk float64 partial sums are combined in chunk order (deterministic).
+// Two passes: sums (means, clipped sums), then CENTRED second moments -- a constant column gets variance exactly 0,
+// as scipy's centred arithmetic does -- and the Jensen-Shannon terms.
+namespace {
+constexpr int EX_N1 = 5;   // pass 1: n, sum a, sum b, sum max(a,0), sum max(b,0)
+constexpr int EX_N2 = 4;   // pass 2: sum (a-ma)^2, sum (b-mb)^2, sum (a-ma)(b-mb), JS terms
+
+__global__ __launch_bounds__(256) void expr_pass1(const float *__restrict__ A, const float *__restrict__ B, int64_t n,
+                                                  int64_t G, const int32_t *__restrict__ group, int sel,
+                                                  int64_t rows_per_chunk, double *__restrict__ part) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
+    if (g >= G) return;
+    double s[EX_N1] = {0, 0, 0, 0, 0};
+    for (int64_t r = r0; r < r1; ++r) {
+        if (sel >= 0 && group[r] != sel) continue;
+        const double a = (double)A[r * G + g], b = (double)B[r * G + g];
+        s[0] += 1.0; s[1] += a; s[2] += b;
+        s[3] += a > 0.0 ? a : 0.0; s[4] += b > 0.0 ? b : 0.0;
+    }
+    double *o = part + ((int64_t)blockIdx.y * G + g) * EX_N1;
+#pragma unroll
+    for (int e = 0; e < EX_N1; ++e) o[e] = s[e];
+}
+
+template <int NS>
+__global__ void expr_combine(const double *__restrict__ part, int64_t G, int chunks, double *__restrict__ tot) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double s[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) s[e] = 0.0;
+    for (int c = 0; c < chunks; ++c)
+#pragma unroll
+        for (int e = 0; e < NS; ++e) s[e] += part[((int64_t)c * G + g) * NS + e];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) tot[g * NS + e] = s[e];
+}
+
+__global__ __launch_bounds__(256) void expr_pass2(const float *__restrict__ A, const float *__restrict__ B, int64_t n,
+                                                  int64_t G, const int32_t *__restrict__ group, int sel,
+                                                  int64_t rows_per_chunk, const double *__restrict__ tot1, int want_js,
+                                                  double *__restrict__ part) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
+    if (g >= G) return;
+    const double cnt = tot1[g * EX_N1], sa = tot1[g * EX_N1 + 3], sb = tot1[g * EX_N1 + 4];
+    const double ma = cnt > 0.0 ? tot1[g * EX_N1 + 1] / cnt : 0.0, mb = cnt > 0.0 ? tot1[g * EX_N1 + 2] / cnt : 0.0;
+    const bool js_ok = want_js && sa > 0.0 && sb > 0.0;
+    double s[EX_N2] = {0, 0, 0, 0};
+    for (int64_t r = r0; r < r1; ++r) {
+        if (sel >= 0 && group[r] != sel) continue;
+        const double a = (double)A[r * G + g], b = (double)B[r * G + g];
+        const double da = a - ma, db = b - mb;
+        s[0] = fma(da, da, s[0]); s[1] = fma(db, db, s[1]); s[2] = fma(da, db, s[2]);
+        if (js_ok) {   // p log(p/m) + q log(q/m), p = a+/sum a+, q = b+/sum b+, m = (p+q)/2; 0 log 0 = 0
+            const double p = (a > 0.0 ? a : 0.0) / sa, q = (b > 0.0 ? b : 0.0) / sb, m = 0.5 * (p + q);
+            if (p > 0.0) s[3] += p * log(p / m);
+            if (q > 0.0) s[3] += q * log(q / m);
+        }
+    }
+    double *o = part + ((int64_t)blockIdx.y * G + g) * EX_N2;
+#pragma unroll
+    for (int e = 0; e < EX_N2; ++e) o[e] = s[e];
+}
+
+__global__ void expr_finish(const double *__restrict__ tot1, const double *__restrict__ tot2, int64_t G, int method,
+                            float *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const double n = tot1[g * EX_N1];
+    double res = NAN;
+    if (n > 0.0) {
+        const double va = tot2[g * EX_N2] / n, vb = tot2[g * EX_N2 + 1] / n, cov = tot2[g * EX_N2 + 2] / n;  // population
+        if (method == 0) {            // scipy.stats.pearsonr: nan for a constant input, clipped to [-1, 1]
+            if (va > 0.0 && vb > 0.0 && n >= 2.0) {
+                res = cov / (sqrt(va) * sqrt(vb));
+                res = res > 1.0 ? 1.0 : (res < -1.0 ? -1.0 : res);
+            }
+        } else if (method == 1) {     // RMSE of the z-scored vectors, std == 0 -> 1 (evaluate.py:40-63)
+            const double sda = va > 0.0 ? sqrt(va) : 1.0, sdb = vb > 0.0 ? sqrt(vb) : 1.0;
+            const double ms = va / (sda * sda) + vb / (sdb * sdb) - 2.0 * cov / (sda * sdb);
+            res = sqrt(ms > 0.0 ? ms : 0.0);
+        } else {                      // scipy.spatial.distance.jensenshannon(p, q, base=10) on the clipped vectors
+            if (tot1[g * EX_N1 + 3] > 0.0 && tot1[g * EX_N1 + 4] > 0.0) {
+                const double js = tot2[g * EX_N2 + 3] / 2.302585092994046;   // ln 10
+                res = sqrt(js > 0.0 ? js * 0.5 : 0.0);
+            }
+        }
+    }
+    out[g] = (float)res;
+}
+
+int expr_chunks(int64_t n) {
+    int chunks = (int)((n + 4095) / 4096);
+    return chunks < 1 ? 1 : (chunks > 512 ? 512 : chunks);
+}
+}  // namespace
+
+cm_status cm_expr_metrics_run(cm_handle_t h, const float *d_a, const float *d_b, int64_t n, int64_t G, const int32_t *d_group,
+                              int n_groups, int method, float *d_out) {
+    if (n < 0 || G < 1 || method < 0 || method > 2 || n_groups < 0) CM_FAIL(h, CM_E_INVALID, "expression metrics: bad arguments");
+    const int chunks = expr_chunks(n);
+    const int64_t rpc = (n + chunks - 1) / chunks;
+    double *part = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)chunks * G * EX_N1);
+    double *tot1 = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)G * EX_N1);
+    double *tot2 = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)G * EX_N2);
+    if (!part || !tot1 || !tot2) CM_FAIL(h, CM_E_NOMEM, "expression metrics: device workspace exhausted");
+    const dim3 grid((unsigned)((G + 255) / 256), (unsigned)chunks), gg((unsigned)((G + 255) / 256));
+    for (int sel = -1; sel < n_groups; ++sel) {   // row 0 of the output: all cells; row 1 + c: cells of group c
+        if (sel >= 0 && !d_group) break;
+        hipLaunchKernelGGL(expr_pass1, grid, dim3(256), 0, h->stream, d_a, d_b, n, G, d_group, sel, rpc, part);
+        hipLaunchKernelGGL(expr_combine<EX_N1>, gg, dim3(256), 0, h->stream, part, G, chunks, tot1);
+        hipLaunchKernelGGL(expr_pass2, grid, dim3(256), 0, h->stream, d_a, d_b, n, G, d_group, sel, rpc, tot1, method == 2 ? 1 : 0, part);
+        hipLaunchKernelGGL(expr_combine<EX_N2>, gg, dim3(256), 0, h->stream, part, G, chunks, tot2);
+        hipLaunchKernelGGL(expr_finish, gg, dim3(256), 0, h->stream, tot1, tot2, G, method, d_out + (int64_t)(sel + 1) * G);
+    }
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+size_t cm_expr_metrics_ws_bytes(int64_t n, int64_t G) {
+    return cm_align(sizeof(double) * (size_t)expr_chunks(n) * G * EX_N1) + 2 * cm_align(sizeof(double) * (size_t)G * EX_N1) + 4096;
+}

@@ -215,6 +215,22 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
 cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_t *indices, const double *data, int64_t n,
                               int32_t include_self, int32_t kmax, int64_t *out_idx, double *out_dist, int32_t *out_kmax);
 
+/* ------------------------------------------------- expression-transfer evaluation --
+ * Replaces the per-gene Python loop of EvaluationMixin.evaluate_expression_transfer (evaluate.py:236-323, helpers
+ * :20-63): agreement between measured (orig) and imputed expression, both float32 row-major [n, n_genes], per gene over
+ * all cells (output row 0) and over the cells of each group (rows 1..n_groups; group int32 [n] in [0, n_groups) or
+ * NULL).  method: 0 = Pearson r (scipy.stats.pearsonr; NaN for a constant column), 1 = RMSE of the z-scored vectors
+ * (std 0 -> 1), 2 = Jensen-Shannon distance base 10 of the clipped, normalised vectors (NaN if either sums to 0).
+ * out float32 [n_groups + 1, n_genes].  Spearman is not provided.  The _dev form takes device pointers (the imputed
+ * matrix never has to leave the GPU). */
+#define CM_EXPR_PEARSON 0
+#define CM_EXPR_RMSE 1
+#define CM_EXPR_JS 2
+cm_status cm_expression_metrics(cm_handle_t h, const float *orig, const float *imputed, int64_t n, int64_t n_genes,
+                                const int32_t *group, int32_t n_groups, int32_t method, float *out);
+cm_status cm_expression_metrics_dev(cm_handle_t h, const float *d_orig, const float *d_imputed, int64_t n, int64_t n_genes,
+                                    const int32_t *d_group, int32_t n_groups, int32_t method, float *d_out);
+
 /* ---------------------------------------------------------------- diagnostics -----------------------
  * n independent products D = A*B + C on one v_mfma_f32_32x32x16_f16 chain each (chain k-steps of 16): a fp16 bits
  * [n, chain, 32, 16] row-major, b fp16 bits [n, chain, 16, 32], c / d float32 [n, 32, 32].  Test aid: pins the

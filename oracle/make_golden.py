@@ -178,10 +178,48 @@ def presence_case(cm_mod):
     return out
 
 
+def expr_eval_case():
+    """Per-gene agreement metrics exactly as EvaluationMixin.evaluate_expression_transfer computes them
+    (evaluate.py:271-289: metric_func per gene over a cell mask, float32 array), using the reference module's own
+    helpers (_rmse_zscore, _jensen_shannon_divergence; pearsonr as imported there), overall and per group."""
+    import warnings
+
+    ev = importlib.import_module("cellmapper.model.evaluate")
+    rng = np.random.default_rng(13)
+    n, G = 600, 40
+    lam = rng.gamma(2.0, 1.5, G)
+    orig = rng.poisson(lam, (n, G)).astype(np.float32)
+    imputed = (0.6 * orig + 0.4 * lam + 0.5 * rng.standard_normal((n, G))).astype(np.float32)
+    orig[:, 3] = 0.0                      # gene never measured: JS nan, pearson nan
+    imputed[:, 5] = 1.25                  # constant imputation: pearson nan, z-score std -> 1
+    orig[:, 7] = 2.0                      # constant measurement
+    imputed[:, 9] = -np.abs(imputed[:, 9])  # all negative: clipped to zero mass -> JS nan
+    labels = np.array(["t%d" % v for v in rng.integers(0, 3, n)])
+    funcs = {
+        "pearson": lambda a, b: ev.pearsonr(a, b)[0],
+        "rmse": ev._rmse_zscore,
+        "js": ev._jensen_shannon_divergence,
+    }
+    groups = list(pd.Series(labels).unique())
+    out = dict(orig=orig, imputed=imputed, labels=labels, group_names=np.array(groups), **VERSIONS)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, f in funcs.items():
+            def compute(mask, f=f):
+                return np.array([f(orig[mask, i], imputed[mask, i]) for i in range(G)], dtype=np.float32)
+            out[f"{name}_all"] = compute(np.ones(n, bool))
+            out[f"{name}_groups"] = np.stack([compute(labels == g) for g in groups], axis=1)   # [G, n_groups]
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cm_mod, knn_mod, utils_mod = load_reference()
     saved = {}
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "expr_eval":
+        np.savez_compressed(os.path.join(OUT, "expr_eval.npz"), **expr_eval_case())
+        print("expr_eval.npz written")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "presence":
         np.savez_compressed(os.path.join(OUT, "presence.npz"), **presence_case(cm_mod))
         print("presence.npz written")
@@ -293,6 +331,7 @@ def main():
     save("identity_k1", run_mapping_case(cm_mod, "identity_k1", xr7, xr7.copy(), 1, only_yx=False, n_cat=7, G=16))
 
     save("presence", presence_case(cm_mod))
+    save("expr_eval", expr_eval_case())
 
     for k_, v in saved.items():
         print(f"{k_:28s} {v/1024:8.1f} KiB")

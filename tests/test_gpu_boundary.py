@@ -339,3 +339,60 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
     big = sp.csr_matrix((np.ones(1500), (np.zeros(1500, int), np.arange(1500))), shape=(1500, 1500))
     with pytest.raises(NotImplementedError):
         extract_neighbors_from_distances(big)
+
+
+@pytest.mark.parametrize("method", ["pearson", "rmse", "js"])
+def test_expression_metrics_match_reference(oracle, method):
+    """cm_expression_metrics vs the reference's per-gene values (golden) and, on a larger ragged case, vs the oracle."""
+    from cellmapper_amd import _native
+
+    hip = _native.default_handle()
+    g = load_golden("expr_eval")
+    groups = list(g["group_names"])
+    codes = np.array([groups.index(v) for v in g["labels"]], np.int32)
+    res = hip.expression_metrics(g["orig"], g["imputed"], method, codes, len(groups))
+    assert res.shape == (len(groups) + 1, g["orig"].shape[1]) and res.dtype == np.float32
+    assert np.allclose(res[0], g[f"{method}_all"], rtol=1e-5, atol=2e-6, equal_nan=True)
+    assert np.array_equal(np.isnan(res[0]), np.isnan(g[f"{method}_all"]))
+    assert np.allclose(res[1:].T, g[f"{method}_groups"], rtol=1e-5, atol=2e-6, equal_nan=True)
+    rng = np.random.default_rng(5)
+    n, G = 20011, 333                               # several row chunks, a partial last column block
+    a = rng.poisson(rng.gamma(2.0, 2.0, G), (n, G)).astype(np.float32)
+    b = (0.5 * a + rng.standard_normal((n, G))).astype(np.float32)
+    a[:, 17] = 3.0
+    b[:, 40] = 0.0
+    codes = rng.integers(0, 4, n).astype(np.int32)
+    res = hip.expression_metrics(a, b, method, codes, 5)   # group 4 is empty: NaN row
+    assert np.allclose(res[0], oracle.expression_metrics(a, b, method), rtol=1e-5, atol=2e-6, equal_nan=True)
+    assert np.allclose(res[2], oracle.expression_metrics(a, b, method, codes == 1), rtol=1e-5, atol=2e-6, equal_nan=True)
+    assert np.isnan(res[5]).all()
+
+
+def test_evaluate_expression_transfer_side_effects():
+    """Drop-in surface of evaluate_expression_transfer (evaluate.py:236-323): query.var / query.varm columns, summary
+    dict, test-gene mask, errors."""
+    from cellmapper_amd import CellMapper, MiniAnnData
+
+    g = load_golden("expr_eval")
+    n, G = g["orig"].shape
+    genes = [f"g{i}" for i in range(G)]
+    query = MiniAnnData(X=g["orig"], obs=pd.DataFrame({"grp": g["labels"]}, index=[f"q{i}" for i in range(n)]),
+                        var=pd.DataFrame({"is_test": np.arange(G) % 2 == 0}, index=genes), obsm={"X_emb": np.zeros((n, 2), np.float32)})
+    ref = MiniAnnData(X=np.zeros((5, G), np.float32), var=pd.DataFrame(index=genes), obsm={"X_emb": np.zeros((5, 2), np.float32)})
+    cm = CellMapper(query, ref)
+    with pytest.raises(ValueError, match="Imputed query data not found"):
+        cm.evaluate_expression_transfer()
+    cm.query_imputed = MiniAnnData(X=g["imputed"], obs=query.obs.copy(), var=pd.DataFrame(index=genes))
+    cm.evaluate_expression_transfer(method="pearson", groupby="grp", test_var_key="is_test")
+    got = query.var["metric_pearson"].to_numpy()
+    assert np.allclose(got, g["pearson_all"], rtol=1e-5, atol=2e-6, equal_nan=True)
+    df = query.varm["metric_pearson"]
+    assert list(df.columns) == list(g["group_names"])
+    assert np.allclose(df.to_numpy(), g["pearson_groups"], rtol=1e-5, atol=2e-6, equal_nan=True)
+    valid = ~np.isnan(g["pearson_all"]) & (np.arange(G) % 2 == 0)
+    m = cm.expression_transfer_metrics
+    assert m["method"] == "pearson" and m["n_shared_genes"] == G and m["n_test_genes"] == int(valid.sum())
+    assert abs(m["average"] - float(np.mean(g["pearson_all"][valid]))) < 1e-5
+    with pytest.raises(NotImplementedError):
+        cm.evaluate_expression_transfer(method="spearman")
+

@@ -134,3 +134,17 @@ def test_oracle_precomputed_distance_ingest_edge_cases(oracle):
     idx, dist = oracle.extract_neighbors_from_distances(m, include_self=True)
     assert idx[0].tolist() == [0, 2, 1] and dist[0].tolist() == [0.0, 1.0, 2.0]
     assert np.isinf(dist[1]).sum() >= 1
+
+
+@pytest.mark.parametrize("method", ["pearson", "rmse", "js"])
+def test_oracle_expression_metrics_match_reference(oracle, method):
+    """oracle.expression_metrics vs the values the reference's helpers produced (evaluate.py:20-63,271-289), overall and
+    per group; genes with a constant / all-zero / all-negative column exercise the NaN and std -> 1 rules."""
+    g = load_golden("expr_eval")
+    r = oracle.expression_metrics(g["orig"], g["imputed"], method)
+    assert np.allclose(r, g[f"{method}_all"], rtol=1e-5, atol=2e-6, equal_nan=True)
+    assert np.array_equal(np.isnan(r), np.isnan(g[f"{method}_all"]))
+    for j, name in enumerate(g["group_names"]):
+        r = oracle.expression_metrics(g["orig"], g["imputed"], method, g["labels"] == name)
+        assert np.allclose(r, g[f"{method}_groups"][:, j], rtol=1e-5, atol=2e-6, equal_nan=True)
+
