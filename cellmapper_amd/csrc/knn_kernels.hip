@@ -749,11 +749,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                          int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int bs = 256;
+    const bool wide = phase1_path(d, k) == 3;   // 62 <= d <= 128: K = 128 kernels, no direct level
     const int dl = lowd_dpad(d);   // row stride of the direct kernel
-    const bool have_direct = d >= 16 && dl <= 64;
+    const bool have_direct = !wide && d >= 16 && dl <= 64;
     const int dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
     int forced = getenv("CELLMAP_FILTER_PRODUCTS") ? atoi(getenv("CELLMAP_FILTER_PRODUCTS")) : 0;
     if (forced < 1 || forced > 4 || (forced == 4 && !have_direct)) forced = 0;
+    if (wide && forced == 2) forced = 3;   // the K = 128 family has no two-product kernel
 
     KnnPlan2 pf;   // plan of the full query set at level 1 (widest candidate lists): sizes the buffers
     CM_TRY(make_plan2(h, n_ref, nq, d, k, 1, 1, &pf));
@@ -774,8 +776,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
-    char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * cmk2::tile_bytes(pf.KSTEPS > 2 ? pf.KSTEPS : 4));  // 256 B per row: any image
-    char *Qp = (char *)cm_ws_alloc(h, (size_t)nq_pad * 256);
+    // any tile image: <= 256 B per row (K <= 64) / 512 B per row + side block (K = 128)
+    char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (wide ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
+    char *Qp = (char *)cm_ws_alloc(h, (size_t)nq_pad * (wide ? 512 : 256));
     uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * Kc_max);
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
@@ -810,7 +813,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     auto run_stage = [&](int level, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
         KnnPlan2 p2;
-        CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : 1, level == 4 ? 3 : level, &p2));
+        const bool w3 = wide && level >= 3;   // K = 128, three products: knn_cand_f16w (256-query blocks, full rows)
+        CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : (w3 ? 3 : 1), level == 4 ? 3 : level, &p2));
+        if (wide) p2.KSTEPS = cmk2::KSTEPS_W;
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * cmk2::BR;   // (the direct kernel's 128-row tiles have the same count)
         if (img != want) {
@@ -819,8 +824,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                    nref_pad, 1, metric, reinterpret_cast<float *>(Rp), dl, (const int *)nullptr);
             else
                 hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                                   p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words, 0,
-                                   want, (const int *)nullptr, (float *)nullptr);
+                                   p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
+                                   wide ? 1 : 0, want, (const int *)nullptr, (float *)nullptr);
             img = want;
         }
         if (level == 4) {
@@ -828,10 +833,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp), dl, qmap);
         } else {
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, 0, 0,
-                               qmap, qlo);
-            p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
-            p2.lds = cmk2::ring_depth(want == 1) * p2.tileb + 64;
+                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr,
+                               wide ? 1 : 0, 0, qmap, qlo);
+            if (!w3) {   // (knn_cand_f16w keeps the plan of make_plan2: 2-deep ring of full tiles)
+                p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
+                p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * p2.tileb + 64;
+            }
         }
         if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
         cmk2::P1Args a;
@@ -845,6 +852,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
         if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
+        else if (w3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
         else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
         if (marks) cm_mark(h, 2);
         if (!rerank) return CM_OK;
@@ -856,7 +864,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
             c_split = (level == 1 ? 2.0f : (level == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f;
             // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
-            c_eps = 2.0f * (float)(16 + 2 * p2.KSTEPS * level) * 5.9604645e-8f + 8.4e-7f;
+            c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
         }
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
                            p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
@@ -948,7 +956,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = main_Kc;
     h->knn_stats[2] = main_S + 100 * start;
-    h->knn_stats[3] = 2;
+    h->knn_stats[3] = wide ? 4 : 2;
     return CM_OK;
 }
 
@@ -957,7 +965,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int path = phase1_path(d, k);
-    if (path == 1) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
+    if (path == 1 || path == 3) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     const bool f16 = path != 0;  // either of the persistent-workgroup kernels (split-fp16 MFMA or low-d VALU)
     KnnPlan p;
     KnnPlan2 p2;

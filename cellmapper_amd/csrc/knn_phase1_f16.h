@@ -49,7 +49,7 @@ constexpr int QB = NW * 64;  // queries per workgroup pass
 constexpr int CL = 128;      // lane-private append buffer capacity (entries)
 // LDS tile buffers of knn_cand_f16 (tile t+1 has landed while tile t is computed, see the kernel): 4 full 32-KB tiles
 // at level 3, 8 hi-only 16-KB tiles at levels 1/2
-__host__ __device__ constexpr int ring_depth(bool hi_only) { return hi_only ? 8 : 4; }
+__host__ __device__ constexpr int ring_depth(bool hi_only, int KSTEPS = 4) { return (hi_only && KSTEPS < 8) ? 8 : 4; }
 
 __host__ __device__ constexpr int row_bytes(int KSTEPS) { return KSTEPS * 16 * 2 * 2; }  // hi + lo halves
 __host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes(KSTEPS); }
@@ -64,7 +64,11 @@ __host__ __device__ constexpr int swz(int row, int KSTEPS) { return swz_b(row, r
 // Filter levels 1 and 2 never touch the lo halves of the reference rows: they run on a hi-only tile image (half the
 // LDS-DMA traffic and LDS footprint).  Level 3 uses the full [hi | lo] rows.
 __host__ __device__ constexpr int img_row_bytes(int KSTEPS, bool hi_only) { return hi_only ? KSTEPS * 32 : row_bytes(KSTEPS); }
-__host__ __device__ constexpr int img_tile_bytes(int KSTEPS, bool hi_only) { return BR * img_row_bytes(KSTEPS, hi_only); }
+// K = 128 (KSTEPS = 8) rows have no spare slots for the norm digits: the tile image ends with a 1-KiB side block of
+// sc^2|y|^2 (float32 per row) that initialises the accumulators
+__host__ __device__ constexpr int img_tile_bytes(int KSTEPS, bool hi_only) {
+    return BR * img_row_bytes(KSTEPS, hi_only) + (KSTEPS >= 8 ? 1024 : 0);
+}
 __host__ inline size_t lds_bytes(int KSTEPS, int scratch_entries) {
     return 2 * size_t(tile_bytes(KSTEPS)) + size_t(NW) * scratch_entries * 8 + 64;
 }
@@ -428,10 +432,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = img_row_bytes(KSTEPS, !LO3);
     constexpr int GRAN = row_bytes(KSTEPS) / 16;   // granules of a full row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
+    constexpr bool SIDE = KSTEPS >= 8;     // |y|^2 in a side block of the tile image instead of spare feature slots
+    static_assert(!(SIDE && LO3), "K = 128 runs level 3 on knn_cand_f16w");
     constexpr int TILEB = img_tile_bytes(KSTEPS, !LO3);
-    constexpr int RING = ring_depth(!LO3);
+    constexpr int ROWS_B = BR * ROWB;      // bytes of the rows of a tile; SIDE: followed by BR floats sc^2|y|^2
+    constexpr int RING = ring_depth(!LO3, KSTEPS);
     constexpr int AHEAD = RING - 1;   // the DMA pieces of tile t + AHEAD are issued during tile t
-    constexpr int NCHUNK = TILEB / 1024;   // 1-KiB pieces per tile image = one LDS-DMA wave-instruction each
+    constexpr int NCHUNK = ROWS_B / 1024;  // 1-KiB pieces of the rows = one LDS-DMA wave-instruction each (+1 side piece)
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
 
@@ -456,7 +463,12 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         _Pragma("unroll") for (int q_ = 0; q_ < NCHUNK / NW; ++q_)                                              \
             __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + q_ * (NW * 1024) + dma_voff),       \
                                              (CM2_AS3 void *)(ldst_ + q_ * (NW * 1024)), 16, 0, 0);             \
+        if (SIDE && wave0) CM2_DMA_SIDE(t_, buf_);                                                              \
     }
+    // the side block (1 KiB) is one more piece, copied by wave 0
+#define CM2_DMA_SIDE(t_, buf_)                                                                                  \
+    __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(a.R + (size_t)(t_) * TILEB + ROWS_B + lane * 16),  \
+                                     (CM2_AS3 void *)(ring + (buf_) * TILEB + ROWS_B), 16, 0, 0)
 #define CM2_DMA_PIECE(t_, buf_, q_)                                                                             \
     __builtin_amdgcn_global_load_lds(                                                                           \
         (const CM2_AS1 void *)(a.R + (size_t)(t_) * TILEB + (q_) * (NW * 1024) + dma_voff),                     \
@@ -465,6 +477,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int NPIECE = NCHUNK / NW;    // DMA pieces per wave and tile
     static_assert(NPIECE <= BR / 32, "one DMA piece per sub-tile");
     const unsigned dma_voff = wave * 1024 + lane * 16;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;   // scalar: issues (and counts) the side piece
 
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
@@ -476,21 +489,22 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         const int64_t qbase = (int64_t)qb * QB + wave * 64;
 
         // ---- query fragments (B operand): lane (c,hh), k-step s -> granule 2s+hh of the hi / lo half
-        half8 qh[2][KSTEPS], ql[2][KSTEPS];
+        constexpr int KL = NP >= 2 ? KSTEPS : 1;   // the lo fragments of the queries are only needed from two products on
+        half8 qh[2][KSTEPS], ql[2][KL];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const _Float16 *qrow = a.Q + (qbase + j * 32 + c) * (2 * K);
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                qh[j][s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
-                ql[j][s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
-            }
+            for (int s = 0; s < KSTEPS; ++s) qh[j][s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
+#pragma unroll
+            for (int s = 0; s < KL; ++s) ql[j][s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
         }
         // Touch the query fragments here: the compiler places its vmcnt wait for the loads above at this first use
         // instead of in front of the first MFMA of the tile loop, where it would also wait for the tile prefetch.
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-            asm volatile("" ::"v"(qh[0][s]), "v"(qh[1][s]), "v"(ql[0][s]), "v"(ql[1][s]));
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[0][s]), "v"(qh[1][s]));
+#pragma unroll
+        for (int s = 0; s < KL; ++s) asm volatile("" ::"v"(ql[0][s]), "v"(ql[1][s]));
         const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
         float thr[2] = {thr_init, thr_init};
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
@@ -527,6 +541,16 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         // swizzle repeats every 32 rows): one row address per lane, fragment = address ^ constant
         const unsigned arow = c * ROWB + ((hh ^ swz_b(c, ROWB)) * 16);
 
+        // SIDE: sc^2|y|^2 of the lane's 16 rows of a sub-tile (rows 4*hh + {0..3} + 8*i): half-wave broadcast reads
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0;
+        const unsigned yrow = ROWS_B + 16 * hh;
+#define CM2_LOAD_SIDE(TB, ST)                                                                                  \
+    {                                                                                                          \
+        CM2_DSR128X(y0, yrow, 0, TB, (ST) * 128);                                                              \
+        CM2_DSR128X(y1, yrow, 0, TB, (ST) * 128 + 32);                                                         \
+        CM2_DSR128X(y2, yrow, 0, TB, (ST) * 128 + 64);                                                         \
+        CM2_DSR128X(y3, yrow, 0, TB, (ST) * 128 + 96);                                                         \
+    }
         int next_refresh = t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
         half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
 #pragma unroll
@@ -536,14 +560,16 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             __builtin_amdgcn_s_barrier();
             const unsigned tile0 = ldsbase + (t0 % RING) * TILEB;
             CM2_LOAD_AH(ah, tile0, 0);
+            if (SIDE) CM2_LOAD_SIDE(tile0, 0);
         }
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0) {   // (the first tile synchronised above)
                 // own pieces of tile t+1 have landed; NP < 3: those of younger tiles may be in
                 // flight -- loads complete in order, stores in between only make the wait more conservative
-                if (t + AHEAD - 1 < t1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (conservative in the tail of a work item)
+                if (t + AHEAD - 1 >= t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (conservative in the tail of a work item)
+                else if (SIDE && wave0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * (NPIECE + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
                 if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
                 if (!(CM2_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
@@ -581,6 +607,14 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                     half8(&cur)[KSTEPS] = (!LO3 && (st & 1)) ? al : ah;
                     half8(&nxt)[KSTEPS] = (!LO3 && (st & 1)) ? ah : al;
                     wait_lds<0>(cur);
+                    if constexpr (SIDE) {   // both accumulators start from the rows' sc^2|y|^2 (C operand of the first MFMAs)
+                        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));   // (ordered after the wait above)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0[e] = y0[e]; acc0[4 + e] = y1[e]; acc0[8 + e] = y2[e]; acc0[12 + e] = y3[e];
+                        }
+                        acc1 = acc0;
+                    }
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
                         const int pr = i / NM1, s = (i % NM1) >> 1, jq = i & 1;
@@ -589,8 +623,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                             if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
                         } else if (pr == 1) {
-                            if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s], acc1, 0, 0, 0);
-                            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s], acc0, 0, 0, 0);
+                            if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s % KL], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s % KL], acc0, 0, 0, 0);
                         } else {
                             if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[1][s], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
@@ -603,13 +637,17 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                                     CM2_DSR128X(ah[i - 2 * NM1], arow, 32 * (i - 2 * NM1), ntile, nst * 32 * ROWB);
                             } else {
                                 if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+                                if (SIDE && i == KSTEPS) CM2_LOAD_SIDE(ntile, nst);   // (y0..y3 were consumed by MFMA 0 and 1)
                             }
                         }
 #pragma unroll
                         for (int jj = 0; jj < PER; ++jj)
                             if (i * PER + jj < 16 && (!(CM2_EXP & 8) || i * PER + jj >= 14)) min_step(i * PER + jj, p0, p1, mm);
                         if (i == NMT - 1 && st < NPIECE && !(CM2_EXP & 1)) {
-                            if (t + AHEAD < t1) CM2_DMA_PIECE(t + AHEAD, (t + AHEAD) % RING, st);
+                            if (t + AHEAD < t1) {
+                                CM2_DMA_PIECE(t + AHEAD, (t + AHEAD) % RING, st);
+                                if (SIDE && st == 0 && wave0) CM2_DMA_SIDE(t + AHEAD, (t + AHEAD) % RING);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -630,11 +668,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         }
         if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
 #undef CM2_LOAD_AH
+#undef CM2_LOAD_SIDE
 
         CM2_FINAL();
     }
 #undef CM2_DMA_TILE
 #undef CM2_DMA_PIECE
+#undef CM2_DMA_SIDE
     if ((a.dbg & 4) && lane == 0) {
         atomicAdd(&a.ctr[0], c_br);
         atomicAdd(&a.ctr[1], c_app);

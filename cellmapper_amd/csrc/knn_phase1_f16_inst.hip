@@ -19,8 +19,11 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
                             : (a.nprod == 2 ? launch_f16<ks_, 2>(h, grid, lds, a) : launch_f16<ks_, 1>(h, grid, lds, a));
         CM_F16_CASE(2) CM_F16_CASE(4)
 #undef CM_F16_CASE
+    case 8:   // K = 128: only the hi*hi level runs on this kernel (64 queries per wave); level 3 uses knn_cand_f16w
+        if (a.nprod == 1) return launch_f16<8, 1>(h, grid, lds, a);
+        break;
     }
-    CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d", KSTEPS);
+    CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d with %d products", KSTEPS, a.nprod);
 }
 
 cm_status cm_p1direct_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
