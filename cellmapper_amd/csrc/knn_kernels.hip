@@ -14,6 +14,16 @@
 
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
+// grid_knn.hip: uniform-grid candidate search for d <= 3
+size_t cm_grid_ws_bytes(int64_t n_ref, int64_t ncell_max);
+int64_t cm_grid_ncell_max(int64_t n_ref, int k);
+template <typename T>
+cm_status cm_grid_build(cm_handle_t h, const T *d_ref, int64_t n_ref, int d, int k, void **gi_out, int64_t **cell_start_out,
+                        float **sxyz_out, int **sidx_out);
+template <typename T>
+cm_status cm_grid_query(cm_handle_t h, const T *d_qry, int64_t nq, int d, const int *rowmap, const void *gi,
+                        const int64_t *cell_start, const float *sxyz, const int *sidx, int k, int Kc, const unsigned *gmax,
+                        int *cand, float *cthr);
 cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a);
 
 // phase-1 instantiation groups (knn_phase1_inst.hip)
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= nq) return;
-    if (lane == 0) s_kc[w] = INFINITY;
+    if (lane == 0) { s_kc[w] = INFINITY; s_kth[w] = INFINITY; }   // (fewer than k valid candidates: bound = inf)
     const int64_t io = qmap ? (int64_t)qmap[i] : i;
     double *q = s_q[w];
     for (int c = lane; c < d; c += 64) q[c] = (double)qry[io * d + c];
@@ -749,12 +759,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                          int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int bs = 256;
-    const bool wide = phase1_path(d, k) == 3;   // 62 <= d <= 128: K = 128 kernels, no direct level
-    const int dl = lowd_dpad(d);   // row stride of the direct kernel
-    const bool have_direct = !wide && d >= 16 && dl <= 64;
+    const int path = phase1_path(d, k);
+    const bool wide = path == 3;     // 62 <= d <= 128: K = 128 kernels, no direct level
+    const bool lowp = path == 2;     // d <= 15 (or CELLMAP_PHASE1=direct): no MFMA levels, the direct kernel is the filter
+    const int dl = lowd_dpad(d);     // row stride of the direct kernel
+    const bool have_direct = !wide && dl <= 64;
+    // level 0: uniform-grid search (grid_knn.hip) for spatial coordinates; worth its set-up from a few thousand rows on
+    const bool have_grid = lowp && d <= 3 && metric == CM_METRIC_EUCLIDEAN && n_ref >= 4096 &&
+                           !(getenv("CELLMAP_LOWD") && !strcmp(getenv("CELLMAP_LOWD"), "brute"));
     const int dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
     int forced = getenv("CELLMAP_FILTER_PRODUCTS") ? atoi(getenv("CELLMAP_FILTER_PRODUCTS")) : 0;
-    if (forced < 1 || forced > 4 || (forced == 4 && !have_direct)) forced = 0;
+    if (forced < 1 || forced > 4 || (forced == 4 && !have_direct) || lowp) forced = 0;
     if (wide && forced == 2) forced = 3;   // the K = 128 family has no two-product kernel
 
     KnnPlan2 pf;   // plan of the full query set at level 1 (widest candidate lists): sizes the buffers
@@ -793,10 +808,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // centre at the reference mean (translation leaves every distance unchanged), common power-of-two scale
     hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
     hipLaunchKernelGGL(colmean_final, dim3(1), dim3(64), 0, st, cpart, n_ref, d, d_mean);
-    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, (const double *)d_mean, words);
-    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, (const double *)d_mean, words);
+    // (the direct / grid filters work on the rows as given: their rounding bound needs max |coordinate| of the raw values)
+    const double *mean_ma = lowp ? (const double *)nullptr : (const double *)d_mean;
+    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, mean_ma, words);
+    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, mean_ma, words);
     hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
     CM_HIP(h, hipGetLastError());
+    // level 0 state: the grid over the reference rows is built on first use
+    void *grid_info = nullptr;
+    int64_t *grid_start = nullptr;
+    float *grid_xyz = nullptr;
+    int *grid_idx = nullptr;
 
     g_dbg_ctr = nullptr;
     unsigned long long *d_ctr = nullptr;
@@ -812,12 +834,28 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int last_Kc = Kc_max, last_S = 1;
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     auto run_stage = [&](int level, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
+        if (level == 0) {   // uniform-grid candidate search (d <= 3): same outputs as a filter kernel, one list per query
+            if (!grid_info) CM_TRY(cm_grid_build<T>(h, d_ref, n_ref, d, k, &grid_info, &grid_start, &grid_xyz, &grid_idx));
+            const int Kc0 = k + knn_slack(k);
+            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+            if (marks) cm_mark(h, 1);
+            CM_TRY(cm_grid_query<T>(h, d_qry, nsub, d, qmap, grid_info, grid_start, grid_xyz, grid_idx, k, Kc0, words, cand, cthr));
+            if (marks) cm_mark(h, 2);
+            last_Kc = Kc0; last_S = 1;
+            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
+                               1, Kc0, k, metric, form, qnorm, words, -(float)(d + 4) * 2.0f * 5.9604645e-8f, 0.f,
+                               (const float *)nullptr, (const double *)nullptr, idx_offset, flags, d_out_dist, d_out_idx, flag_out,
+                               (int *)(words + 2), bound, qmap, 0, (const float *)nullptr, 0);
+            CM_HIP(h, hipGetLastError());
+            if (marks) cm_mark(h, 3);
+            return CM_OK;
+        }
         KnnPlan2 p2;
         const bool w3 = wide && level >= 3;   // K = 128, three products: knn_cand_f16w (256-query blocks, full rows)
         CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : (w3 ? 3 : 1), level == 4 ? 3 : level, &p2));
         if (wide) p2.KSTEPS = cmk2::KSTEPS_W;
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
-        const int64_t nref_pad = (int64_t)p2.n_tiles * cmk2::BR;   // (the direct kernel's 128-row tiles have the same count)
+        const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
         if (img != want) {
             if (want == 2)
                 hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
@@ -883,10 +921,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     };
 
     // ---- choose the level the whole set starts at
-    int start = 1;
+    int start = lowp ? (have_grid ? 0 : 4) : 1;
     const bool hinted = h->staged_hint_level == 1 && h->staged_hint_d == d && h->staged_hint_k == k &&
                         h->staged_hint_metric == metric && !getenv("CELLMAP_NO_HINT");
-    if (forced) start = forced;
+    if (lowp) {}   // grid or direct kernel: nothing to choose
+    else if (forced) start = forced;
     else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
     else if (hinted) start = 1;   // level 1 certified most queries last time: no pilot
     else if (n_pilot > 0 && !(dbg & 3)) {
@@ -910,16 +949,26 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
         if (stage == 0) { main_Kc = last_Kc; main_S = last_S; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
-        const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0 : (level < 3 ? 3 : (level == 3 && have_direct ? 4 : 0));
+        const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0
+                         : (level == 0 ? 4 : (level == 4 ? 0 : (level < 3 ? 3 : (have_direct ? 4 : 0))));
         if (!next) break;
         int64_t nf = 0;
         CM_TRY(read_flags(&nf));
-        if (stage == 0 && !forced) {   // remember whether the cheapest level is worth starting with next time
+        if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
             const bool good = level == 1 && nf * 2 <= nsub;
             h->staged_hint_level = good ? 1 : 0;
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
         }
-        if (nf <= 64) break;      // the sliced exact scan is cheaper than another stage for a handful of queries
+        if (dbg & 16) {
+            unsigned gc[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(gc, words + 12, 16, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld queries uncertified (grid give-ups: <k %u, >cap %u, >K' %u)\n",
+                    stage, level, (long long)nf, (long long)nsub, gc[0], gc[1], gc[2]);
+        }
+        if (nf == 0) break;
+        // the sliced exact scan is cheaper than another stage for a handful of queries -- except after the grid stage,
+        // whose give-ups carry no usable bound (no candidates were evaluated for them)
+        if (nf <= 64 && level != 0) break;
         qmap = flag_out;
         nsub = nf;
         flag_out = flag_out == flag_a ? flag_b : flag_a;
@@ -956,7 +1005,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = main_Kc;
     h->knn_stats[2] = main_S + 100 * start;
-    h->knn_stats[3] = wide ? 4 : 2;
+    h->knn_stats[3] = wide ? 4 : (lowp ? 3 : 2);
     return CM_OK;
 }
 
@@ -965,7 +1014,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int path = phase1_path(d, k);
-    if (path == 1 || path == 3) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
+    if (path == 1 || path == 2 || path == 3) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     const bool f16 = path != 0;  // either of the persistent-workgroup kernels (split-fp16 MFMA or low-d VALU)
     KnnPlan p;
     KnnPlan2 p2;
@@ -1191,6 +1240,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
+        if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
     } else {
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;

@@ -279,6 +279,44 @@ def test_staged_search_stale_level_hint_is_harmless(hip, oracle):
     assert hip.knn_stats()["filter_products"] >= 3
 
 
+@pytest.mark.parametrize("d,k,dtype", [(2, 15, np.float32), (2, 90, np.float32), (3, 20, np.float32), (1, 8, np.float32),
+                                       (2, 30, np.float64)])
+def test_grid_search_matches_oracle(hip, oracle, d, k, dtype):
+    """Spatial coordinates (d <= 3, n_ref >= 4096) take the uniform-grid candidate search: uniform points, a dense blob
+    (cells beyond the per-query budget -> brute-force subset), exact duplicates (ties beyond K'), queries outside the
+    reference's bounding box, float64 coordinates of magnitude 1e4."""
+    rng = np.random.default_rng(100 + d + k)
+    n_ref, nq = 30000, 6000
+    ref = rng.random((n_ref, d)) * 2000.0
+    ref[:4000] = 1000.0 + rng.standard_normal((4000, d)) * 0.5      # dense blob: > 2048 points in a few cells
+    ref[5000:5200] = ref[5000]                                      # 200 exact duplicates
+    qry = rng.random((nq, d)) * 2400.0 - 200.0                      # some queries outside the bounding box
+    qry[:500] = 1000.0 + rng.standard_normal((500, d)) * 0.5
+    qry[500] = ref[5000]
+    if dtype == np.float64:
+        ref += 1.0e4
+        qry += 1.0e4
+    ref, qry = ref.astype(dtype), qry.astype(dtype)
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od), st
+    assert st["lowd_path"] == 3
+
+
+def test_grid_search_self_mapping_and_brute_agree(hip, oracle, monkeypatch):
+    """Self-mapping on a jittered lattice (many near-ties), grid vs the brute-force direct kernel (CELLMAP_LOWD=brute)."""
+    rng = np.random.default_rng(77)
+    g = np.stack(np.meshgrid(np.arange(150), np.arange(150)), -1).reshape(-1, 2).astype(np.float32)
+    pts = (g * 10.0 + rng.standard_normal(g.shape).astype(np.float32) * 0.01).astype(np.float32)
+    d1, i1 = hip.knn(pts, pts, 12)
+    monkeypatch.setenv("CELLMAP_LOWD", "brute")
+    d2, i2 = hip.knn(pts, pts, 12)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    od, oi = oracle.knn_euclidean(pts, pts[:3000], 12)
+    assert np.array_equal(i1[:3000], oi) and np.array_equal(d1[:3000], od)
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
