@@ -317,6 +317,22 @@ def test_grid_search_self_mapping_and_brute_agree(hip, oracle, monkeypatch):
     assert np.array_equal(i1[:3000], oi) and np.array_equal(d1[:3000], od)
 
 
+@pytest.mark.parametrize("d", [16, 20, 29, 30, 45, 61, 62, 100, 125, 128])
+def test_every_filter_level_is_exact_for_every_kernel_width(hip, oracle, monkeypatch, d):
+    """Pin each filter level in turn (CELLMAP_FILTER_PRODUCTS: no escalation, uncertified queries go to the exact scan) for
+    feature widths on both sides of every kernel boundary: K = 32 (d <= 29), K = 64 (d <= 61), K = 128 (d <= 128; hi*hi
+    on knn_cand_f16<8,1>, three products on knn_cand_f16w), and the padded direct kernel."""
+    rng = np.random.default_rng(d)
+    ref = rng.standard_normal((9000, d)).astype(np.float32)
+    qry = rng.standard_normal((1500, d)).astype(np.float32)
+    od, oi = oracle.knn_euclidean(ref, qry, 20)
+    for level in ("1", "2", "3", "4"):
+        monkeypatch.setenv("CELLMAP_FILTER_PRODUCTS", level)
+        monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+        dist, idx = hip.knn(ref, qry, 20)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (d, level, hip.knn_stats())
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
