@@ -886,6 +886,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
         a.dbg = dbg; a.ctr = d_ctr;
+        a.perm_mul = 1;
+        if (level != 4 && !w3 && p2.n_tiles > 8 && !getenv("CELLMAP_NO_PERM")) {   // knn_cand_f16: scattered tile order
+            unsigned long long pm = (unsigned long long)((double)p2.n_tiles * 0.6180339887498949) | 1ull;
+            auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
+            while (gcd(pm, (unsigned long long)p2.n_tiles) != 1ull) pm += 2;
+            a.perm_mul = (unsigned)pm;
+        }
         last_Kc = p2.Kc; last_S = p2.S;
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
@@ -1100,6 +1107,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
         a.ctr = nullptr;
+        a.perm_mul = 1;
         g_dbg_ctr = nullptr;
         if (a.dbg & 4) {
             static unsigned long long *d_ctr = nullptr;

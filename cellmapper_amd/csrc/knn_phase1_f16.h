@@ -87,6 +87,9 @@ struct P1Args {
                            // (~2^-11), 1 = hi*hi only (~2^-10); the certificate in knn_rerank uses the matching bound
     int dbg;               // timing experiments only (CELLMAP_DBG): 1 = never append, 2 = skip the filter, 4 = counters
     unsigned long long *ctr;  // [16] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
+    unsigned perm_mul;     // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
+                           // n_tiles; 0/1 = identity).  A scattered visiting order keeps the streaming thresholds
+                           // representative when the reference rows are sorted (by cluster, batch, ...)
 };
 
 __device__ __forceinline__ uint2 ld_fresh(const uint2 *p) {
@@ -478,6 +481,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     static_assert(NPIECE <= BR / 32, "one DMA piece per sub-tile");
     const unsigned dma_voff = wave * 1024 + lane * 16;
     const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;   // scalar: issues (and counts) the side piece
+    // physical tile of logical tile t_ (uniform; a 64-bit modulo: used at the start of a work item only, the tile loop
+    // advances the physical index by perm_mul modulo n_tiles)
+#define CM2_PT(t_) (a.perm_mul > 1u ? (int)(((unsigned long long)(unsigned)(t_) * a.perm_mul) % (unsigned)a.n_tiles) : (int)(t_))
 
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
-            if (t0 + u < t1) CM2_DMA_TILE(t0 + u, (t0 + u) % RING);
+            if (t0 + u < t1) CM2_DMA_TILE(CM2_PT(t0 + u), (t0 + u) % RING);
 
         // Software pipeline: the filter of sub-tile i-1 (VALU) is issued in the shadow of sub-tile i's MFMA chain.
         f32x16 p0, p1;          // accumulators of the previous sub-tile, waiting to be filtered (+inf = nothing pending)
@@ -562,6 +568,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             CM2_LOAD_AH(ah, tile0, 0);
             if (SIDE) CM2_LOAD_SIDE(tile0, 0);
         }
+        int ptile = CM2_PT(t0), ptile_a = CM2_PT(t0 + AHEAD);
+        const int pstep = a.perm_mul > 1u ? (int)(a.perm_mul % (unsigned)a.n_tiles) : 1;
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0) {   // (the first tile synchronised above)
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             }
             const unsigned tile = ldsbase + (t % RING) * TILEB;
             const unsigned tile_n = ldsbase + ((t + 1) % RING) * TILEB;
+            // physical tiles of t and of t + AHEAD (advanced by perm_mul modulo n_tiles at the end of the iteration)
             const bool more = t + 1 < t1;   // uniform: prefetch the next tile's first fragments at the last sub-tile
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
@@ -645,8 +654,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                             if (i * PER + jj < 16 && (!(CM2_EXP & 8) || i * PER + jj >= 14)) min_step(i * PER + jj, p0, p1, mm);
                         if (i == NMT - 1 && st < NPIECE && !(CM2_EXP & 1)) {
                             if (t + AHEAD < t1) {
-                                CM2_DMA_PIECE(t + AHEAD, (t + AHEAD) % RING, st);
-                                if (SIDE && st == 0 && wave0) CM2_DMA_SIDE(t + AHEAD, (t + AHEAD) % RING);
+                                CM2_DMA_PIECE(ptile_a, (t + AHEAD) % RING, st);
+                                if (SIDE && st == 0 && wave0) CM2_DMA_SIDE(ptile_a, (t + AHEAD) % RING);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -656,9 +665,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 if (!(a.dbg & 2)) CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
                 p0 = acc0;
                 p1 = acc1;
-                prbase = t * BR + st * 32 + 4 * hh;
+                prbase = ptile * BR + st * 32 + 4 * hh;
             }
             CM2_REFRESH_T(t, t0, CL - 16 * NST);
+            ptile += pstep; if (ptile >= a.n_tiles) ptile -= a.n_tiles;
+            ptile_a += pstep; if (ptile_a >= a.n_tiles) ptile_a -= a.n_tiles;
         }
         if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
             float mp0, mp1;
@@ -675,6 +686,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 #undef CM2_DMA_TILE
 #undef CM2_DMA_PIECE
 #undef CM2_DMA_SIDE
+#undef CM2_PT
     if ((a.dbg & 4) && lane == 0) {
         atomicAdd(&a.ctr[0], c_br);
         atomicAdd(&a.ctr[1], c_app);

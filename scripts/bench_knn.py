@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--clusters", type=int, default=0, help="draw rows from this many Gaussian clusters (centres N(0, spread^2))")
     ap.add_argument("--spread", type=float, default=5.0); ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--sorted", action="store_true", help="reference rows sorted by cluster label (worst case for streaming thresholds)")
     a = ap.parse_args()
     import torch
     from cellmapper_amd.device import DevicePipeline
@@ -22,6 +23,8 @@ def main():
         cen = torch.randn((a.clusters, a.d), generator=g, device=pipe.device) * a.spread
         def mk(n):
             lab = torch.randint(0, a.clusters, (n,), generator=g, device=pipe.device)
+            if a.sorted:
+                lab = torch.sort(lab).values
             return cen[lab] + torch.randn((n, a.d), generator=g, device=pipe.device) * a.sigma
     ref = mk(a.nref); qry = ref if a.self else mk(a.nq)
     for _ in range(a.reps):
