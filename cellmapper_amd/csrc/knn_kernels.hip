@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
                                                    int *__restrict__ flag_cnt, double *__restrict__ bound,
                                                    const int *__restrict__ qmap, int pilot_kc,
-                                                   const float *__restrict__ qlo, int level) {
+                                                   const float *__restrict__ qlo, int level, const int *__restrict__ rmap) {
     // qmap != nullptr: the nq rows of cand / cthr / qnorm belong to the query SUBSET qmap[0..nq) (staged search);
     // the query row, the outputs, the bound and the flag entry use the original index io.
     // pilot_kc > 0 (pilot of the staged search): a small sample runs with many reference splits, whose union of
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     const int *cq = cand + i * nc;
     for (int s = lane; s < nc; s += 64) {
         int j = cq[s];
+        if (j >= 0 && rmap) j = rmap[j];   // candidate positions refer to the locality-sorted tile image
         double v = INFINITY;
         if (j >= 0) v = pair_value<T>(q, xn, ref + (int64_t)j * d, d, metric, form);
         s_v[w][s] = v;
@@ -737,6 +738,74 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     return CM_OK;
 }
 
+// ------------------------------------------------------------------ locality sort ---------------------
+// Rows are bucketed by their nearest of C pivots (reference rows sampled at a fixed stride) and both the reference tile
+// image and the order in which queries are packed into waves follow that bucketing.  A wave then holds 64 queries of one
+// neighbourhood and a tile holds reference rows of one neighbourhood: candidates arrive in bursts that one append event
+// handles together, instead of one event per stray value.  Pure scheduling: which rows share a tile or a wave has no
+// influence on the result.
+constexpr int LS_CMAX = 64;    // pivots
+constexpr int LS_ROWS = 4096;  // rows per workgroup of the bucketing kernels
+constexpr int LS_DSUB = 16;    // leading coordinates used for the bucketing (one 64-byte line per row; for PCA embeddings
+                               // these carry most of the cluster structure -- any partition is valid, this one is cheap)
+template <typename T>
+__global__ __launch_bounds__(256) void ls_assign(const T *__restrict__ X, int64_t n, int d, const T *__restrict__ pivsrc,
+                                                 int64_t piv_stride, int C, int *__restrict__ label, int *__restrict__ counts) {
+    __shared__ float ls_piv[LS_CMAX][LS_DSUB];
+    const int ds = d < LS_DSUB ? d : LS_DSUB;
+    for (int t = threadIdx.x; t < C * LS_DSUB; t += blockDim.x) {
+        const int c = t / LS_DSUB, e = t % LS_DSUB;
+        ls_piv[c][e] = e < ds ? (float)pivsrc[(int64_t)c * piv_stride * d + e] : 0.f;
+    }
+    __shared__ int ls_hist[LS_CMAX];
+    if (threadIdx.x < LS_CMAX) ls_hist[threadIdx.x] = 0;
+    __syncthreads();
+    // LS_ROWS rows per workgroup: the per-bucket counts go through an LDS histogram (64 global atomics per workgroup)
+    for (int rr = 0; rr < LS_ROWS / 256; ++rr) {
+        const int64_t i = (int64_t)blockIdx.x * LS_ROWS + rr * 256 + threadIdx.x;
+        if (i >= n) break;
+        float x[LS_DSUB];
+#pragma unroll
+        for (int e = 0; e < LS_DSUB; ++e) x[e] = e < ds ? (float)X[i * d + e] : 0.f;
+        float best = INFINITY;
+        int bc = 0;
+        for (int c = 0; c < C; ++c) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < LS_DSUB; ++e) { const float t = x[e] - ls_piv[c][e]; sacc = fmaf(t, t, sacc); }
+            if (sacc < best) { best = sacc; bc = c; }
+        }
+        label[i] = bc;
+        atomicAdd(&ls_hist[bc], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < C && ls_hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], ls_hist[threadIdx.x]);
+}
+__global__ void ls_offsets(const int *__restrict__ counts, int C, int *__restrict__ cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < C; ++c) { cursor[c] = run; run += counts[c]; }
+    }
+}
+__global__ __launch_bounds__(256) void ls_scatter(const int *__restrict__ label, int64_t n, int *__restrict__ cursor,
+                                                  int *__restrict__ perm) {
+    __shared__ int hist[LS_CMAX], base[LS_CMAX];
+    if (threadIdx.x < LS_CMAX) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * LS_ROWS;
+    for (int rr = 0; rr < LS_ROWS / 256; ++rr) {
+        const int64_t i = r0 + rr * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[label[i]], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < LS_CMAX) { base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], hist[threadIdx.x]) : 0; hist[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int rr = 0; rr < LS_ROWS / 256; ++rr) {
+        const int64_t i = r0 + rr * 256 + threadIdx.x;
+        if (i < n) { const int c = label[i]; perm[base[c] + atomicAdd(&hist[c], 1)] = (int)i; }
+    }
+}
+
 __global__ void strided_rows(int *__restrict__ out, int n, int64_t stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)(i * stride);
@@ -814,6 +883,28 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, mean_ma, words);
     hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
     CM_HIP(h, hipGetLastError());
+    // locality sort (see ls_assign): permutation of the reference rows for the tile images, of the queries for the order
+    // in which full-set stages pack them into waves
+    int *rperm = nullptr, *qperm = nullptr;
+    if (!lowp && n_ref >= 65536 && nq >= 4096 && !getenv("CELLMAP_NO_SORT")) {
+        const int C = LS_CMAX;
+        int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
+        int *cnt_c = (int *)cm_ws_alloc(h, sizeof(int) * 2 * LS_CMAX);
+        rperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_ref);
+        qperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nq);
+        if (!lab || !cnt_c || !rperm || !qperm) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        auto assign = ls_assign<T>;
+        for (int side = 0; side < 2; ++side) {
+            const T *X = side ? d_qry : d_ref;
+            const int64_t nn = side ? nq : n_ref;
+            int *perm = side ? qperm : rperm;
+            CM_HIP(h, hipMemsetAsync(cnt_c, 0, sizeof(int) * 2 * LS_CMAX, st));
+            hipLaunchKernelGGL(assign, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, X, nn, d, d_ref, n_ref / C, C, lab, cnt_c);
+            hipLaunchKernelGGL(ls_offsets, dim3(1), dim3(64), 0, st, cnt_c, C, cnt_c + LS_CMAX);
+            hipLaunchKernelGGL(ls_scatter, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, lab, nn, cnt_c + LS_CMAX, perm);
+        }
+        CM_HIP(h, hipGetLastError());
+    }
     // level 0 state: the grid over the reference rows is built on first use
     void *grid_info = nullptr;
     int64_t *grid_start = nullptr;
@@ -845,7 +936,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
                                1, Kc0, k, metric, form, qnorm, words, -(float)(d + 4) * 2.0f * 5.9604645e-8f, 0.f,
                                (const float *)nullptr, (const double *)nullptr, idx_offset, flags, d_out_dist, d_out_idx, flag_out,
-                               (int *)(words + 2), bound, qmap, 0, (const float *)nullptr, 0);
+                               (int *)(words + 2), bound, qmap, 0, (const float *)nullptr, 0, (const int *)nullptr);
             CM_HIP(h, hipGetLastError());
             if (marks) cm_mark(h, 3);
             return CM_OK;
@@ -859,11 +950,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (img != want) {
             if (want == 2)
                 hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                                   nref_pad, 1, metric, reinterpret_cast<float *>(Rp), dl, (const int *)nullptr);
+                                   nref_pad, 1, metric, reinterpret_cast<float *>(Rp), dl, (const int *)rperm);
             else
                 hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                    p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
-                                   wide ? 1 : 0, want, (const int *)nullptr, (float *)nullptr);
+                                   wide ? 1 : 0, want, (const int *)rperm, (float *)nullptr);
             img = want;
         }
         if (level == 4) {
@@ -915,7 +1006,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                            p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
                            idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
-                           level == 4 ? (const float *)nullptr : (const float *)qlo, level);
+                           level == 4 ? (const float *)nullptr : (const float *)qlo, level, (const int *)rperm);
         CM_HIP(h, hipGetLastError());
         if (marks) cm_mark(h, 3);
         return CM_OK;
@@ -948,7 +1039,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     }
 
     // ---- the ladder
-    const int *qmap = nullptr;
+    const int *qmap = qperm;   // full set: in locality-sorted order (nullptr = as given)
     int64_t nsub = nq;
     int *flag_out = flag_a;
     int level = start, main_Kc = Kc_max, main_S = 1;
@@ -1161,7 +1252,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
             // not the last level: re-rank now and look at how many queries failed the certificate
             hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                                S, Kc, k, metric, form, qnorm, words, c_eps, c_split, scale3, (const double *)d_mean, idx_offset,
-                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0);
+                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0, (const int *)nullptr);
             cm_mark(h, 3);
             CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             CM_HIP(h, hipStreamSynchronize(st));
@@ -1203,7 +1294,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
                            S, Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
-                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0);
+                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0, (const int *)nullptr);
     if (!reranked) cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
@@ -1249,6 +1340,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
+        b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
     } else {
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;
