@@ -1107,195 +1107,57 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     return CM_OK;
 }
 
+// Entry point of the search.  d <= 128 (and k small enough for the in-register merges) runs the staged search above;
+// wider rows or very large k use the f32-input MFMA filter (knn_phase1.h: LDS candidate buffers, one pass, certificate
+// from the fmaf-chain bound), then the same re-rank and exact fallback.
 template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
-    const int path = phase1_path(d, k);
-    if (path == 1 || path == 2 || path == 3) return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
-    const bool f16 = path != 0;  // either of the persistent-workgroup kernels (split-fp16 MFMA or low-d VALU)
+    if (phase1_path(d, k) != 0)
+        return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     KnnPlan p;
-    KnnPlan2 p2;
-    int Kc, S;
-    int64_t nq_pad;
-    // Adaptive filter precision (split-fp16 kernels): start with the cheapest split (hi*hi only, 1/3 of the MFMA work,
-    // bound ~2^-10 |q||y|); if more than a sliver of the queries cannot be certified, redo the filter with all three
-    // products.  Exactness never depends on the level -- the certificate uses the matching bound.
-    int levels[2] = {3, 0}, n_levels = 1;
-    if (path == 1 || path == 3) {
-        const char *e = getenv("CELLMAP_FILTER_PRODUCTS");
-        int forced = e ? atoi(e) : 0;
-        if (forced >= 1 && forced <= 3) levels[0] = forced;
-        else if (!(flags & CM_KNN_FORCE_FALLBACK)) { levels[0] = 1; levels[1] = 3; n_levels = 2; }
-    }
-    if (f16) { CM_TRY(make_plan2(h, n_ref, nq, d, k, path, levels[0], &p2)); Kc = p2.Kc; S = p2.S; nq_pad = p2.nq_pad; }
-    else { CM_TRY(make_plan(h, n_ref, nq, d, k, &p)); Kc = p.Kc; S = p.S; nq_pad = p.nq_pad; }
-    const int Kc_max = Kc;  // level 1 has the widest candidate list: buffers are sized for it
+    CM_TRY(make_plan(h, n_ref, nq, d, k, &p));
+    const int Kc = p.Kc, S = p.S;
+    const int64_t nq_pad = p.nq_pad;
     float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
-    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc_max);
+    int *cand = (int *)cm_ws_alloc(h, sizeof(int) * nq_pad * S * Kc);
     float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad * S);
     int *flag_list = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
     double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
-    unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
+    unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow
     int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);                       // sliced exact fallback: candidate lists
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
-    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words || !fb_count || !fb_v || !fb_i)
+    float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
+    float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
+    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp || !Qp)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-    float *scale3 = reinterpret_cast<float *>(words + 8);
-    double *d_mean = nullptr;
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
-    float c_eps, c_split = 0.f;
-    int level_used = 3;
-    bool reranked = false;
     const int bs = 256;
-    if (f16) {
-        int img_hi_only = 0;   // layout of the reference tile image currently in Rp
-        char *Rp = (char *)cm_ws_alloc(h, (size_t)p2.n_tiles * p2.tileb);
-        char *Qp = (char *)cm_ws_alloc(h, (size_t)p2.nq_pad * p2.rowb);
-        const int wpb = path == 3 ? cmk2::NWW : cmk2::NW;  // waves per workgroup
-        uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * Kc_max);
-        uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)p2.grid * wpb * 64 * 2 * cmk2::CL);
-        if (!Rp || !Qp || !kept || !lbuf) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-        int64_t nref_pad = (int64_t)p2.n_tiles * (path == 2 ? cmk2::lowd_rows(lowd_dpad(d)) : cmk2::BR);
-        if (path == 1 || path == 3) {  // centre at the reference mean (translation leaves every distance unchanged)
-            double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
-            d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
-            if (!cpart || !d_mean) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-            hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
-            hipLaunchKernelGGL(colmean_final, dim3(1), dim3(64), 0, st, cpart, n_ref, d, d_mean);
-        }
-        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, (const double *)d_mean, words);
-        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, (const double *)d_mean, words);
-        if (path == 2) {
-            hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               nref_pad, 1, metric, reinterpret_cast<float *>(Rp), lowd_dpad(d), (const int *)nullptr);
-            hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp), lowd_dpad(d), (const int *)nullptr);
-        } else {
-            hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
-            // reference image in the layout the first level reads (levels 1/2 of the K <= 64 kernel: hi-only rows); rebuilt
-            // inside the level loop if the filter escalates to level 3
-            img_hi_only = (path == 1 && levels[0] < 3) ? 1 : 0;
-            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                               p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
-                               path == 3, img_hi_only, (const int *)nullptr, (float *)nullptr);
-            if (path == 1) {
-                p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, img_hi_only != 0);
-                p2.lds = cmk2::ring_depth(img_hi_only != 0) * p2.tileb + 64;
-            }
-            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d,
-                               p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr, path == 3, 0,
-                               (const int *)nullptr, (float *)nullptr);
-        }
-        CM_HIP(h, hipGetLastError());
-        cm_mark(h, 1);
-        cmk2::P1Args a;
-        a.Q = reinterpret_cast<const _Float16 *>(Qp);
-        a.R = Rp;
-        a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
-        a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
-        a.dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
-        a.ctr = nullptr;
-        a.perm_mul = 1;
-        g_dbg_ctr = nullptr;
-        if (a.dbg & 4) {
-            static unsigned long long *d_ctr = nullptr;
-            if (!d_ctr) (void)hipMalloc((void **)&d_ctr, 128);
-            (void)hipMemsetAsync(d_ctr, 0, 128, st);
-            a.ctr = d_ctr;
-            g_dbg_ctr = d_ctr;
-        }
-        c_eps = 0.f;  // split-fp16 kernels: set per level below
-        // low-d kernel: relative bound of the fp32 direct sum (sign of c_eps selects the certificate form)
-        if (path == 2) c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;
-        for (int li = 0; li < n_levels; ++li) {
-            const int nprod = levels[li];
-            level_used = nprod;
-            if (path == 1 || path == 3) { Kc = k + knn_slack_level(k, nprod); a.Kc = Kc; }
-            a.nprod = nprod;
-            // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
-            c_split = (path == 1 || path == 3) ? (nprod == 1 ? 2.0f : (nprod == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f : 0.f;
-            if (path == 1 || path == 3) {
-                // Error of the products that ARE evaluated, relative to |y'|^2 + 2|q'||y'|:
-                //  * accumulation: one v_mfma_f32_32x32x16_f16 returns C + sum of 16 exact products with an error of at most
-                //    16*2^-24*max|product| (alignment of the addends, truncated below 2^-24 of the largest one in each
-                //    half of 8) + 2*2^-24*(|C| + sum|products|) (roundings when the halves and C are combined).  Over a
-                //    chain of n instructions: (16 + 2n)*2^-24*(sum of all magnitudes).  This model of the instruction is
-                //    validated on the device by tests/test_gpu_parity.py::test_mfma_f16_accumulation_bound (observed
-                //    maximum 8*2^-24 at n = 24); the certificate uses TWICE the bound.
-                //  * representation: dropped lo*lo product and the residuals of the two-term splits (3*2^-22), fp32
-                //    rounding of the centred, scaled coordinates (2*2^-24), times 1.01 for the second-order terms.
-                const int n_instr = p2.KSTEPS * nprod + (path == 3 ? 1 : 0);   // K = 128 kernel: + the fp32 add of |y|^2
-                c_eps = 2.0f * (float)(16 + 2 * n_instr) * 5.9604645e-8f + 8.4e-7f;
-            }
-            if (li > 0) hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
-            if (path == 1 || path == 3) {
-                const int hi_only = (path == 1 && nprod < 3) ? 1 : 0;
-                if (hi_only != img_hi_only) {   // (re)build the reference tile image in the layout this level reads
-                    hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref,
-                                       d, p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr,
-                                       words, path == 3, hi_only, (const int *)nullptr, (float *)nullptr);
-                    img_hi_only = hi_only;
-                    if (path == 1) {
-                        p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, hi_only != 0);
-                        p2.lds = cmk2::ring_depth(hi_only != 0) * p2.tileb + 64;
-                    }
-                }
-            }
-            if (path == 2) CM_TRY(cm_p1lowd_launch(h, lowd_dpad(d), p2.grid, p2.lds, a));
-            else if (path == 3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
-            else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
-            cm_mark(h, 2);
-            if (li + 1 == n_levels) break;
-            // not the last level: re-rank now and look at how many queries failed the certificate
-            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                               S, Kc, k, metric, form, qnorm, words, c_eps, c_split, scale3, (const double *)d_mean, idx_offset,
-                               flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0, (const int *)nullptr);
-            cm_mark(h, 3);
-            CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-            CM_HIP(h, hipStreamSynchronize(st));
-            const int64_t nflag = h->d_nflag_pinned[0];
-            const int64_t tolerated = nq / 2000 > 64 ? nq / 2000 : 64;
-            if (nflag <= tolerated) { reranked = true; break; }
-        }
-    } else {
-        float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
-        float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
-        if (!Rp || !Qp) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-        hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
-                           p.KP, p.nref_pad, 1, metric, Rp, (float *)nullptr, words);
-        hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, p.KP,
-                           p.nq_pad, 0, metric, Qp, qnorm, (unsigned *)nullptr);
-        CM_HIP(h, hipGetLastError());
-        cm_mark(h, 1);
-        dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
-        cm_status s = CM_E_INTERNAL;
-        bool ok = cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
-                  cm_p1_launch_g1(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
-                  cm_p1_launch_g2(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
-                  cm_p1_launch_g3(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s);
-        if (!ok) CM_FAIL(h, CM_E_INTERNAL, "k-NN: no phase-1 instantiation for KP=%d", p.KP);
-        CM_TRY(s);
-        // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
-        c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
-    }
-    if (!f16) cm_mark(h, 2);
-    if (f16 && g_dbg_ctr) {
-        unsigned long long hc[16] = {0};
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(hc, g_dbg_ctr, 128, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu event_cycles=%llu barrier_cycles=%llu dma_wait_cycles=%llu mfma_cluster_cycles=%llu\n",
-                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9]);
-    }
-    if (f16 && getenv("CELLMAP_DBG") && (atoi(getenv("CELLMAP_DBG")) & 3)) return CM_OK;  // timing experiments: phase 1 only
-    if (!reranked)
-        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
-                           S, Kc, k, metric, form, qnorm, words, c_eps, c_split,
-                           (path == 1 || path == 3) ? scale3 : (const float *)nullptr, (const double *)d_mean, idx_offset,
-                           flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0, (const int *)nullptr);
-    if (!reranked) cm_mark(h, 3);
+    hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                       p.KP, p.nref_pad, 1, metric, Rp, (float *)nullptr, words);
+    hipLaunchKernelGGL(prep_rows<T>, dim3((unsigned)((p.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, p.KP,
+                       p.nq_pad, 0, metric, Qp, qnorm, (unsigned *)nullptr);
+    CM_HIP(h, hipGetLastError());
+    cm_mark(h, 1);
+    dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
+    cm_status s = CM_E_INTERNAL;
+    bool ok = cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+              cm_p1_launch_g1(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+              cm_p1_launch_g2(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+              cm_p1_launch_g3(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s);
+    if (!ok) CM_FAIL(h, CM_E_INTERNAL, "k-NN: no phase-1 instantiation for KP=%d", p.KP);
+    CM_TRY(s);
+    cm_mark(h, 2);
+    // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
+    const float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
+    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
+                       S, Kc, k, metric, form, qnorm, words, c_eps, 0.f, (const float *)nullptr, (const double *)nullptr,
+                       idx_offset, flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0,
+                       (const float *)nullptr, 0, (const int *)nullptr);
+    cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
         int rc = (int)(52 * 1024 / ((size_t)d * sizeof(T)));   // rows per staged chunk
@@ -1317,8 +1179,8 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = Kc;
-    h->knn_stats[2] = S + 100 * ((path == 1 || path == 3) ? level_used : 0);
-    h->knn_stats[3] = path == 1 ? 2 : (path == 2 ? 3 : (path == 3 ? 4 : 1));
+    h->knn_stats[2] = S;
+    h->knn_stats[3] = 1;
     return CM_OK;
 }
 

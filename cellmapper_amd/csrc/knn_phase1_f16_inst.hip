@@ -58,5 +58,7 @@ static cm_status launch_f16w(cm_handle_t h, int grid, size_t lds, const cmk2::P1
 }
 
 cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    return a.nprod >= 3 ? launch_f16w<true>(h, grid, lds, a) : launch_f16w<false>(h, grid, lds, a);
+    // (the hi*hi level of the K = 128 family runs on knn_cand_f16<8, 1>; this kernel is its three-product level)
+    if (a.nprod < 3) CM_FAIL(h, CM_E_INTERNAL, "phase1/f16w: only the three-product level is instantiated");
+    return launch_f16w<true>(h, grid, lds, a);
 }
