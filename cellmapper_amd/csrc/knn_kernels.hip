@@ -178,7 +178,11 @@ template <typename T>
 __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KSTEPS, int64_t n_pad, int is_ref, int metric,
                               const float *__restrict__ scale3, const double *__restrict__ mean, char *__restrict__ P,
                               float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only,
-                              const int *__restrict__ rowmap, float *__restrict__ rowlo) {
+                              const int *__restrict__ rowmap, float *__restrict__ rowlo,
+                              const double *__restrict__ cen = nullptr, const int *__restrict__ blk_bucket = nullptr,
+                              float *__restrict__ rownorm_c = nullptr, float *__restrict__ rowcen = nullptr) {
+    // cen != nullptr (bucket-centred queries, knn_cand_f16<.,1,true>): the row is prepared as q' - cen[bucket of its
+    // 512-query block]; rownorm stays |q'|, rownorm_c = |q' - c|, rowcen = |c|; rowmap entries < 0 are padding (zero row).
     // rowlo (queries): |lo part of the row| in input units -- the certificate of filter level 1 bounds the dropped
     // lo(query)*hi(ref) product with the query's ACTUAL lo norm (typically a third of the worst case 2^-11 |q'|);
     // reference rows: gmax[5] = max over rows of |lo part| / |row| (same purpose, dropped hi(query)*lo(ref)).
@@ -197,21 +201,28 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
         const int f = is_ref ? cmk2::swz_b(r, ROWB) : 0;
         double nscale = 1.0;
         // rowmap (queries only): prepare row i from source row rowmap[i] (query subsets of the staged search)
-        const T *x = X + ((rowmap && i < n) ? (int64_t)rowmap[i] : i) * d;
+        const bool live = i < n && !(rowmap && rowmap[i] < 0);
+        const T *x = X + ((rowmap && live) ? (int64_t)rowmap[i] : (live ? i : 0)) * d;
+        const double *cj = (cen && blk_bucket) ? cen + (size_t)blk_bucket[i / cmk2::QB] * d : nullptr;
         double s2 = 0.0;  // squared norm of the centred (cosine: normalised, then centred) row
-        if (i < n) {
+        double s2c = 0.0, c2 = 0.0;   // centred mode: |q' - c|^2, |c|^2
+        if (live) {
             if (metric == CM_METRIC_COSINE) {
                 double s = 0.0;
                 for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
                 double nrm = sqrt(s);
                 nscale = nrm > 0.0 ? 1.0 / nrm : 1.0;
             }
-            for (int c = 0; c < d; ++c) { double v = (double)x[c] * nscale - mean[c]; s2 = fma(v, v, s2); }
+            for (int c = 0; c < d; ++c) {
+                double v = (double)x[c] * nscale - mean[c];
+                s2 = fma(v, v, s2);
+                if (cj) { const double w = v - cj[c]; s2c = fma(w, w, s2c); c2 = fma(cj[c], cj[c], c2); }
+            }
         }
         // norm digits / query constants for slots d, d+1, d+2
         float slot[3];
         if (is_ref) {
-            if (i < n) {
+            if (live) {
                 double N = s2 * (double)sc * (double)sc;
                 _Float16 a1 = (_Float16)(float)(N * 0x1p-15);
                 double r1 = N - (double)(float)a1 * 0x1p15;
@@ -234,8 +245,8 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                 int c = g * 8 + e;
                 _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
                 if (c < d) {
-                    if (i < n) {
-                        float v = (float)((double)x[c] * nscale - mean[c]) * mul;
+                    if (live) {
+                        float v = (float)((double)x[c] * nscale - mean[c] - (cj ? cj[c] : 0.0)) * mul;
                         h = (_Float16)v;
                         l = (_Float16)(v - (float)h);
                         lo2 = fma((double)(float)l, (double)(float)l, lo2);
@@ -249,15 +260,17 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
             *reinterpret_cast<cmk2::half8 *>(rowp + ((g ^ f) * 16)) = hi;
             if (!(is_ref && hi_only)) *reinterpret_cast<cmk2::half8 *>(rowp + (((GRAN / 2 + g) ^ f) * 16)) = lo;
         }
-        yn_f = (i < n) ? (float)s2 : 0.f;
+        yn_f = live ? (float)s2 : 0.f;
         if (yn_block && is_ref) {
             float *ynp = reinterpret_cast<float *>(P + tile * TILEB + (size_t)cmk2::BR * ROWB);
-            ynp[r] = (i < n) ? (float)(s2 * (double)sc * (double)sc) : INFINITY;
+            ynp[r] = live ? (float)(s2 * (double)sc * (double)sc) : INFINITY;
             if (r == 0) for (int e = cmk2::BR; e < 256; ++e) ynp[e] = 0.f;
         }
         if (rownorm && i < n) rownorm[i] = sqrtf(yn_f) * 1.0000002f;
         if (rowlo && i < n) rowlo[i] = (float)(sqrt(lo2) / (double)sc) * 1.000001f;
-        if (is_ref && i < n && s2 > 0.0) lo_ratio = (float)(sqrt(lo2) / (2.0 * (double)sc * sqrt(s2))) * 1.000001f;
+        if (rownorm_c && i < n) rownorm_c[i] = (float)sqrt(s2c) * 1.000001f;
+        if (rowcen && i < n) rowcen[i] = (float)sqrt(c2) * 1.000001f;
+        if (is_ref && live && s2 > 0.0) lo_ratio = (float)(sqrt(lo2) / (2.0 * (double)sc * sqrt(s2))) * 1.000001f;
     }
     if (is_ref && gmax) {
         float m = yn_f, lr = lo_ratio;
@@ -343,7 +356,10 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    int64_t *__restrict__ out_idx, int *__restrict__ flag_list,
                                                    int *__restrict__ flag_cnt, double *__restrict__ bound,
                                                    const int *__restrict__ qmap, int pilot_kc,
-                                                   const float *__restrict__ qlo, int level, const int *__restrict__ rmap) {
+                                                   const float *__restrict__ qlo, int level, const int *__restrict__ rmap,
+                                                   const float *__restrict__ qnc = nullptr,
+                                                   const float *__restrict__ qcen = nullptr) {
+    // qnc / qcen != nullptr (bucket-centred filter): |q' - c| and |c| of every packed row; qmap entries < 0 are padding.
     // qmap != nullptr: the nq rows of cand / cthr / qnorm belong to the query SUBSET qmap[0..nq) (staged search);
     // the query row, the outputs, the bound and the flag entry use the original index io.
     // pilot_kc > 0 (pilot of the staged search): a small sample runs with many reference splits, whose union of
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     if (i >= nq) return;
     if (lane == 0) { s_kc[w] = INFINITY; s_kth[w] = INFINITY; }   // (fewer than k valid candidates: bound = inf)
     const int64_t io = qmap ? (int64_t)qmap[i] : i;
+    if (io < 0) return;   // padding row of the bucket-aligned packing
     double *q = s_q[w];
     for (int c = lane; c < d; c += 64) q[c] = (double)qry[io * d + c];
     __builtin_amdgcn_wave_barrier();
@@ -419,7 +436,15 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             const double ymax2 = ymax * ymax;
             // c_eps: accumulation / representation error on every term; c_split: split products that were dropped
             double eps = (double)c_eps * (ymax2 + 2.0 * qn * ymax + 1e-30);
-            if (qlo) {
+            if (qnc) {
+                // bucket-centred filter: the MFMA chain accumulates |y'|^2 digits, the side value -2c.y' (float32, one
+                // rounding of a float64 dot product) and the products of q'' = q' - c with y': magnitudes
+                // Y^2 + 2|c|Y + 2|q''|Y; the dropped lo products involve q'' only
+                const double qc = (double)qnc[i], cn = (double)qcen[i];
+                const double rho_y = (double)__uint_as_float(gmax[5]);
+                eps = (double)c_eps * (ymax2 + 2.0 * (cn + qc) * ymax + 1e-30) + 2.4e-7 * cn * ymax +
+                      2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qc * rho_y : 0.0));
+            } else if (qlo) {
                 // dropped split products with the ACTUAL lo norms (Cauchy-Schwarz): level 1 drops lo(q).hi(y) and
                 // hi(q).lo(y), level 2 only the latter; |hi(.)| <= (1 + 2^-11)|.|; gmax[5] = max |lo(y')| / |y'|
                 const double rho_y = (double)__uint_as_float(gmax[5]);
@@ -744,7 +769,7 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
 // neighbourhood and a tile holds reference rows of one neighbourhood: candidates arrive in bursts that one append event
 // handles together, instead of one event per stray value.  Pure scheduling: which rows share a tile or a wave has no
 // influence on the result.
-constexpr int LS_CMAX = 64;    // pivots
+constexpr int LS_CMAX = 256;   // pivots
 constexpr int LS_ROWS = 4096;  // rows per workgroup of the bucketing kernels
 constexpr int LS_DSUB = 16;    // leading coordinates used for the bucketing (one 64-byte line per row; for PCA embeddings
                                // these carry most of the cluster structure -- any partition is valid, this one is cheap)
@@ -787,6 +812,13 @@ __global__ void ls_offsets(const int *__restrict__ counts, int C, int *__restric
         for (int c = 0; c < C; ++c) { cursor[c] = run; run += counts[c]; }
     }
 }
+__global__ void ls_starts(const int *__restrict__ counts, int C, int *__restrict__ start /* C + 1 */) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < C; ++c) { start[c] = run; run += counts[c]; }
+        start[C] = run;
+    }
+}
 __global__ __launch_bounds__(256) void ls_scatter(const int *__restrict__ label, int64_t n, int *__restrict__ cursor,
                                                   int *__restrict__ perm) {
     __shared__ int hist[LS_CMAX], base[LS_CMAX];
@@ -803,6 +835,82 @@ __global__ __launch_bounds__(256) void ls_scatter(const int *__restrict__ label,
     for (int rr = 0; rr < LS_ROWS / 256; ++rr) {
         const int64_t i = r0 + rr * 256 + threadIdx.x;
         if (i < n) { const int c = label[i]; perm[base[c] + atomicAdd(&hist[c], 1)] = (int)i; }
+    }
+}
+
+// ------------------------------------------------------------------ bucket-centred queries -----------
+// (knn_cand_f16<., 1, true>)  Buckets are those of the locality sort.  cen_centroid: mean of the bucket's prepared
+// (centred, cosine: normalised) query rows in float64.  cen_pack: packed query order in which no 512-query block
+// straddles two buckets (-1 = padding).  cen_side: for every bucket and every row of the (sorted, padded) reference
+// image the float32 value -2 sc^2 c_bucket . y'_row, accumulated in float64.
+template <typename T>
+__global__ __launch_bounds__(256) void cen_centroid(const T *__restrict__ Q, int d, int metric, const double *__restrict__ mean,
+                                                    const int *__restrict__ qperm, const int *__restrict__ bstart,
+                                                    double *__restrict__ cen) {
+    __shared__ double s_acc[4][64];
+    const int j = blockIdx.x, e = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int lo = bstart[j], hi = bstart[j + 1];
+    double acc = 0.0;
+    if (e < d)
+        for (int r = lo + rl; r < hi; r += 4) {
+            const T *x = Q + (int64_t)qperm[r] * d;
+            double ns = 1.0;
+            if (metric == CM_METRIC_COSINE) {
+                double s = 0.0;
+                for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+                const double nrm = sqrt(s);
+                ns = nrm > 0.0 ? 1.0 / nrm : 1.0;
+            }
+            acc += (double)x[e] * ns - mean[e];
+        }
+    s_acc[rl][e] = acc;
+    __syncthreads();
+    if (rl == 0 && e < d) cen[(size_t)j * d + e] = hi > lo ? (s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]) / (double)(hi - lo) : 0.0;
+}
+
+__global__ void cen_pack(const int *__restrict__ qperm, const int *__restrict__ bstart, const int *__restrict__ pstart, int C,
+                         int64_t n_packed, int *__restrict__ qpack, int *__restrict__ blk_bucket) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_packed) return;
+    int j = 0;
+    while (j + 1 < C && (int64_t)pstart[j + 1] <= i) ++j;   // C <= 64: linear search
+    const int64_t off = i - pstart[j];
+    qpack[i] = off < (int64_t)(bstart[j + 1] - bstart[j]) ? qperm[bstart[j] + off] : -1;
+    if ((i % cmk2::QB) == 0) blk_bucket[i / cmk2::QB] = j;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cen_side(const T *__restrict__ R, int64_t n_ref, int d, int metric,
+                                                const double *__restrict__ mean, const int *__restrict__ rperm,
+                                                const double *__restrict__ cen, int C, const float *__restrict__ scale3,
+                                                int64_t stride, float *__restrict__ side) {
+    extern __shared__ double s_cen[];   // [C][d]
+    for (int t = threadIdx.x; t < C * d; t += blockDim.x) s_cen[t] = cen[t];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= stride) return;
+    double y[64];
+    const bool live = r < n_ref;
+    if (live) {
+        const T *x = R + (int64_t)(rperm ? rperm[r] : r) * d;
+        double ns = 1.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) { double v = (double)x[c]; s = fma(v, v, s); }
+            const double nrm = sqrt(s);
+            ns = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 64; ++c) y[c] = c < d ? (double)x[c] * ns - mean[c] : 0.0;
+    }
+    const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
+    for (int j = 0; j < C; ++j) {
+        double dot = 0.0;
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) if (c < d) dot = fma(s_cen[j * d + c], y[c], dot);
+        }
+        side[(size_t)j * stride + r] = (float)(m2 * dot);
     }
 }
 
@@ -838,17 +946,18 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                            !(getenv("CELLMAP_LOWD") && !strcmp(getenv("CELLMAP_LOWD"), "brute"));
     const int dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
     int forced = getenv("CELLMAP_FILTER_PRODUCTS") ? atoi(getenv("CELLMAP_FILTER_PRODUCTS")) : 0;
-    if (forced < 1 || forced > 4 || (forced == 4 && !have_direct) || lowp) forced = 0;
+    if (forced < 1 || forced > 5 || (forced == 4 && !have_direct) || lowp) forced = 0;   // (5 = bucket-centred hi*hi level)
     if (wide && forced == 2) forced = 3;   // the K = 128 family has no two-product kernel
 
     KnnPlan2 pf;   // plan of the full query set at level 1 (widest candidate lists): sizes the buffers
     CM_TRY(make_plan2(h, n_ref, nq, d, k, 1, 1, &pf));
-    const int Kc_max = pf.Kc;
+    const int Kc_max = pf.Kc + 16;   // (+16: the bucket-centred level uses k + max(30, k) candidates)
     const int64_t nq_pad = pf.nq_pad;
     // subsets may use more reference splits than the full set: rows of the candidate buffers
     const int64_t cand_rows = std::max<int64_t>(nq_pad * pf.S, nq_pad + (int64_t)cmk2::QB * 512);
-    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);
-    float *qlo = (float *)cm_ws_alloc(h, sizeof(float) * nq_pad);   // |lo part| of every prepared query row
+    const int64_t pack_slack = (int64_t)LS_CMAX * cmk2::QB;   // bucket-aligned packing pads every bucket to whole blocks
+    float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));
+    float *qlo = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));   // |lo part| of every prepared query row
     int *cand = (int *)cm_ws_alloc(h, sizeof(int) * cand_rows * Kc_max);
     float *cthr = (float *)cm_ws_alloc(h, sizeof(float) * cand_rows);
     int *flag_a = (int *)cm_ws_alloc(h, sizeof(int) * (nq + 1));
@@ -862,7 +971,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
     // any tile image: <= 256 B per row (K <= 64) / 512 B per row + side block (K = 128)
     char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (wide ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
-    char *Qp = (char *)cm_ws_alloc(h, (size_t)nq_pad * (wide ? 512 : 256));
+    char *Qp = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * (wide ? 512 : 256));
     uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * Kc_max);
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
@@ -885,7 +994,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipGetLastError());
     // locality sort (see ls_assign): permutation of the reference rows for the tile images, of the queries for the order
     // in which full-set stages pack them into waves
-    int *rperm = nullptr, *qperm = nullptr;
+    int *rperm = nullptr, *qperm = nullptr, *q_bstart = nullptr, *q_bcount = nullptr;
     if (!lowp && n_ref >= 65536 && nq >= 4096 && !getenv("CELLMAP_NO_SORT")) {
         const int C = LS_CMAX;
         int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
@@ -903,8 +1012,20 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             hipLaunchKernelGGL(ls_offsets, dim3(1), dim3(64), 0, st, cnt_c, C, cnt_c + LS_CMAX);
             hipLaunchKernelGGL(ls_scatter, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, lab, nn, cnt_c + LS_CMAX, perm);
         }
+        // query buckets: [start of bucket j in qperm] for the centred mode (cnt_c still holds the query counts)
+        q_bstart = (int *)cm_ws_alloc(h, sizeof(int) * (LS_CMAX + 1));
+        q_bcount = cnt_c;
+        if (!q_bstart) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        hipLaunchKernelGGL(ls_starts, dim3(1), dim3(64), 0, st, cnt_c, C, q_bstart);
         CM_HIP(h, hipGetLastError());
     }
+    // bucket-centred hi*hi level (level 5): state built on first use
+    // (worth it from ~131k queries on: every bucket is padded to whole 512-query blocks; smaller sets only when forced)
+    const bool have_cen = rperm && !wide && !lowp && !getenv("CELLMAP_NO_CENTRE") && (nq >= 131072 || forced == 5);
+    int *qpack = nullptr, *blk_bucket = nullptr;
+    double *cen = nullptr;
+    float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
+    int64_t n_packed = 0, side_stride = 0;
     // level 0 state: the grid over the reference rows is built on first use
     void *grid_info = nullptr;
     int64_t *grid_start = nullptr;
@@ -924,7 +1045,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int img = -1;          // reference image currently in Rp: 0 full [hi|lo] tiles, 1 hi-only tiles, 2 direct (fp32 rows)
     int last_Kc = Kc_max, last_S = 1;
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
-    auto run_stage = [&](int level, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
+    auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
+        int level = level_in;
         if (level == 0) {   // uniform-grid candidate search (d <= 3): same outputs as a filter kernel, one list per query
             if (!grid_info) CM_TRY(cm_grid_build<T>(h, d_ref, n_ref, d, k, &grid_info, &grid_start, &grid_xyz, &grid_idx));
             const int Kc0 = k + knn_slack(k);
@@ -941,10 +1063,16 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (marks) cm_mark(h, 3);
             return CM_OK;
         }
+        const bool cenl = level == 5;   // bucket-centred hi*hi level: the filter arithmetic of level 1
+        if (cenl) level = 1;
         KnnPlan2 p2;
         const bool w3 = wide && level >= 3;   // K = 128, three products: knn_cand_f16w (256-query blocks, full rows)
         CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : (w3 ? 3 : 1), level == 4 ? 3 : level, &p2));
         if (wide) p2.KSTEPS = cmk2::KSTEPS_W;
+        if (cenl) {   // the centred level keeps a wider candidate list: its residual error is dominated by bucket quality
+            const int kc2 = k + (k > 30 ? k : 30);
+            if (kc2 <= Kc_max + 16 && kc2 + 2 * cmk2::CL <= 512) p2.Kc = kc2;
+        }
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
         if (img != want) {
@@ -963,10 +1091,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         } else {
             hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
                                p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr,
-                               wide ? 1 : 0, 0, qmap, qlo);
+                               wide ? 1 : 0, 0, qmap, qlo, cenl ? (const double *)cen : (const double *)nullptr,
+                               cenl ? (const int *)blk_bucket : (const int *)nullptr, cenl ? qnc : (float *)nullptr,
+                               cenl ? qcen : (float *)nullptr);
             if (!w3) {   // (knn_cand_f16w keeps the plan of make_plan2: 2-deep ring of full tiles)
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
-                p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * p2.tileb + 64;
+                p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * (p2.tileb + (cenl ? 1024 : 0)) + 64;
             }
         }
         if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
@@ -977,6 +1107,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
         a.dbg = dbg; a.ctr = d_ctr;
+        if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !getenv("CELLMAP_NO_PERM")) {   // knn_cand_f16: scattered tile order
             unsigned long long pm = (unsigned long long)((double)p2.n_tiles * 0.6180339887498949) | 1ull;
@@ -1006,7 +1137,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                            p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
                            idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
-                           level == 4 ? (const float *)nullptr : (const float *)qlo, level, (const int *)rperm);
+                           level == 4 ? (const float *)nullptr : (const float *)qlo, level, (const int *)rperm,
+                           cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr);
         CM_HIP(h, hipGetLastError());
         if (marks) cm_mark(h, 3);
         return CM_OK;
@@ -1018,20 +1150,59 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         return CM_OK;
     };
 
+    // bucket-centred mode: packed query order, bucket centroids, side values (one host read of the 64 bucket counts)
+    auto setup_centred = [&]() -> cm_status {
+        if (qpack) return CM_OK;
+        const int C = LS_CMAX;
+        int hcount[LS_CMAX], hps[LS_CMAX + 1];
+        CM_HIP(h, hipMemcpyAsync(hcount, q_bcount, sizeof(int) * C, hipMemcpyDeviceToHost, st));
+        CM_HIP(h, hipStreamSynchronize(st));
+        int64_t run = 0;
+        for (int j = 0; j < C; ++j) { hps[j] = (int)run; run += ((int64_t)hcount[j] + cmk2::QB - 1) / cmk2::QB * cmk2::QB; }
+        hps[C] = (int)run;
+        n_packed = run;
+        side_stride = (int64_t)pf.n_tiles * cmk2::BR + 256;
+        int *pstart = (int *)cm_ws_alloc(h, sizeof(int) * (C + 1));
+        qpack = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_packed);
+        blk_bucket = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)(n_packed / cmk2::QB + 1));
+        cen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * d);
+        side = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)C * side_stride);
+        qnc = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
+        qcen = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
+        if (!pstart || !qpack || !blk_bucket || !cen || !side || !qnc || !qcen) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        CM_HIP(h, hipMemcpyAsync(pstart, hps, sizeof(int) * (C + 1), hipMemcpyHostToDevice, st));
+        CM_HIP(h, hipStreamSynchronize(st));   // (hps lives on this stack frame)
+        hipLaunchKernelGGL(cen_centroid<T>, dim3(C), dim3(256), 0, st, d_qry, d, metric, (const double *)d_mean, (const int *)qperm,
+                           (const int *)q_bstart, cen);
+        hipLaunchKernelGGL(cen_pack, dim3((unsigned)((n_packed + 255) / 256)), dim3(256), 0, st, (const int *)qperm, (const int *)q_bstart,
+                           (const int *)pstart, C, n_packed, qpack, blk_bucket);
+        const size_t lds_c = sizeof(double) * (size_t)C * d;
+        auto sidek = cen_side<T>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(sidek), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        hipLaunchKernelGGL(sidek, dim3((unsigned)((side_stride + 255) / 256)), dim3(256), lds_c, st, d_ref, n_ref, d, metric,
+                           (const double *)d_mean, (const int *)rperm, (const double *)cen, C, (const float *)scale3, side_stride, side);
+        CM_HIP(h, hipGetLastError());
+        return CM_OK;
+    };
+
     // ---- choose the level the whole set starts at
     int start = lowp ? (have_grid ? 0 : 4) : 1;
-    const bool hinted = h->staged_hint_level == 1 && h->staged_hint_d == d && h->staged_hint_k == k &&
-                        h->staged_hint_metric == metric && !getenv("CELLMAP_NO_HINT");
+    const bool hint_ok = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
+                         !getenv("CELLMAP_NO_HINT");
+    const bool hinted = hint_ok && (h->staged_hint_level == 1 || (h->staged_hint_level == 5 && have_cen));
+    const bool cen_bad = hint_ok && h->staged_hint_level == -5;   // the centred level failed for most queries last time
     if (lowp) {}   // grid or direct kernel: nothing to choose
     else if (forced) start = forced;
     else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
-    else if (hinted) start = 1;   // level 1 certified most queries last time: no pilot
+    else if (hinted) start = h->staged_hint_level;   // that level certified most queries last time: no pilot
     else if (n_pilot > 0 && !(dbg & 3)) {
         hipLaunchKernelGGL(strided_rows, dim3((n_pilot + 255) / 256), dim3(256), 0, st, sample, n_pilot, nq / n_pilot);
         int64_t nf = 0;
         CM_TRY(run_stage(1, sample, n_pilot, flag_b, true, false, true));
         CM_TRY(read_flags(&nf));
-        if (nf * 2 > n_pilot) {   // level 1 would fail for more than half: not worth its time
+        if (nf * 2 > n_pilot && have_cen && !cen_bad) {
+            start = 5;   // the cancellation that defeats level 1 shrinks with the bucket radius: try it centred
+        } else if (nf * 2 > n_pilot) {   // level 1 would fail for more than half: not worth its time
             CM_TRY(run_stage(3, sample, n_pilot, flag_b, true, false, true));
             CM_TRY(read_flags(&nf));
             start = (have_direct && nf * 5 > (int64_t)n_pilot * 4) ? 4 : 3;
@@ -1039,8 +1210,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     }
 
     // ---- the ladder
-    const int *qmap = qperm;   // full set: in locality-sorted order (nullptr = as given)
-    int64_t nsub = nq;
+    if (start == 5 && !have_cen) start = 1;
+    if (start == 5) CM_TRY(setup_centred());
+    const int *qmap = start == 5 ? (const int *)qpack : (const int *)qperm;   // full set: bucket-packed / locality-sorted order
+    int64_t nsub = start == 5 ? n_packed : nq;
     int *flag_out = flag_a;
     int level = start, main_Kc = Kc_max, main_S = 1;
     for (int stage = 0;; ++stage) {
@@ -1048,13 +1221,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (stage == 0) { main_Kc = last_Kc; main_S = last_S; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
         const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0
-                         : (level == 0 ? 4 : (level == 4 ? 0 : (level < 3 ? 3 : (have_direct ? 4 : 0))));
+                         : (level == 0 ? 4 : (level == 4 ? 0 : ((level < 3 || level == 5) ? 3 : (have_direct ? 4 : 0))));
         if (!next) break;
         int64_t nf = 0;
         CM_TRY(read_flags(&nf));
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
-            const bool good = level == 1 && nf * 2 <= nsub;
-            h->staged_hint_level = good ? 1 : 0;
+            const bool good = (level == 1 || level == 5) && nf * 2 <= nq;
+            h->staged_hint_level = good ? level : (level == 5 ? -5 : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
         }
         if (dbg & 16) {
@@ -1201,8 +1374,12 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
+        b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
         b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
+        if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
+            b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
+                 cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
     } else {
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;

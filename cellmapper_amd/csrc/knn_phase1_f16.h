@@ -87,7 +87,10 @@ struct P1Args {
                            // (~2^-11), 1 = hi*hi only (~2^-10); the certificate in knn_rerank uses the matching bound
     int dbg;               // timing experiments only (CELLMAP_DBG): 1 = never append, 2 = skip the filter, 4 = counters
     unsigned long long *ctr;  // [16] debug counters (dbg & 4): branches, appends, prunes, prune cycles, wave cycles
-    unsigned perm_mul;     // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
+    const float *side = nullptr;     // centred mode (knn_cand_f16<.,1,true>): [n_buckets][side_stride] float32 -2 sc^2 c_bucket . y'_row
+    const int *blk_bucket = nullptr; // centred mode: bucket of every 512-query block
+    long long side_stride = 0; // centred mode: floats per bucket row (padded image rows + 256)
+    unsigned perm_mul = 1; // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
                            // n_tiles; 0/1 = identity).  A scattered visiting order keeps the streaming thresholds
                            // representative when the reference rows are sorted (by cluster, batch, ...)
 };
@@ -429,15 +432,22 @@ __device__ __forceinline__ void min_step(int I, const f32x16 &P0, const f32x16 &
 
 // NP = number of split products evaluated: 3 = hi*hi + hi*lo(query) + lo(ref)*hi (needs the lo halves of the reference
 // rows), 2 = hi*hi + hi*lo(query), 1 = hi*hi.  For NP < 3 the lo fragments' registers double-buffer the hi fragments.
-template <int KSTEPS, int NP>
+// CEN (hi*hi level, K <= 64): bucket-centred queries.  The B operand holds q'' = q' - c (c = centroid of the bucket all 512
+// queries of the work item belong to); the missing term -2 sc^2 c.y' is a float32 side value per (bucket, reference row),
+// computed in float64 beforehand (knn_kernels.hip: cen_side) and copied per tile next to the rows like the |y|^2 side
+// block of K = 128: it initialises the accumulators.  Every error term of the filter then scales with the radius of the
+// bucket instead of the distance of the query from the global mean.
+template <int KSTEPS, int NP, bool CEN = false>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr bool LO3 = NP == 3;
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = img_row_bytes(KSTEPS, !LO3);
     constexpr int GRAN = row_bytes(KSTEPS) / 16;   // granules of a full row; hi = [0, GRAN/2), lo = [GRAN/2, GRAN)
-    constexpr bool SIDE = KSTEPS >= 8;     // |y|^2 in a side block of the tile image instead of spare feature slots
-    static_assert(!(SIDE && LO3), "K = 128 runs level 3 on knn_cand_f16w");
-    constexpr int TILEB = img_tile_bytes(KSTEPS, !LO3);
+    constexpr bool SIDE = KSTEPS >= 8 || CEN;   // a float32 per row initialises the accumulators (|y|^2, or the centring term)
+    static_assert(!(SIDE && LO3), "K = 128 runs level 3 on knn_cand_f16w; centring is implemented for the hi*hi level");
+    static_assert(!(CEN && (KSTEPS >= 8 || NP != 1)), "centred mode: K <= 64, hi*hi level");
+    constexpr int GTILEB = img_tile_bytes(KSTEPS, !LO3);      // stride of the tile images in global memory
+    constexpr int TILEB = GTILEB + (CEN ? 1024 : 0);          // stride of the LDS ring (CEN: + the side block)
     constexpr int ROWS_B = BR * ROWB;      // bytes of the rows of a tile; SIDE: followed by BR floats sc^2|y|^2
     constexpr int RING = ring_depth(!LO3, KSTEPS);
     constexpr int AHEAD = RING - 1;   // the DMA pieces of tile t + AHEAD are issued during tile t
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     // wave-instruction copies one contiguous KiB.  Wave w moves pieces w, w+NW, ...
 #define CM2_DMA_TILE(t_, buf_)                                                                                  \
     {                                                                                                           \
-        const char *gsrc_ = a.R + (size_t)(t_) * TILEB;               /* uniform: scalar base + one 32-bit VGPR */ \
+        const char *gsrc_ = a.R + (size_t)(t_) * GTILEB;              /* uniform: scalar base + one 32-bit VGPR */ \
         unsigned char *ldst_ = ring + (buf_) * TILEB + wave * 1024;                                             \
         _Pragma("unroll") for (int q_ = 0; q_ < NCHUNK / NW; ++q_)                                              \
             __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + q_ * (NW * 1024) + dma_voff),       \
@@ -470,11 +480,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     }
     // the side block (1 KiB) is one more piece, copied by wave 0
 #define CM2_DMA_SIDE(t_, buf_)                                                                                  \
-    __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(a.R + (size_t)(t_) * TILEB + ROWS_B + lane * 16),  \
-                                     (CM2_AS3 void *)(ring + (buf_) * TILEB + ROWS_B), 16, 0, 0)
+    __builtin_amdgcn_global_load_lds(                                                                           \
+        (const CM2_AS1 void *)(CEN ? reinterpret_cast<const char *>(side_row + (size_t)(t_) * BR) + lane * 16   \
+                                   : a.R + (size_t)(t_) * GTILEB + ROWS_B + lane * 16),                         \
+        (CM2_AS3 void *)(ring + (buf_) * TILEB + ROWS_B), 16, 0, 0)
 #define CM2_DMA_PIECE(t_, buf_, q_)                                                                             \
     __builtin_amdgcn_global_load_lds(                                                                           \
-        (const CM2_AS1 void *)(a.R + (size_t)(t_) * TILEB + (q_) * (NW * 1024) + dma_voff),                     \
+        (const CM2_AS1 void *)(a.R + (size_t)(t_) * GTILEB + (q_) * (NW * 1024) + dma_voff),                    \
         (CM2_AS3 void *)(ring + (buf_) * TILEB + wave * 1024 + (q_) * (NW * 1024)), 16, 0, 0)
     static_assert(NCHUNK % NW == 0, "every wave copies the same number of 1-KiB pieces");
     constexpr int NPIECE = NCHUNK / NW;    // DMA pieces per wave and tile
@@ -493,6 +505,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         const int t0 = split * a.tiles_per_split;
         const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
         const int64_t qbase = (int64_t)qb * QB + wave * 64;
+        // CEN: side values of this work item's bucket, one float per row of the (padded) reference image
+        const float *side_row = CEN ? a.side + (size_t)a.blk_bucket[qb] * (size_t)a.side_stride : nullptr;
+        (void)side_row;
 
         // ---- query fragments (B operand): lane (c,hh), k-step s -> granule 2s+hh of the hi / lo half
         constexpr int KL = NP >= 2 ? KSTEPS : 1;   // the lo fragments of the queries are only needed from two products on

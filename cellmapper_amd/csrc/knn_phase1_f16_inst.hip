@@ -2,9 +2,9 @@
 #include "cm_internal.h"
 #include "knn_phase1_f16.h"
 
-template <int KSTEPS, int NP>
+template <int KSTEPS, int NP, bool CEN = false>
 static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    auto kern = cmk2::knn_cand_f16<KSTEPS, NP>;
+    auto kern = cmk2::knn_cand_f16<KSTEPS, NP, CEN>;
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
     CM_HIP(h, hipGetLastError());
@@ -12,6 +12,11 @@ static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1A
 }
 
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
+    if (a.side) {   // bucket-centred hi*hi level
+        if (a.nprod == 1 && KSTEPS == 2) return launch_f16<2, 1, true>(h, grid, lds, a);
+        if (a.nprod == 1 && KSTEPS == 4) return launch_f16<4, 1, true>(h, grid, lds, a);
+        CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: centred mode exists for the hi*hi level at K <= 64 only");
+    }
     switch (KSTEPS) {
 #define CM_F16_CASE(ks_)                                                                \
     case ks_:                                                                           \

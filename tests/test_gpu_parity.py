@@ -333,6 +333,32 @@ def test_every_filter_level_is_exact_for_every_kernel_width(hip, oracle, monkeyp
         assert np.array_equal(idx, oi) and np.array_equal(dist, od), (d, level, hip.knn_stats())
 
 
+@pytest.mark.parametrize("sigma,metric", [(1.0, "euclidean"), (0.3, "euclidean"), (1.0, "cosine")])
+def test_bucket_centred_level_is_exact(hip, oracle, monkeypatch, sigma, metric):
+    """The bucket-centred hi*hi level (CELLMAP_FILTER_PRODUCTS=5; chosen by the pilot for >= 131k clustered queries):
+    queries packed by bucket, q' - c in the B operand, float64-computed side values as accumulator init.  Pinned here on a
+    smaller clustered problem; results must equal the oracle and the plain path bit for bit."""
+    rng = np.random.default_rng(53)
+    d, k, n_ref, nq = 50, 15, 70000, 8192
+    cen = rng.standard_normal((20, d)) * 5.0
+    ref = (cen[rng.integers(0, 20, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 20, nq)] + sigma * rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    d0, i0 = hip.knn(ref, qry, k, metric=metric)
+    monkeypatch.setenv("CELLMAP_FILTER_PRODUCTS", "5")
+    d1, i1 = hip.knn(ref, qry, k, metric=metric)
+    st = hip.knn_stats()
+    assert st["filter_products"] == 5, st
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1), st
+    if metric == "euclidean":
+        od, oi = oracle.knn_euclidean(ref, qry[:2048], k)
+        assert np.array_equal(i1[:2048], oi) and np.array_equal(d1[:2048], od), st
+        # the point of centring: far fewer uncertified queries than the plain hi*hi level leaves behind
+        monkeypatch.setenv("CELLMAP_FILTER_PRODUCTS", "1")
+        hip.knn(ref, qry, k)
+        assert st["fallback_queries"] <= hip.knn_stats()["fallback_queries"], (st, hip.knn_stats())
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
