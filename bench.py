@@ -158,7 +158,8 @@ def main():
                  else "knn_cand_mfma (v_mfma_f32_32x32x2_f32 distance GEMM + fused top-k filter)")
         # the split-fp16 kernel executes 1-3 MFMA products over the feature dimension padded to a multiple of 16 (+3 slots)
         kpad = 128 if fb["lowd_path"] == 4 else (32 if a.d + 3 <= 32 else 64)
-        nprod = min(3, max(1, fb.get("filter_products", 3)))  # split products of the level the query set started at (4 = direct VALU filter)
+        lvl = fb.get("filter_products", 3)   # level the query set started at: 1-3 split products, 4 = direct VALU filter,
+        nprod = 1 if lvl == 5 else min(3, max(1, lvl))   # 5 = bucket-centred hi*hi
         executed = (nprod * 2.0 * qry.shape[0] * (hi - lo) * kpad if f16_path
                     else 2.0 * qry.shape[0] * (hi - lo) * (4 * ((a.d + 4) // 4)))
         traffic = None
