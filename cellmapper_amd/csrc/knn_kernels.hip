@@ -366,12 +366,18 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     // candidate lists certifies far more easily than the single list of pilot_kc candidates the full run will keep.
     // The flag then answers "would a single list of pilot_kc candidates have been certified?": the threshold is
     // emulated by the exact value of the pilot_kc-th best candidate of the union, less the filter error.
-    __shared__ double s_q[4][RR_DMAX];
-    __shared__ double s_v[4][RR_NCMAX];
-    __shared__ int s_i[4][RR_NCMAX];
-    __shared__ double s_kth[4];
-    __shared__ double s_kc[4];
+    // dynamic LDS sized by the candidate count (rerank_lds_bytes): a fixed RR_NCMAX-sized layout holds the kernel to two
+    // workgroups per CU, too few to hide the latency of the candidate gathers
+    extern __shared__ __align__(16) unsigned char rr_smem[];
+    const int ncp = (S * Kc + 1) & ~1;
+    double(*s_q)[RR_DMAX] = reinterpret_cast<double(*)[RR_DMAX]>(rr_smem);
+    double *s_vb = reinterpret_cast<double *>(rr_smem + sizeof(double) * 4 * RR_DMAX);
+    int *s_ib = reinterpret_cast<int *>(s_vb + 4 * ncp);
+    double *s_kth = reinterpret_cast<double *>(s_ib + 4 * ncp);
+    double *s_kc = s_kth + 4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    struct Row2 { double *v; int *i; };
+    const Row2 s_vw{s_vb + (size_t)w * ncp, s_ib + (size_t)w * ncp};
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= nq) return;
     if (lane == 0) { s_kc[w] = INFINITY; s_kth[w] = INFINITY; }   // (fewer than k valid candidates: bound = inf)
@@ -389,15 +395,15 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (j >= 0 && rmap) j = rmap[j];   // candidate positions refer to the locality-sorted tile image
         double v = INFINITY;
         if (j >= 0) v = pair_value<T>(q, xn, ref + (int64_t)j * d, d, metric, form);
-        s_v[w][s] = v;
-        s_i[w][s] = j >= 0 ? j : 0x7fffffff;
+        s_vw.v[s] = v;
+        s_vw.i[s] = j >= 0 ? j : 0x7fffffff;
     }
     __builtin_amdgcn_wave_barrier();
     for (int s = lane; s < nc; s += 64) {
-        double v = s_v[w][s];
-        int id = s_i[w][s];
+        double v = s_vw.v[s];
+        int id = s_vw.i[s];
         int rk = 0;
-        for (int j = 0; j < nc; ++j) rk += pair_before(s_v[w][j], s_i[w][j], v, id) ? 1 : 0;
+        for (int j = 0; j < nc; ++j) rk += pair_before(s_vw.v[j], s_vw.i[j], v, id) ? 1 : 0;
         if (rk < k) {
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
@@ -477,6 +483,11 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             bound[io] = kth;
         }
     }
+}
+
+static inline size_t rerank_lds_bytes(int S, int Kc) {
+    const int ncp = (S * Kc + 1) & ~1;
+    return sizeof(double) * 4 * RR_DMAX + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
 }
 
 // ------------------------------------------------------------------ exact fallback ------------------
@@ -1055,7 +1066,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             CM_TRY(cm_grid_query<T>(h, d_qry, nsub, d, qmap, grid_info, grid_start, grid_xyz, grid_idx, k, Kc0, words, cand, cthr));
             if (marks) cm_mark(h, 2);
             last_Kc = Kc0; last_S = 1;
-            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
+            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rerank_lds_bytes(1, Kc0), st, d_ref, d_qry, nsub, d, cand, cthr,
                                1, Kc0, k, metric, form, qnorm, words, -(float)(d + 4) * 2.0f * 5.9604645e-8f, 0.f,
                                (const float *)nullptr, (const double *)nullptr, idx_offset, flags, d_out_dist, d_out_idx, flag_out,
                                (int *)(words + 2), bound, qmap, 0, (const float *)nullptr, 0, (const int *)nullptr);
@@ -1133,7 +1144,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
             c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
         }
-        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nsub, d, cand, cthr,
+        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rerank_lds_bytes(p2.S, p2.Kc), st, d_ref, d_qry, nsub, d, cand, cthr,
                            p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
                            idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
@@ -1326,7 +1337,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     cm_mark(h, 2);
     // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
     const float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
-    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, d_ref, d_qry, nq, d, cand, cthr,
+    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), rerank_lds_bytes(S, Kc), st, d_ref, d_qry, nq, d, cand, cthr,
                        S, Kc, k, metric, form, qnorm, words, c_eps, 0.f, (const float *)nullptr, (const double *)nullptr,
                        idx_offset, flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0,
                        (const float *)nullptr, 0, (const int *)nullptr);
