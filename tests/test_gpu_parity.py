@@ -359,6 +359,23 @@ def test_bucket_centred_level_is_exact(hip, oracle, monkeypatch, sigma, metric):
         assert st["fallback_queries"] <= hip.knn_stats()["fallback_queries"], (st, hip.knn_stats())
 
 
+def test_pilot_selects_centred_level_for_large_clustered_sets(hip, oracle, monkeypatch):
+    """From 131 072 queries on, a clustered set for which the plain hi*hi level fails makes the pilot start the whole set
+    on the bucket-centred level (no forcing here); spot-checked against the oracle."""
+    rng = np.random.default_rng(59)
+    d, k, n_ref, nq = 50, 15, 70000, 140000
+    cen = rng.standard_normal((25, d)) * 5.0
+    ref = (cen[rng.integers(0, 25, n_ref)] + 0.5 * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 25, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["filter_products"] == 5, st
+    sel = rng.choice(nq, 1500, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
