@@ -21,6 +21,7 @@ struct cm_handle_s {
     // staged search: the filter level that certified most queries on the previous call with this (d, k, metric); lets
     // repeated calls on similar data skip the pilot (a stale hint only costs time: the ladder still escalates)
     int staged_hint_level = 0, staged_hint_d = 0, staged_hint_k = 0, staged_hint_metric = 0;
+    int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    const int *__restrict__ qmap, int pilot_kc,
                                                    const float *__restrict__ qlo, int level, const int *__restrict__ rmap,
                                                    const float *__restrict__ qnc = nullptr,
-                                                   const float *__restrict__ qcen = nullptr) {
+                                                   const float *__restrict__ qcen = nullptr, int ncap = 0) {
+    // ncap > 0 (bucket pruning: many lists per query, most of them empty): the LDS holds ncap candidates; the valid
+    // entries of the lists are compacted first, a query with more than ncap of them is left to the next stage.
     // qnc / qcen != nullptr (bucket-centred filter): |q' - c| and |c| of every packed row; qmap entries < 0 are padding.
     // qmap != nullptr: the nq rows of cand / cthr / qnorm belong to the query SUBSET qmap[0..nq) (staged search);
     // the query row, the outputs, the bound and the flag entry use the original index io.
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     // dynamic LDS sized by the candidate count (rerank_lds_bytes): a fixed RR_NCMAX-sized layout holds the kernel to two
     // workgroups per CU, too few to hide the latency of the candidate gathers
     extern __shared__ __align__(16) unsigned char rr_smem[];
-    const int ncp = (S * Kc + 1) & ~1;
+    const int cap = ncap > 0 ? ncap : S * Kc;
+    const int ncp = (cap + 1) & ~1;
     double(*s_q)[RR_DMAX] = reinterpret_cast<double(*)[RR_DMAX]>(rr_smem);
     double *s_vb = reinterpret_cast<double *>(rr_smem + sizeof(double) * 4 * RR_DMAX);
     int *s_ib = reinterpret_cast<int *>(s_vb + 4 * ncp);
@@ -388,11 +391,24 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     __builtin_amdgcn_wave_barrier();
     double xn = 0.0;
     for (int c = 0; c < d; ++c) xn = fma(q[c], q[c], xn);
-    const int nc = S * Kc;
-    const int *cq = cand + i * nc;
+    const int nc_all = S * Kc;
+    const int *cq = cand + i * nc_all;
+    int nc = 0;   // valid candidates, compacted to the front
+    for (int s0 = 0; s0 < nc_all; s0 += 64) {
+        const int s = s0 + lane;
+        const int j = s < nc_all ? cq[s] : -1;
+        const bool ok = j >= 0;
+        const unsigned long long m = __ballot(ok);
+        const int p = nc + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && p < cap) s_vw.i[p] = j;
+        nc += __popcll(m);
+    }
+    const bool over = nc > cap;
+    if (over) nc = cap;
+    __builtin_amdgcn_wave_barrier();
     for (int s = lane; s < nc; s += 64) {
-        int j = cq[s];
-        if (j >= 0 && rmap) j = rmap[j];   // candidate positions refer to the locality-sorted tile image
+        int j = s_vw.i[s];
+        if (rmap) j = rmap[j];   // candidate positions refer to the locality-sorted tile image
         double v = INFINITY;
         if (j >= 0) v = pair_value<T>(q, xn, ref + (int64_t)j * d, d, metric, form);
         s_vw.v[s] = v;
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             double eps = crel * big + 2.0 * dlt * sqrt((double)d) * sqrt(big) + (double)d * dlt * dlt;
             certified = sk + eps < (double)tau - eps;
         }
-        if (!certified || (flags & CM_KNN_FORCE_FALLBACK)) {
+        if (!certified || over || (flags & CM_KNN_FORCE_FALLBACK)) {
             int pos = atomicAdd(flag_cnt, 1);
             flag_list[pos] = (int)io;
             bound[io] = kth;
@@ -784,14 +800,58 @@ constexpr int LS_CMAX = 256;   // pivots
 constexpr int LS_ROWS = 4096;  // rows per workgroup of the bucketing kernels
 constexpr int LS_DSUB = 16;    // leading coordinates used for the bucketing (one 64-byte line per row; for PCA embeddings
                                // these carry most of the cluster structure -- any partition is valid, this one is cheap)
+__global__ void strided_rows(int *__restrict__ out, int n, int64_t stride);
+// Bucket numbering: a greedy nearest-neighbour chain through the pivots, so that buckets with consecutive numbers are
+// neighbours in space.  Query blocks and reference tiles that straddle two buckets then still cover one neighbourhood
+// (bucket pruning bounds every block and bucket by a ball).  One wave; order[p] = pivot at chain position p.
+template <typename T>
+__global__ __launch_bounds__(64) void ls_chain(const T *__restrict__ pivsrc, int64_t piv_stride, int d, int C,
+                                               int *__restrict__ order) {
+    __shared__ float piv[LS_CMAX][LS_DSUB];
+    const int lane = threadIdx.x;
+    const int ds = d < LS_DSUB ? d : LS_DSUB;
+    for (int t = lane; t < C * LS_DSUB; t += 64) {
+        const int c = t / LS_DSUB, e = t % LS_DSUB;
+        piv[c][e] = e < ds ? (float)pivsrc[(int64_t)c * piv_stride * d + e] : 0.f;
+    }
+    __syncthreads();
+    bool used[LS_CMAX / 64];   // lane owns pivots lane + 64*i
+#pragma unroll
+    for (int i = 0; i < LS_CMAX / 64; ++i) used[i] = lane + 64 * i >= C;
+    int cur = 0;
+    if (lane == 0) { order[0] = 0; used[0] = true; }
+    for (int p = 1; p < C; ++p) {
+        float best = INFINITY;
+        int bc = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < LS_CMAX / 64; ++i) {
+            const int c = lane + 64 * i;
+            if (used[i]) continue;
+            float sacc = 0.f;
+#pragma unroll
+            for (int e = 0; e < LS_DSUB; ++e) { const float t = piv[c][e] - piv[cur][e]; sacc = fmaf(t, t, sacc); }
+            if (sacc < best || (sacc == best && c < bc)) { best = sacc; bc = c; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oc = __shfl_xor(bc, o);
+            if (ob < best || (ob == best && oc < bc)) { best = ob; bc = oc; }
+        }
+        cur = bc;
+        if (lane == (cur & 63)) used[cur >> 6] = true;
+        if (lane == 0) order[p] = cur;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ls_assign(const T *__restrict__ X, int64_t n, int d, const T *__restrict__ pivsrc,
-                                                 int64_t piv_stride, int C, int *__restrict__ label, int *__restrict__ counts) {
+                                                 int64_t piv_stride, int C, int *__restrict__ label, int *__restrict__ counts,
+                                                 const int *__restrict__ order) {
     __shared__ float ls_piv[LS_CMAX][LS_DSUB];
     const int ds = d < LS_DSUB ? d : LS_DSUB;
     for (int t = threadIdx.x; t < C * LS_DSUB; t += blockDim.x) {
         const int c = t / LS_DSUB, e = t % LS_DSUB;
-        ls_piv[c][e] = e < ds ? (float)pivsrc[(int64_t)c * piv_stride * d + e] : 0.f;
+        ls_piv[c][e] = e < ds ? (float)pivsrc[(int64_t)order[c] * piv_stride * d + e] : 0.f;
     }
     __shared__ int ls_hist[LS_CMAX];
     if (threadIdx.x < LS_CMAX) ls_hist[threadIdx.x] = 0;
@@ -925,6 +985,217 @@ __global__ __launch_bounds__(256) void cen_side(const T *__restrict__ R, int64_t
     }
 }
 
+// ------------------------------------------------------------------ bucket pruning (exact) -----------
+// The locality sort leaves the reference image grouped by bucket and the queries packed by bucket, so whole
+// (query block, reference bucket) pairs can be ruled out with the triangle inequality before any product is formed:
+//   every query of block b lies within r_b of its centre c_b, every row of bucket j within rho_j of its centre m_j, so
+//   all their squared distances are >= LB_bj^2, LB_bj = |c_b - m_j| - r_b - rho_j.
+// Pass A runs the filter of every block over its nearest bucket only; the K'-th candidate of a query there is an upper
+// bound D_q on its k-th neighbour distance (its filter threshold, plus |q'|^2, plus the filter's error bound).  Pass B
+// then visits, for every block, only the buckets with LB_bj^2 <= max_q D_q, as contiguous tile runs of the sorted
+// image, each run with its own candidate list; its thresholds start at the pass-A threshold.  A skipped row has
+// d^2 >= LB^2 > D_q >= (k-th neighbour distance)^2, so it cannot be among the k nearest, whatever the filter would have
+// said about it; for the rows that were visited the usual certificate (min over the lists' thresholds) applies.
+// Nothing here depends on how good the buckets are: bad buckets only mean nothing is skipped.
+constexpr int IVF_SB = 13;      // pass-B runs (candidate lists) per query block; slot 0 is pass A
+constexpr int IVF_CSTR = 64;    // doubles per centre (d <= 61 on this path)
+
+// bounding ball of a group of prepared rows (centred at the reference mean; cosine: normalised first): group g holds
+// the rows map[lo..hi), lo/hi from gstart or (gstart == nullptr) 512-row blocks of map[0..n_map); map entries < 0 skip
+template <typename T>
+__global__ __launch_bounds__(256) void ivf_ball(const T *__restrict__ X, int d, int metric, const double *__restrict__ mean,
+                                                const int *__restrict__ map, const int *__restrict__ gstart, int64_t n_map,
+                                                double *__restrict__ cen, double *__restrict__ rad, int *__restrict__ cnt) {
+    __shared__ double s_acc[4][64];
+    __shared__ double s_c[64];
+    __shared__ double s_r[4];
+    __shared__ int s_n[4];
+    const int g = blockIdx.x, e = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t lo = gstart ? (int64_t)gstart[g] : (int64_t)g * cmk2::QB;
+    int64_t hi = gstart ? (int64_t)gstart[g + 1] : lo + cmk2::QB;
+    if (hi > n_map) hi = n_map;
+    const double me = e < d ? mean[e] : 0.0;
+    double acc = 0.0;
+    int n = 0;
+    for (int64_t r = lo + w; r < hi; r += 4) {
+        const int src = map ? map[r] : (int)r;
+        if (src < 0) continue;   // (wave-uniform)
+        double v = e < d ? (double)X[(int64_t)src * d + e] : 0.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s2 = v * v;
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const double nrm = sqrt(s2);
+            v *= nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+        acc += e < d ? v - me : 0.0;
+        ++n;
+    }
+    s_acc[w][e] = acc;
+    if (e == 0) s_n[w] = n;
+    __syncthreads();
+    const int ntot = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    if (w == 0) s_c[e] = ntot ? (s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]) / (double)ntot : 0.0;
+    __syncthreads();
+    const double ce = s_c[e];
+    double rmax = 0.0;
+    for (int64_t r = lo + w; r < hi; r += 4) {
+        const int src = map ? map[r] : (int)r;
+        if (src < 0) continue;
+        double v = e < d ? (double)X[(int64_t)src * d + e] : 0.0;
+        if (metric == CM_METRIC_COSINE) {
+            double s2 = v * v;
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            const double nrm = sqrt(s2);
+            v *= nrm > 0.0 ? 1.0 / nrm : 1.0;
+        }
+        const double t = e < d ? v - me - ce : 0.0;
+        double s2 = t * t;
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        rmax = fmax(rmax, s2);
+    }
+    if (e == 0) s_r[w] = rmax;
+    __syncthreads();
+    if (w == 0) cen[(size_t)g * IVF_CSTR + e] = e < d ? ce : 0.0;
+    if (threadIdx.x == 0) {
+        rad[g] = sqrt(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3]))) * (1.0 + 1e-9);
+        cnt[g] = ntot;
+    }
+}
+
+// pass A: one work item per query block over the tiles of the nearest bucket that holds at least min_rows rows
+__global__ __launch_bounds__(256) void ivf_plan_a(const double *__restrict__ bcen, const double *__restrict__ rcen,
+                                                  const int *__restrict__ r_bstart, int C, int d, int min_rows, int n_tiles,
+                                                  int4 *__restrict__ wl, int *__restrict__ jstar) {
+    __shared__ double s_d[256];
+    __shared__ int s_j[256];
+    const int b = blockIdx.x, j = threadIdx.x;
+    double dist = INFINITY;
+    if (j < C && r_bstart[j + 1] - r_bstart[j] >= min_rows) {
+        double s2 = 0.0;
+        for (int c = 0; c < d; ++c) { const double t = bcen[(size_t)b * IVF_CSTR + c] - rcen[(size_t)j * IVF_CSTR + c]; s2 = fma(t, t, s2); }
+        dist = s2;
+    }
+    s_d[j] = dist;
+    s_j[j] = j;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (j < o && s_d[j + o] < s_d[j]) { s_d[j] = s_d[j + o]; s_j[j] = s_j[j + o]; }
+        __syncthreads();
+    }
+    if (j == 0) {
+        int js = s_d[0] < INFINITY ? s_j[0] : -1;
+        int t0 = 0, t1 = n_tiles;
+        if (js >= 0) { t0 = r_bstart[js] / cmk2::BR; t1 = (r_bstart[js + 1] + cmk2::BR - 1) / cmk2::BR; }
+        wl[b] = make_int4(b, t0, t1, 0);
+        jstar[b] = js;
+    }
+}
+
+// pass B: the tile runs every query block still has to visit (see the section comment).  counters[0] = work items,
+// counters[2..3] = 64-bit count of the tiles visited by both passes (the caller compares it with a full scan).
+__global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bcen, const double *__restrict__ brad,
+                                                  const double *__restrict__ rcen, const double *__restrict__ rrad,
+                                                  const int *__restrict__ r_bstart, int C, int d,
+                                                  const int *__restrict__ qmap, int64_t nsub, const float *__restrict__ cthr,
+                                                  int S, const float *__restrict__ qnorm, const float *__restrict__ qlo,
+                                                  const float *__restrict__ qnc, const float *__restrict__ qcen,
+                                                  const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
+                                                  float c_eps, int level, const int4 *__restrict__ wl_a,
+                                                  const int *__restrict__ jstar, int4 *__restrict__ wl_b,
+                                                  int *__restrict__ counters) {
+    __shared__ double s_red[256];
+    __shared__ unsigned char s_need[256];
+    __shared__ int s_u0[132], s_u1[132];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // D = max over the block's live queries of (pass-A threshold in input units + |q'|^2 + filter error bound)
+    const double ymax = (double)__uint_as_float(gmax[1]);
+    const double rho_y = (double)__uint_as_float(gmax[5]);
+    double dm = 0.0;
+    for (int64_t i = (int64_t)b * cmk2::QB + tid; i < (int64_t)(b + 1) * cmk2::QB && i < nsub; i += 256) {
+        if (qmap && qmap[i] < 0) continue;
+        const float tau = cthr[i * S];
+        double D = INFINITY;
+        if (tau < INFINITY) {
+            const double qn = (double)qnorm[i];
+            double eps;   // the re-rank's bound (knn_rerank) with the global |y'| maximum
+            if (qnc) {
+                const double qc = (double)qnc[i], cn = (double)qcen[i];
+                eps = (double)c_eps * (ymax * ymax + 2.0 * (cn + qc) * ymax + 1e-30) + 2.4e-7 * cn * ymax +
+                      2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qc * rho_y : 0.0));
+            } else {
+                eps = (double)c_eps * (ymax * ymax + 2.0 * qn * ymax + 1e-30) +
+                      2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qn * rho_y : 0.0));
+            }
+            D = (double)tau * (double)scale3[2] + qn * qn + eps;
+        }
+        dm = fmax(dm, D);
+    }
+    s_red[tid] = dm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] = fmax(s_red[tid], s_red[tid + o]);
+        __syncthreads();
+    }
+    const double Dmax = s_red[0];
+    const int js = jstar[b];
+    bool need = false;
+    if (tid < C && r_bstart[tid + 1] > r_bstart[tid]) {
+        double s2 = 0.0;
+        for (int c = 0; c < d; ++c) { const double t = bcen[(size_t)b * IVF_CSTR + c] - rcen[(size_t)tid * IVF_CSTR + c]; s2 = fma(t, t, s2); }
+        const double lb = sqrt(s2) * (1.0 - 1e-9) - (brad[b] + rrad[tid]) * (1.0 + 1e-9);
+        need = !(lb > 0.0 && lb * lb > Dmax * (1.0 + 1e-6) + 1e-30);
+    }
+    s_need[tid] = need ? 1 : 0;
+    __syncthreads();
+    if (tid != 0) return;
+    const int a0 = wl_a[b].y, a1 = wl_a[b].z;
+    if (js < 0) {   // pass A already visited every tile
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)(a1 - a0));
+        return;
+    }
+    // maximal runs of needed buckets, in tiles (neighbouring buckets share their boundary tile)
+    int nr = 0;
+    for (int j = 0; j < C; ++j) {
+        if (!s_need[j]) continue;
+        const int t0 = r_bstart[j] / cmk2::BR, t1 = (r_bstart[j + 1] + cmk2::BR - 1) / cmk2::BR;
+        if (nr > 0 && t0 <= s_u1[nr - 1]) { if (t1 > s_u1[nr - 1]) s_u1[nr - 1] = t1; }
+        else { s_u0[nr] = t0; s_u1[nr] = t1; ++nr; }
+    }
+    // minus the tiles of pass A
+    int p0[134], p1[134];
+    int np = 0;
+    for (int r = 0; r < nr; ++r) {
+        const int u0 = s_u0[r], u1 = s_u1[r];
+        if (u1 <= a0 || u0 >= a1) { p0[np] = u0; p1[np] = u1; ++np; continue; }
+        if (u0 < a0) { p0[np] = u0; p1[np] = a0; ++np; }
+        if (u1 > a1) { p0[np] = a1; p1[np] = u1; ++np; }
+    }
+    // at most IVF_SB runs: close the smallest gaps (never the one that holds the pass-A tiles)
+    while (np > IVF_SB) {
+        int bi = -1, bg = 0x7fffffff;
+        for (int i = 0; i + 1 < np; ++i) {
+            const int gap = p0[i + 1] - p1[i];
+            if (p1[i] <= a0 && p0[i + 1] >= a1) continue;
+            if (gap < bg) { bg = gap; bi = i; }
+        }
+        if (bi < 0) break;   // (cannot happen: at most one gap is excluded and IVF_SB >= 2)
+        p1[bi] = p1[bi + 1];
+        for (int i = bi + 1; i + 1 < np; ++i) { p0[i] = p0[i + 1]; p1[i] = p1[i + 1]; }
+        --np;
+    }
+    long long tiles = a1 - a0;
+    if (np > 0) {
+        const int base = atomicAdd(&counters[0], np);
+        for (int i = 0; i < np; ++i) { wl_b[base + i] = make_int4(b, p0[i], p1[i], 1 + i); tiles += p1[i] - p0[i]; }
+    }
+    atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)tiles);
+}
+
+__global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ void strided_rows(int *__restrict__ out, int n, int64_t stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)(i * stride);
@@ -1005,21 +1276,27 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipGetLastError());
     // locality sort (see ls_assign): permutation of the reference rows for the tile images, of the queries for the order
     // in which full-set stages pack them into waves
-    int *rperm = nullptr, *qperm = nullptr, *q_bstart = nullptr, *q_bcount = nullptr;
+    int *rperm = nullptr, *qperm = nullptr, *q_bstart = nullptr, *q_bcount = nullptr, *r_bstart = nullptr;
     if (!lowp && n_ref >= 65536 && nq >= 4096 && !getenv("CELLMAP_NO_SORT")) {
         const int C = LS_CMAX;
         int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
         int *cnt_c = (int *)cm_ws_alloc(h, sizeof(int) * 2 * LS_CMAX);
         rperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_ref);
         qperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nq);
-        if (!lab || !cnt_c || !rperm || !qperm) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        r_bstart = (int *)cm_ws_alloc(h, sizeof(int) * (LS_CMAX + 1));
+        if (!lab || !cnt_c || !rperm || !qperm || !r_bstart) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         auto assign = ls_assign<T>;
+        int *b_order = (int *)cm_ws_alloc(h, sizeof(int) * LS_CMAX);
+        if (!b_order) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        hipLaunchKernelGGL(ls_chain<T>, dim3(1), dim3(64), 0, st, d_ref, n_ref / C, d, C, b_order);
+        if (getenv("CELLMAP_NO_CHAIN")) hipLaunchKernelGGL(strided_rows, dim3(1), dim3(256), 0, st, b_order, C, (int64_t)1);   // (experiments)
         for (int side = 0; side < 2; ++side) {
             const T *X = side ? d_qry : d_ref;
             const int64_t nn = side ? nq : n_ref;
             int *perm = side ? qperm : rperm;
             CM_HIP(h, hipMemsetAsync(cnt_c, 0, sizeof(int) * 2 * LS_CMAX, st));
-            hipLaunchKernelGGL(assign, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, X, nn, d, d_ref, n_ref / C, C, lab, cnt_c);
+            hipLaunchKernelGGL(assign, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, X, nn, d, d_ref, n_ref / C, C, lab, cnt_c, (const int *)b_order);
+            if (side == 0) hipLaunchKernelGGL(ls_starts, dim3(1), dim3(64), 0, st, cnt_c, C, r_bstart);   // (bucket pruning)
             hipLaunchKernelGGL(ls_offsets, dim3(1), dim3(64), 0, st, cnt_c, C, cnt_c + LS_CMAX);
             hipLaunchKernelGGL(ls_scatter, dim3((unsigned)((nn + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, lab, nn, cnt_c + LS_CMAX, perm);
         }
@@ -1037,6 +1314,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     double *cen = nullptr;
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
     int64_t n_packed = 0, side_stride = 0;
+    // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
+    const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
+    if (!hint_same) h->staged_ivf_skip = 0;
+    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && !getenv("CELLMAP_NO_IVF");
+    if (ivf_try && h->staged_ivf_skip > 0 && !getenv("CELLMAP_NO_HINT")) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
+    const int ivf_S = IVF_SB + 1;
+    double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
+    int *ivf_rcnt = nullptr, *ivf_bcnt = nullptr, *ivf_jstar = nullptr, *ivf_ctr = nullptr, *ivf_cand = nullptr;
+    int4 *ivf_wla = nullptr, *ivf_wlb = nullptr;
+    float *ivf_cthr = nullptr;
+    int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
     // level 0 state: the grid over the reference rows is built on first use
     void *grid_info = nullptr;
     int64_t *grid_start = nullptr;
@@ -1127,14 +1415,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             a.perm_mul = (unsigned)pm;
         }
         last_Kc = p2.Kc; last_S = p2.S;
-        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
-        if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
-        if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
-        else if (w3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
-        else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
-        if (marks) cm_mark(h, 2);
-        if (!rerank) return CM_OK;
-        const int pilot_kc = pilot ? p2.Kc : 0;
+        // error-bound constants of this level (knn_rerank; the pruning plan bounds the pass-A thresholds with them too)
         float c_eps, c_split = 0.f;
         if (level == 4) {
             c_eps = -(float)(d + 4) * 2.0f * 5.9604645e-8f;   // relative bound of the fp32 direct sum (knn_rerank)
@@ -1144,12 +1425,92 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
             c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
         }
-        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rerank_lds_bytes(p2.S, p2.Kc), st, d_ref, d_qry, nsub, d, cand, cthr,
-                           p2.S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
+        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+        if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
+        const int *rr_cand = cand;
+        const float *rr_cthr = cthr;
+        int rr_S = p2.S, rr_ncap = 0;
+        bool pruned = false;
+        const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack);
+        if (ivf_try && full_set && !pilot && rerank && level != 4 && !w3 && 3 * p2.Kc <= RR_NCMAX && nsub >= 65536) {
+            // ---- bucket pruning: pass A over every block's nearest bucket, plan, pass B over what cannot be ruled out
+            const int C = LS_CMAX;
+            const int64_t nqb_max = (nq_pad + pack_slack) / cmk2::QB + 1;
+            if (!ivf_rcen) {
+                ivf_rcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * IVF_CSTR);
+                ivf_rrad = (double *)cm_ws_alloc(h, sizeof(double) * C);
+                ivf_rcnt = (int *)cm_ws_alloc(h, sizeof(int) * C);
+                ivf_bcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max * IVF_CSTR);
+                ivf_brad = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max);
+                ivf_bcnt = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
+                ivf_jstar = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
+                ivf_wla = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max);
+                ivf_wlb = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max * IVF_SB);
+                ivf_ctr = (int *)cm_ws_alloc(h, 64);
+                ivf_cand = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)(nq_pad + pack_slack) * ivf_S * Kc_max);
+                ivf_cthr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)(nq_pad + pack_slack) * ivf_S);
+                if (!ivf_rcen || !ivf_rrad || !ivf_rcnt || !ivf_bcen || !ivf_brad || !ivf_bcnt || !ivf_jstar || !ivf_wla || !ivf_wlb ||
+                    !ivf_ctr || !ivf_cand || !ivf_cthr)
+                    CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                hipLaunchKernelGGL(ivf_ball<T>, dim3(C), dim3(256), 0, st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm,
+                                   (const int *)r_bstart, n_ref, ivf_rcen, ivf_rrad, ivf_rcnt);
+            }
+            hipLaunchKernelGGL(ivf_ball<T>, dim3(p2.nqb), dim3(256), 0, st, d_qry, d, metric, (const double *)d_mean, qmap,
+                               (const int *)nullptr, nsub, ivf_bcen, ivf_brad, ivf_bcnt);
+            hipLaunchKernelGGL(ivf_plan_a, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_rcen,
+                               (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, ivf_wla, ivf_jstar);
+            const int64_t n_ent = (int64_t)p2.nq_pad * ivf_S;
+            CM_HIP(h, hipMemsetAsync(ivf_cand, 0xff, sizeof(int) * (size_t)n_ent * p2.Kc, st));
+            hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, ivf_cthr, n_ent, INFINITY);
+            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 8);
+            cmk2::P1Args b = a;
+            b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = ivf_S; b.perm_mul = 1;
+            b.wlist = ivf_wla; b.n_wlist = p2.nqb;
+            CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, b));
+            hipLaunchKernelGGL(ivf_plan_b, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
+                               (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, qmap, nsub,
+                               (const float *)ivf_cthr, ivf_S, (const float *)qnorm, (const float *)qlo,
+                               cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
+                               (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
+                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr);
+            CM_HIP(h, hipGetLastError());
+            int *hc = h->d_nflag_pinned + 4;
+            CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+            CM_HIP(h, hipStreamSynchronize(st));
+            unsigned long long tiles;
+            memcpy(&tiles, hc + 2, 8);
+            const unsigned long long full = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
+            if (dbg & 16)
+                fprintf(stderr, "[cellmap dbg] bucket pruning: %llu of %llu (block, tile) pairs to visit, %d pass-B runs for %d blocks\n",
+                        tiles, full, hc[0], p2.nqb);
+            if (tiles * 10ull <= full * 6ull) {
+                if (hc[0] > 0) {
+                    b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
+                    CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, b));
+                }
+                pruned = true;
+                rr_cand = ivf_cand; rr_cthr = ivf_cthr; rr_S = ivf_S; rr_ncap = 3 * p2.Kc;
+                ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
+            } else {
+                ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
+                h->staged_ivf_skip = 15;
+            }
+        }
+        if (!pruned) {
+            if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
+            else if (w3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
+            else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
+        }
+        if (marks) cm_mark(h, 2);
+        if (!rerank) return CM_OK;
+        const int pilot_kc = pilot ? p2.Kc : 0;
+        const size_t rr_lds = rr_ncap ? rerank_lds_bytes(1, rr_ncap) : rerank_lds_bytes(p2.S, p2.Kc);
+        hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rr_lds, st, d_ref, d_qry, nsub, d, rr_cand, rr_cthr,
+                           rr_S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
                            idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
                            level == 4 ? (const float *)nullptr : (const float *)qlo, level, (const int *)rperm,
-                           cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr);
+                           cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr, rr_ncap);
         CM_HIP(h, hipGetLastError());
         if (marks) cm_mark(h, 3);
         return CM_OK;
@@ -1287,7 +1648,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = main_Kc;
     h->knn_stats[2] = main_S + 100 * start;
-    h->knn_stats[3] = wide ? 4 : (lowp ? 3 : 2);
+    h->knn_stats[3] = (wide ? 4 : (lowp ? 3 : 2)) + 100 * ivf_pct;
     return CM_OK;
 }
 
@@ -1391,6 +1752,12 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
             b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
                  cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
+        if (d + cmk2::NORM_SLOTS <= 64 && nq >= 65536 && n_ref >= 65536) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
+            const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 512 + 1;
+            b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
+                 cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
+                 cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
+        }
     } else {
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;

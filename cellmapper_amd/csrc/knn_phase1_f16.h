@@ -90,6 +90,13 @@ struct P1Args {
     const float *side = nullptr;     // centred mode (knn_cand_f16<.,1,true>): [n_buckets][side_stride] float32 -2 sc^2 c_bucket . y'_row
     const int *blk_bucket = nullptr; // centred mode: bucket of every 512-query block
     long long side_stride = 0; // centred mode: floats per bucket row (padded image rows + 256)
+    // bucket pruning (knn_kernels.hip, ivf_*): explicit work list instead of (query block, split) pairs.  Item =
+    // (query block, first tile, end tile, candidate-list slot); n_wlist_dev (device) or n_wlist items.  thr0_slot0: the
+    // thresholds start at the final threshold of the query's slot-0 list (cthr[q * S]) instead of +inf.
+    const int4 *wlist = nullptr;
+    const int *n_wlist_dev = nullptr;
+    int n_wlist = 0;
+    int thr0_slot0 = 0;
     unsigned perm_mul = 1; // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
                            // n_tiles; 0/1 = identity).  A scattered visiting order keeps the streaming thresholds
                            // representative when the reference rows are sorted (by cluster, batch, ...)
@@ -499,11 +506,18 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
-    const int n_work = a.nqb * a.S;
+    const int n_work = a.wlist ? (a.n_wlist_dev ? *a.n_wlist_dev : a.n_wlist) : a.nqb * a.S;
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
-        const int qb = work / a.S, split = work - qb * a.S;
-        const int t0 = split * a.tiles_per_split;
-        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        int qb, split, t0, t1;
+        if (a.wlist) {
+            const int4 w_ = a.wlist[work];
+            qb = __builtin_amdgcn_readfirstlane(w_.x); t0 = __builtin_amdgcn_readfirstlane(w_.y);
+            t1 = __builtin_amdgcn_readfirstlane(w_.z); split = __builtin_amdgcn_readfirstlane(w_.w);
+        } else {
+            qb = work / a.S; split = work - qb * a.S;
+            t0 = split * a.tiles_per_split;
+            t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        }
         const int64_t qbase = (int64_t)qb * QB + wave * 64;
         // CEN: side values of this work item's bucket, one float per row of the (padded) reference image
         const float *side_row = CEN ? a.side + (size_t)a.blk_bucket[qb] * (size_t)a.side_stride : nullptr;
@@ -528,6 +542,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         for (int s = 0; s < KL; ++s) asm volatile("" ::"v"(ql[0][s]), "v"(ql[1][s]));
         const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
         float thr[2] = {thr_init, thr_init};
+        if (a.thr0_slot0) {
+            thr[0] = a.cthr[(qbase + c) * a.S];
+            thr[1] = a.cthr[(qbase + 32 + c) * a.S];
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));   // (the wait for these loads belongs here, not in the tile loop)
+        }
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
         int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
 

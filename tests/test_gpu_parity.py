@@ -376,6 +376,45 @@ def test_pilot_selects_centred_level_for_large_clustered_sets(hip, oracle, monke
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
+@pytest.mark.parametrize("metric,sigma,k", [("euclidean", 1.0, 30), ("euclidean", 0.3, 15), ("cosine", 1.0, 20)])
+def test_bucket_pruning_on_clustered_sets_is_exact(hip, oracle, monkeypatch, metric, sigma, k):
+    """Clustered sets of >= 65 536 queries: the main stage rules out far (query block, reference bucket) pairs with the
+    triangle inequality (ivf_* kernels) and visits a fraction of the tiles; results stay identical to the oracle."""
+    rng = np.random.default_rng(61)
+    d, n_ref, nq = 50, 150000, 80000
+    cen = rng.standard_normal((30, d)) * 5.0
+    ref = (cen[rng.integers(0, 30, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 30, nq)] + sigma * rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k, metric=metric)
+    st = hip.knn_stats()
+    assert 0 < st["tiles_visited_pct"] <= 60, st
+    sel = rng.choice(nq, 1200, replace=False)
+    if metric == "cosine":
+        od, oi = oracle.knn_cosine(ref, qry[sel], k)
+    else:
+        od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    if metric == "cosine":   # (float32 cosine distances of the oracle carry rounding noise: tie-aware comparison)
+        assert_knn_parity(dist[sel], idx[sel], od, oi, ref, qry[sel], "cosine")
+    else:
+        assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
+def test_bucket_pruning_backs_off_on_unclustered_sets(hip, oracle, monkeypatch):
+    """Isotropic data: nothing can be ruled out, the plan says so after pass A and the stage runs as a full scan."""
+    rng = np.random.default_rng(62)
+    d, k, n_ref, nq = 24, 10, 70000, 70000
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["tiles_visited_pct"] == 0, st
+    sel = rng.choice(nq, 1000, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
