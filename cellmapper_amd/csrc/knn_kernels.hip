@@ -985,6 +985,25 @@ __global__ __launch_bounds__(256) void cen_side(const T *__restrict__ R, int64_t
     }
 }
 
+// flag list of a stage (queries in the order the re-rank flagged them) -> the same queries grouped by bucket, so that
+// the 512-query blocks of the next stage are neighbourhoods again (bucket pruning of subset stages)
+__global__ __launch_bounds__(256) void fl_labels(const int *__restrict__ flag, int64_t n, const int *__restrict__ lab,
+                                                 int *__restrict__ lab_pos, int *__restrict__ counts) {
+    __shared__ int hist[LS_CMAX];
+    if (threadIdx.x < LS_CMAX) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int rr = 0; rr < LS_ROWS / 256; ++rr) {
+        const int64_t i = (int64_t)blockIdx.x * LS_ROWS + rr * 256 + threadIdx.x;
+        if (i < n) { const int l = lab[flag[i]]; lab_pos[i] = l; atomicAdd(&hist[l], 1); }
+    }
+    __syncthreads();
+    if (threadIdx.x < LS_CMAX && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ void fl_gather(const int *__restrict__ flag, const int *__restrict__ perm, int64_t n, int *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = flag[perm[i]];
+}
+
 // ------------------------------------------------------------------ bucket pruning (exact) -----------
 // The locality sort leaves the reference image grouped by bucket and the queries packed by bucket, so whole
 // (query block, reference bucket) pairs can be ruled out with the triangle inequality before any product is formed:
@@ -1001,13 +1020,15 @@ constexpr int IVF_SB = 13;      // pass-B runs (candidate lists) per query block
 constexpr int IVF_CSTR = 64;    // doubles per centre (d <= 61 on this path)
 
 // bounding ball of a group of prepared rows (centred at the reference mean; cosine: normalised first): group g holds
-// the rows map[lo..hi), lo/hi from gstart or (gstart == nullptr) 512-row blocks of map[0..n_map); map entries < 0 skip
-template <typename T>
-__global__ __launch_bounds__(256) void ivf_ball(const T *__restrict__ X, int d, int metric, const double *__restrict__ mean,
-                                                const int *__restrict__ map, const int *__restrict__ gstart, int64_t n_map,
-                                                double *__restrict__ cen, double *__restrict__ rad, int *__restrict__ cnt) {
+// the rows map[lo..hi), lo/hi from gstart or (gstart == nullptr) 512-row blocks of map[0..n_map); map entries < 0 skip.
+// Four small kernels over a (groups, slices) grid: coordinate sums (float64 atomics) -> centre -> max squared distance
+// to the centre (atomic max on the bit pattern of a non-negative double) -> radius, rounded up.
+template <typename T, bool RAD>
+__global__ __launch_bounds__(256) void ivf_ball_pass(const T *__restrict__ X, int d, int metric, const double *__restrict__ mean,
+                                                     const int *__restrict__ map, const int *__restrict__ gstart, int64_t n_map,
+                                                     double *__restrict__ cen, unsigned long long *__restrict__ rad2,
+                                                     int *__restrict__ cnt) {
     __shared__ double s_acc[4][64];
-    __shared__ double s_c[64];
     __shared__ double s_r[4];
     __shared__ int s_n[4];
     const int g = blockIdx.x, e = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1015,9 +1036,10 @@ __global__ __launch_bounds__(256) void ivf_ball(const T *__restrict__ X, int d, 
     int64_t hi = gstart ? (int64_t)gstart[g + 1] : lo + cmk2::QB;
     if (hi > n_map) hi = n_map;
     const double me = e < d ? mean[e] : 0.0;
-    double acc = 0.0;
+    const double ce = RAD ? cen[(size_t)g * IVF_CSTR + e] : 0.0;
+    double acc = 0.0;   // RAD: running max of the squared distance; otherwise this lane's coordinate sum
     int n = 0;
-    for (int64_t r = lo + w; r < hi; r += 4) {
+    for (int64_t r = lo + (int64_t)blockIdx.y * 4 + w; r < hi; r += 4 * (int64_t)gridDim.y) {
         const int src = map ? map[r] : (int)r;
         if (src < 0) continue;   // (wave-uniform)
         double v = e < d ? (double)X[(int64_t)src * d + e] : 0.0;
@@ -1027,45 +1049,59 @@ __global__ __launch_bounds__(256) void ivf_ball(const T *__restrict__ X, int d, 
             const double nrm = sqrt(s2);
             v *= nrm > 0.0 ? 1.0 / nrm : 1.0;
         }
-        acc += e < d ? v - me : 0.0;
+        if (RAD) {
+            const double t = e < d ? v - me - ce : 0.0;
+            double s2 = t * t;
+            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+            acc = fmax(acc, s2);
+        } else {
+            acc += e < d ? v - me : 0.0;
+        }
         ++n;
     }
-    s_acc[w][e] = acc;
-    if (e == 0) s_n[w] = n;
-    __syncthreads();
-    const int ntot = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-    if (w == 0) s_c[e] = ntot ? (s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]) / (double)ntot : 0.0;
-    __syncthreads();
-    const double ce = s_c[e];
-    double rmax = 0.0;
-    for (int64_t r = lo + w; r < hi; r += 4) {
-        const int src = map ? map[r] : (int)r;
-        if (src < 0) continue;
-        double v = e < d ? (double)X[(int64_t)src * d + e] : 0.0;
-        if (metric == CM_METRIC_COSINE) {
-            double s2 = v * v;
-            for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-            const double nrm = sqrt(s2);
-            v *= nrm > 0.0 ? 1.0 / nrm : 1.0;
-        }
-        const double t = e < d ? v - me - ce : 0.0;
-        double s2 = t * t;
-        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
-        rmax = fmax(rmax, s2);
+    if (RAD) {
+        if (e == 0) s_r[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(&rad2[g], (unsigned long long)__double_as_longlong(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3]))));
+    } else {
+        s_acc[w][e] = acc;
+        if (e == 0) s_n[w] = n;
+        __syncthreads();
+        if (w == 0 && e < d) atomicAdd(&cen[(size_t)g * IVF_CSTR + e], s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]);
+        if (threadIdx.x == 0) atomicAdd(&cnt[g], s_n[0] + s_n[1] + s_n[2] + s_n[3]);
     }
-    if (e == 0) s_r[w] = rmax;
-    __syncthreads();
-    if (w == 0) cen[(size_t)g * IVF_CSTR + e] = e < d ? ce : 0.0;
-    if (threadIdx.x == 0) {
-        rad[g] = sqrt(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3]))) * (1.0 + 1e-9);
-        cnt[g] = ntot;
-    }
+}
+__global__ void ivf_ball_zero(int G, double *__restrict__ cen, unsigned long long *__restrict__ rad2, int *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G * IVF_CSTR) cen[i] = 0.0;
+    if (i < G) { rad2[i] = 0ull; cnt[i] = 0; }
+}
+__global__ void ivf_ball_centre(int G, double *__restrict__ cen, const int *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G * IVF_CSTR) { const int n = cnt[i / IVF_CSTR]; cen[i] = n ? cen[i] / (double)n : 0.0; }
+}
+__global__ void ivf_ball_radius(int G, double *__restrict__ rad /* in: bits of the max squared distance */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G) rad[i] = sqrt(rad[i]) * (1.0 + 1e-9);
+}
+template <typename T>
+static void ivf_ball(hipStream_t st, const T *X, int d, int metric, const double *mean, const int *map, const int *gstart,
+                     int64_t n_map, int G, int slices, double *cen, double *rad, int *cnt) {
+    const unsigned nb = (unsigned)((G * IVF_CSTR + 255) / 256);
+    auto *rad2 = reinterpret_cast<unsigned long long *>(rad);
+    hipLaunchKernelGGL(ivf_ball_zero, dim3(nb), dim3(256), 0, st, G, cen, rad2, cnt);
+    hipLaunchKernelGGL((ivf_ball_pass<T, false>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, cen, rad2, cnt);
+    hipLaunchKernelGGL(ivf_ball_centre, dim3(nb), dim3(256), 0, st, G, cen, (const int *)cnt);
+    hipLaunchKernelGGL((ivf_ball_pass<T, true>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, cen, rad2, cnt);
+    hipLaunchKernelGGL(ivf_ball_radius, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, rad);
 }
 
 // pass A: one work item per query block over the tiles of the nearest bucket that holds at least min_rows rows
 __global__ __launch_bounds__(256) void ivf_plan_a(const double *__restrict__ bcen, const double *__restrict__ rcen,
                                                   const int *__restrict__ r_bstart, int C, int d, int min_rows, int n_tiles,
-                                                  int4 *__restrict__ wl, int *__restrict__ jstar) {
+                                                  int BRt /* reference rows per tile */, int4 *__restrict__ wl,
+                                                  int *__restrict__ jstar) {
     __shared__ double s_d[256];
     __shared__ int s_j[256];
     const int b = blockIdx.x, j = threadIdx.x;
@@ -1085,7 +1121,7 @@ __global__ __launch_bounds__(256) void ivf_plan_a(const double *__restrict__ bce
     if (j == 0) {
         int js = s_d[0] < INFINITY ? s_j[0] : -1;
         int t0 = 0, t1 = n_tiles;
-        if (js >= 0) { t0 = r_bstart[js] / cmk2::BR; t1 = (r_bstart[js + 1] + cmk2::BR - 1) / cmk2::BR; }
+        if (js >= 0) { t0 = r_bstart[js] / BRt; t1 = (r_bstart[js + 1] + BRt - 1) / BRt; }
         wl[b] = make_int4(b, t0, t1, 0);
         jstar[b] = js;
     }
@@ -1102,7 +1138,9 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
                                                   float c_eps, int level, const int4 *__restrict__ wl_a,
                                                   const int *__restrict__ jstar, int4 *__restrict__ wl_b,
-                                                  int *__restrict__ counters) {
+                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len) {
+    // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
+    // relative error -c_eps and the float64 -> float32 input rounding dlt per coordinate (see knn_rerank)
     __shared__ double s_red[256];
     __shared__ unsigned char s_need[256];
     __shared__ int s_u0[132], s_u1[132];
@@ -1110,12 +1148,16 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     // D = max over the block's live queries of (pass-A threshold in input units + |q'|^2 + filter error bound)
     const double ymax = (double)__uint_as_float(gmax[1]);
     const double rho_y = (double)__uint_as_float(gmax[5]);
+    const double dlt = is_f64 ? 2.0 * 5.9604645e-8 * (double)__uint_as_float(gmax[4]) : 0.0;
     double dm = 0.0;
     for (int64_t i = (int64_t)b * cmk2::QB + tid; i < (int64_t)(b + 1) * cmk2::QB && i < nsub; i += 256) {
         if (qmap && qmap[i] < 0) continue;
         const float tau = cthr[i * S];
         double D = INFINITY;
-        if (tau < INFINITY) {
+        if (tau < INFINITY && level == 4) {
+            const double t = (double)tau;
+            D = t * (1.0 + 2.0 * (double)(-c_eps)) + 2.0 * (2.0 * dlt * sqrt((double)d_rows) * sqrt(t) + (double)d_rows * dlt * dlt);
+        } else if (tau < INFINITY) {
             const double qn = (double)qnorm[i];
             double eps;   // the re-rank's bound (knn_rerank) with the global |y'| maximum
             if (qnc) {
@@ -1157,7 +1199,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     int nr = 0;
     for (int j = 0; j < C; ++j) {
         if (!s_need[j]) continue;
-        const int t0 = r_bstart[j] / cmk2::BR, t1 = (r_bstart[j + 1] + cmk2::BR - 1) / cmk2::BR;
+        const int t0 = r_bstart[j] / BRt, t1 = (r_bstart[j + 1] + BRt - 1) / BRt;
         if (nr > 0 && t0 <= s_u1[nr - 1]) { if (t1 > s_u1[nr - 1]) s_u1[nr - 1] = t1; }
         else { s_u0[nr] = t0; s_u1[nr] = t1; ++nr; }
     }
@@ -1182,6 +1224,17 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
         p1[bi] = p1[bi + 1];
         for (int i = bi + 1; i + 1 < np; ++i) { p0[i] = p0[i + 1]; p1[i] = p1[i + 1]; }
         --np;
+    }
+    // long runs are halved while list slots are left: a block that cannot rule out much would otherwise occupy one
+    // compute unit for a whole scan while the others idle
+    while (np > 0 && np < IVF_SB) {
+        int bi = 0;
+        for (int i = 1; i < np; ++i) if (p1[i] - p0[i] > p1[bi] - p0[bi]) bi = i;
+        const int len = p1[bi] - p0[bi];
+        if (len <= split_len) break;
+        p0[np] = p0[bi] + len / 2; p1[np] = p1[bi];
+        p1[bi] = p0[np];
+        ++np;
     }
     long long tiles = a1 - a0;
     if (np > 0) {
@@ -1277,6 +1330,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // locality sort (see ls_assign): permutation of the reference rows for the tile images, of the queries for the order
     // in which full-set stages pack them into waves
     int *rperm = nullptr, *qperm = nullptr, *q_bstart = nullptr, *q_bcount = nullptr, *r_bstart = nullptr;
+    int *q_lab = nullptr, *flag_s = nullptr, *fl_tmp = nullptr, *fl_cnt = nullptr;   // bucket of every query; sorted flag list
     if (!lowp && n_ref >= 65536 && nq >= 4096 && !getenv("CELLMAP_NO_SORT")) {
         const int C = LS_CMAX;
         int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
@@ -1284,6 +1338,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         rperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_ref);
         qperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nq);
         r_bstart = (int *)cm_ws_alloc(h, sizeof(int) * (LS_CMAX + 1));
+        if (nq >= 65536) {
+            flag_s = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)(nq + 1));
+            fl_tmp = (int *)cm_ws_alloc(h, sizeof(int) * 2 * (size_t)(nq + 1));
+            fl_cnt = (int *)cm_ws_alloc(h, sizeof(int) * 2 * LS_CMAX);
+            if (!flag_s || !fl_tmp || !fl_cnt) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        }
+        q_lab = lab;   // (after the loop below: the bucket of every query)
         if (!lab || !cnt_c || !rperm || !qperm || !r_bstart) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         auto assign = ls_assign<T>;
         int *b_order = (int *)cm_ws_alloc(h, sizeof(int) * LS_CMAX);
@@ -1431,8 +1492,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         const float *rr_cthr = cthr;
         int rr_S = p2.S, rr_ncap = 0;
         bool pruned = false;
-        const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack);
-        if (ivf_try && full_set && !pilot && rerank && level != 4 && !w3 && 3 * p2.Kc <= RR_NCMAX && nsub >= 65536) {
+        const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
+        auto launch = [&](const cmk2::P1Args &x) -> cm_status {
+            if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
+            if (w3) return cm_p1f16w_launch(h, p2.grid, p2.lds, x);
+            return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);
+        };
+        if (ivf_try && full_set && !pilot && rerank && !w3 && 3 * p2.Kc <= RR_NCMAX && nsub >= 65536) {
+            const int BRt = level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR;   // reference rows per tile of this level's image
+
             // ---- bucket pruning: pass A over every block's nearest bucket, plan, pass B over what cannot be ruled out
             const int C = LS_CMAX;
             const int64_t nqb_max = (nq_pad + pack_slack) / cmk2::QB + 1;
@@ -1452,27 +1520,28 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (!ivf_rcen || !ivf_rrad || !ivf_rcnt || !ivf_bcen || !ivf_brad || !ivf_bcnt || !ivf_jstar || !ivf_wla || !ivf_wlb ||
                     !ivf_ctr || !ivf_cand || !ivf_cthr)
                     CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-                hipLaunchKernelGGL(ivf_ball<T>, dim3(C), dim3(256), 0, st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm,
-                                   (const int *)r_bstart, n_ref, ivf_rcen, ivf_rrad, ivf_rcnt);
+                ivf_ball<T>(st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm, (const int *)r_bstart, n_ref, C, 32,
+                            ivf_rcen, ivf_rrad, ivf_rcnt);
             }
-            hipLaunchKernelGGL(ivf_ball<T>, dim3(p2.nqb), dim3(256), 0, st, d_qry, d, metric, (const double *)d_mean, qmap,
-                               (const int *)nullptr, nsub, ivf_bcen, ivf_brad, ivf_bcnt);
+            ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
+                        ivf_bcnt);
             hipLaunchKernelGGL(ivf_plan_a, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_rcen,
-                               (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, ivf_wla, ivf_jstar);
+                               (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, BRt, ivf_wla, ivf_jstar);
             const int64_t n_ent = (int64_t)p2.nq_pad * ivf_S;
             CM_HIP(h, hipMemsetAsync(ivf_cand, 0xff, sizeof(int) * (size_t)n_ent * p2.Kc, st));
             hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, ivf_cthr, n_ent, INFINITY);
-            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 8);
+            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
             cmk2::P1Args b = a;
             b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = ivf_S; b.perm_mul = 1;
             b.wlist = ivf_wla; b.n_wlist = p2.nqb;
-            CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, b));
+            b.wctr = ivf_ctr + 8;
+            CM_TRY(launch(b));
             hipLaunchKernelGGL(ivf_plan_b, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
                                (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, qmap, nsub,
                                (const float *)ivf_cthr, ivf_S, (const float *)qnorm, (const float *)qlo,
                                cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
                                (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
-                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr);
+                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256);
             CM_HIP(h, hipGetLastError());
             int *hc = h->d_nflag_pinned + 4;
             CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1486,21 +1555,22 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (tiles * 10ull <= full * 6ull) {
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
-                    CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, b));
+                    b.wctr = ivf_ctr + 9;
+                    CM_TRY(launch(b));
                 }
                 pruned = true;
-                rr_cand = ivf_cand; rr_cthr = ivf_cthr; rr_S = ivf_S; rr_ncap = 3 * p2.Kc;
-                ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
+                rr_cand = ivf_cand; rr_cthr = ivf_cthr; rr_S = ivf_S;
+                // re-rank capacity: the lists are mostly empty; a query that overflows it is left to the next level -- on
+                // the last level that would be the exact scan, so there the capacity covers every list
+                const bool last_level = level == 4 || (level == 3 && !have_direct);
+                rr_ncap = std::min(RR_NCMAX, (last_level ? ivf_S : 6) * p2.Kc);
+                if (marks) ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
-                h->staged_ivf_skip = 15;
+                if (marks) h->staged_ivf_skip = 15;
             }
         }
-        if (!pruned) {
-            if (level == 4) CM_TRY(cm_p1lowd_launch(h, dl, p2.grid, p2.lds, a));
-            else if (w3) CM_TRY(cm_p1f16w_launch(h, p2.grid, p2.lds, a));
-            else CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, a));
-        }
+        if (!pruned) CM_TRY(launch(a));
         if (marks) cm_mark(h, 2);
         if (!rerank) return CM_OK;
         const int pilot_kc = pilot ? p2.Kc : 0;
@@ -1614,6 +1684,18 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (nf <= 64 && level != 0) break;
         qmap = flag_out;
         nsub = nf;
+        if (ivf_try && flag_s && nf >= 65536) {   // group the flagged queries by bucket: the next stage can prune as well
+            hipLaunchKernelGGL(zero_words, dim3(2), dim3(256), 0, st, (unsigned *)fl_cnt, 2 * LS_CMAX);
+            hipLaunchKernelGGL(fl_labels, dim3((unsigned)((nf + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, (const int *)flag_out, nf,
+                               (const int *)q_lab, fl_tmp, fl_cnt);
+            hipLaunchKernelGGL(ls_offsets, dim3(1), dim3(64), 0, st, fl_cnt, LS_CMAX, fl_cnt + LS_CMAX);
+            hipLaunchKernelGGL(ls_scatter, dim3((unsigned)((nf + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, (const int *)fl_tmp, nf,
+                               fl_cnt + LS_CMAX, fl_tmp + (nq + 1));
+            hipLaunchKernelGGL(fl_gather, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, (const int *)flag_out,
+                               (const int *)(fl_tmp + (nq + 1)), nf, flag_s);
+            CM_HIP(h, hipGetLastError());
+            qmap = flag_s;
+        }
         flag_out = flag_out == flag_a ? flag_b : flag_a;
         level = next;
     }
@@ -1757,6 +1839,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
             b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
                  cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
                  cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
+            b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;   // bucket-sorted flag lists of the subset stages
         }
     } else {
         int KP = pick_kp(d);

@@ -97,6 +97,8 @@ struct P1Args {
     const int *n_wlist_dev = nullptr;
     int n_wlist = 0;
     int thr0_slot0 = 0;
+    int *wctr = nullptr;   // work-list mode: items beyond the first gridDim.x are handed out through this counter (zeroed
+                           // by the caller): runs differ in length by orders of magnitude, a static assignment does not balance
     unsigned perm_mul = 1; // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
                            // n_tiles; 0/1 = identity).  A scattered visiting order keeps the streaming thresholds
                            // representative when the reference rows are sorted (by cluster, batch, ...)
@@ -507,7 +509,15 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
     const int n_work = a.wlist ? (a.n_wlist_dev ? *a.n_wlist_dev : a.n_wlist) : a.nqb * a.S;
-    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    auto next_work = [&](int w) -> int {
+        if (!a.wctr) return w + (int)gridDim.x;
+        volatile int *slot = reinterpret_cast<volatile int *>(smem + RING * TILEB);   // spare bytes behind the ring
+        __syncthreads();
+        if (tid == 0) *slot = (int)gridDim.x + atomicAdd(a.wctr, 1);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(*slot);
+    };
+    for (int work = blockIdx.x; work < n_work; work = next_work(work)) {
         int qb, split, t0, t1;
         if (a.wlist) {
             const int4 w_ = a.wlist[work];
@@ -765,16 +775,32 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
     (void)wsc;
 
-    const int n_work = a.nqb * a.S;
-    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
-        const int qb = work / a.S, split = work - qb * a.S;
-        const int t0 = split * a.tiles_per_split;
-        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+    const int n_work = a.wlist ? (a.n_wlist_dev ? *a.n_wlist_dev : a.n_wlist) : a.nqb * a.S;
+    auto next_work = [&](int w) -> int {
+        if (!a.wctr) return w + (int)gridDim.x;
+        volatile int *slot = reinterpret_cast<volatile int *>(smem + 2 * TILEB);   // spare bytes behind the ring
+        __syncthreads();
+        if (tid == 0) *slot = (int)gridDim.x + atomicAdd(a.wctr, 1);
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(*slot);
+    };
+    for (int work = blockIdx.x; work < n_work; work = next_work(work)) {
+        int qb, split, t0, t1;
+        if (a.wlist) {   // bucket pruning: explicit (query block, tile run, candidate-list slot) items
+            const int4 w_ = a.wlist[work];
+            qb = __builtin_amdgcn_readfirstlane(w_.x); t0 = __builtin_amdgcn_readfirstlane(w_.y);
+            t1 = __builtin_amdgcn_readfirstlane(w_.z); split = __builtin_amdgcn_readfirstlane(w_.w);
+        } else {
+            qb = work / a.S; split = work - qb * a.S;
+            t0 = split * a.tiles_per_split;
+            t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        }
         const int64_t qbase = (int64_t)qb * QB + wave * 64;
         float q0[D], q1[D];
 #pragma unroll
         for (int e = 0; e < D; ++e) { q0[e] = Qf[(qbase + c) * D + e]; q1[e] = Qf[(qbase + 32 + c) * D + e]; }
         float thr[2] = {INFINITY, INFINITY};
+        if (a.thr0_slot0) { thr[0] = a.cthr[(qbase + c) * a.S]; thr[1] = a.cthr[(qbase + 32 + c) * a.S]; }
         int cnt[2] = {0, 0};
         int keptn[2] = {0, 0};
 
