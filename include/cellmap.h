@@ -83,7 +83,9 @@ cm_status cm_synchronize(cm_handle_t h);
 cm_status cm_set_profiling(cm_handle_t h, int32_t on);
 cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
 /* counters of the last cm_knn / cm_knn_dev call: out[0] = queries sent to the exact fallback,
- * out[1] = candidate-list size K', out[2] = reference splits, out[3] = 1 if the low-d VALU path ran */
+ * out[1] = candidate-list size K', out[2] = reference splits + 100 * (filter level the full set started at),
+ * out[3] = filter family (1 f32-input MFMA, 2 split-fp16 MFMA K <= 64, 3 direct VALU / grid, 4 split-fp16 MFMA K = 128)
+ *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning) */
 cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]);
 
 /* ---------------------------------------------------------------- K0: exact k-NN ------------------
