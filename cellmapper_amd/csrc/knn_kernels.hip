@@ -1249,6 +1249,41 @@ __global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
     if (i < n) p[i] = v;
 }
 
+// cen_side for the (bucket, reference row) pairs a work list visits only (bucket pruning): item = (query block, first
+// tile, end tile, .); same arithmetic as cen_side.  Blocks of one bucket write the same values (benign).
+template <typename T>
+__global__ __launch_bounds__(256) void cen_side_items(const T *__restrict__ R, int64_t n_ref, int d, int metric,
+                                                      const double *__restrict__ mean, const int *__restrict__ rperm,
+                                                      const double *__restrict__ cen, const int *__restrict__ blk_bucket,
+                                                      const int4 *__restrict__ wl, int n_items,
+                                                      const float *__restrict__ scale3, int64_t stride,
+                                                      float *__restrict__ side) {
+    __shared__ double s_c[64];
+    if ((int)blockIdx.x >= n_items) return;
+    const int4 w = wl[blockIdx.x];
+    const int j = blk_bucket[w.x];
+    if (threadIdx.x < 64) s_c[threadIdx.x] = (int)threadIdx.x < d ? cen[(size_t)j * d + threadIdx.x] : 0.0;
+    __syncthreads();
+    const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
+    int64_t r1 = (int64_t)w.z * cmk2::BR;
+    if (r1 > stride) r1 = stride;
+    for (int64_t r = (int64_t)w.y * cmk2::BR + (int64_t)blockIdx.y * 256 + threadIdx.x; r < r1; r += 256 * (int64_t)gridDim.y) {
+        double dot = 0.0;
+        if (r < n_ref) {
+            const T *x = R + (int64_t)(rperm ? rperm[r] : r) * d;
+            double ns = 1.0;
+            if (metric == CM_METRIC_COSINE) {
+                double s2 = 0.0;
+                for (int c = 0; c < d; ++c) { double v = (double)x[c]; s2 = fma(v, v, s2); }
+                const double nrm = sqrt(s2);
+                ns = nrm > 0.0 ? 1.0 / nrm : 1.0;
+            }
+            for (int c = 0; c < d; ++c) dot = fma(s_c[c], (double)x[c] * ns - mean[c], dot);
+        }
+        side[(size_t)j * stride + r] = (float)(m2 * dot);
+    }
+}
+
 __global__ void strided_rows(int *__restrict__ out, int n, int64_t stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int)(i * stride);
@@ -1375,6 +1410,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     double *cen = nullptr;
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
     int64_t n_packed = 0, side_stride = 0;
+    bool side_full = false;   // side values computed for every (bucket, reference row) pair
     // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     if (!hint_same) h->staged_ivf_skip = 0;
@@ -1402,6 +1438,18 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         g_dbg_ctr = s_ctr;
     }
 
+    auto side_full_compute = [&]() -> cm_status {
+        if (side_full) return CM_OK;
+        const int C = LS_CMAX;
+        const size_t lds_c = sizeof(double) * (size_t)C * d;
+        auto sidek = cen_side<T>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(sidek), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        hipLaunchKernelGGL(sidek, dim3((unsigned)((side_stride + 255) / 256)), dim3(256), lds_c, st, d_ref, n_ref, d, metric,
+                           (const double *)d_mean, (const int *)rperm, (const double *)cen, C, (const float *)scale3, side_stride, side);
+        CM_HIP(h, hipGetLastError());
+        side_full = true;
+        return CM_OK;
+    };
     int img = -1;          // reference image currently in Rp: 0 full [hi|lo] tiles, 1 hi-only tiles, 2 direct (fp32 rows)
     int last_Kc = Kc_max, last_S = 1;
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
@@ -1535,6 +1583,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = ivf_S; b.perm_mul = 1;
             b.wlist = ivf_wla; b.n_wlist = p2.nqb;
             b.wctr = ivf_ctr + 8;
+            auto side_items = [&](const int4 *wl, int n_items) {   // centred level: side values of the pairs a list visits
+                if (!cenl || side_full || n_items < 1) return;
+                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, 4), dim3(256), 0, st, d_ref, n_ref, d, metric,
+                                   (const double *)d_mean, (const int *)rperm, (const double *)cen, (const int *)blk_bucket, wl,
+                                   n_items, (const float *)scale3, side_stride, side);
+            };
+            side_items(ivf_wla, p2.nqb);
             CM_TRY(launch(b));
             hipLaunchKernelGGL(ivf_plan_b, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
                                (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, qmap, nsub,
@@ -1556,6 +1611,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
                     b.wctr = ivf_ctr + 9;
+                    side_items(ivf_wlb, hc[0]);
                     CM_TRY(launch(b));
                 }
                 pruned = true;
@@ -1570,7 +1626,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (marks) h->staged_ivf_skip = 15;
             }
         }
-        if (!pruned) CM_TRY(launch(a));
+        if (!pruned) {
+            if (cenl) CM_TRY(side_full_compute());
+            CM_TRY(launch(a));
+        }
         if (marks) cm_mark(h, 2);
         if (!rerank) return CM_OK;
         const int pilot_kc = pilot ? p2.Kc : 0;
@@ -1618,13 +1677,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                            (const int *)q_bstart, cen);
         hipLaunchKernelGGL(cen_pack, dim3((unsigned)((n_packed + 255) / 256)), dim3(256), 0, st, (const int *)qperm, (const int *)q_bstart,
                            (const int *)pstart, C, n_packed, qpack, blk_bucket);
-        const size_t lds_c = sizeof(double) * (size_t)C * d;
-        auto sidek = cen_side<T>;
-        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(sidek), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        hipLaunchKernelGGL(sidek, dim3((unsigned)((side_stride + 255) / 256)), dim3(256), lds_c, st, d_ref, n_ref, d, metric,
-                           (const double *)d_mean, (const int *)rperm, (const double *)cen, C, (const float *)scale3, side_stride, side);
         CM_HIP(h, hipGetLastError());
-        return CM_OK;
+        return CM_OK;   // (the side values are computed by the stage that needs them: side_full_compute / cen_side_items)
     };
 
     // ---- choose the level the whole set starts at

@@ -400,6 +400,26 @@ def test_bucket_pruning_on_clustered_sets_is_exact(hip, oracle, monkeypatch, met
         assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
+def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
+    """Very tight, off-centre clusters in float64: the MFMA levels fail for (nearly) every query, the flag lists of
+    >= 65 536 queries are regrouped by bucket and the three-product and direct-difference stages prune as well."""
+    rng = np.random.default_rng(63)
+    d, k, n_ref, nq = 40, 10, 150000, 80000
+    cen = rng.standard_normal((30, d)) * 5.0
+    ref = cen[rng.integers(0, 30, n_ref)] + 0.02 * rng.standard_normal((n_ref, d))
+    qry = cen[rng.integers(0, 30, nq)] + 0.02 * rng.standard_normal((nq, d))
+    # a call on easy data first: the handle then starts the clustered set on level 1 without a pilot, so the failures
+    # walk down the whole ladder as subset stages
+    easy = rng.standard_normal((8192, d))
+    hip.knn(easy, easy[:4096], k)
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["filter_products"] == 1 and st["fallback_queries"] <= 64, st
+    sel = rng.choice(nq, 1000, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 def test_bucket_pruning_backs_off_on_unclustered_sets(hip, oracle, monkeypatch):
     """Isotropic data: nothing can be ruled out, the plan says so after pass A and the stage runs as a full scan."""
     rng = np.random.default_rng(62)
