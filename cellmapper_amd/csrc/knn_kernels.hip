@@ -1018,6 +1018,10 @@ __global__ void fl_gather(const int *__restrict__ flag, const int *__restrict__ 
 // Nothing here depends on how good the buckets are: bad buckets only mean nothing is skipped.
 constexpr int IVF_SB = 13;      // pass-B runs (candidate lists) per query block; slot 0 is pass A
 constexpr int IVF_CSTR = 64;    // doubles per centre (d <= 61 on this path)
+// the IVF_SB + 1 candidate lists per query are the one large buffer of the scheme: not worth more than 16 GiB of workspace
+static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
+    return (size_t)(nq_pad + 256 * 512) * (IVF_SB + 1) * (size_t)Kc_max * 4 <= ((size_t)16 << 30);
+}
 
 // bounding ball of a group of prepared rows (centred at the reference mean; cosine: normalised first): group g holds
 // the rows map[lo..hi), lo/hi from gstart or (gstart == nullptr) 512-row blocks of map[0..n_map); map entries < 0 skip.
@@ -1414,7 +1418,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     if (!hint_same) h->staged_ivf_skip = 0;
-    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && !getenv("CELLMAP_NO_IVF");
+    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !getenv("CELLMAP_NO_IVF");
     if (ivf_try && h->staged_ivf_skip > 0 && !getenv("CELLMAP_NO_HINT")) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
@@ -1479,7 +1483,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (wide) p2.KSTEPS = cmk2::KSTEPS_W;
         if (cenl) {   // the centred level keeps a wider candidate list: its residual error is dominated by bucket quality
             const int kc2 = k + (k > 30 ? k : 30);
-            if (kc2 <= Kc_max + 16 && kc2 + 2 * cmk2::CL <= 512) p2.Kc = kc2;
+            if (kc2 <= Kc_max && kc2 + 2 * cmk2::CL <= 512) p2.Kc = kc2;   // (every candidate buffer is sized for Kc_max)
         }
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
@@ -1888,7 +1892,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
             b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
                  cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
-        if (d + cmk2::NORM_SLOTS <= 64 && nq >= 65536 && n_ref >= 65536) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
+        if (d + cmk2::NORM_SLOTS <= 64 && nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
             const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 512 + 1;
             b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
                  cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
