@@ -245,7 +245,7 @@ class Handle:
 
     def expression_metrics(self, orig, imputed, method: str, group=None, n_groups: int = 0):
         """Per-gene agreement [n_groups + 1, G] float32 (row 0: all cells) -- evaluate.py:236-323."""
-        mid = {"pearson": 0, "rmse": 1, "js": 2, "jensen-shannon": 2}[method]
+        mid = {"pearson": 0, "rmse": 1, "js": 2, "jensen-shannon": 2, "spearman": 3}[method]
         orig = np.ascontiguousarray(orig, np.float32)
         imputed = np.ascontiguousarray(imputed, np.float32)
         if orig.shape != imputed.shape or orig.ndim != 2:

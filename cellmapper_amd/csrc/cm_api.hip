@@ -516,6 +516,10 @@ cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_
 cm_status cm_expression_metrics_dev(cm_handle_t h, const float *d_orig, const float *d_imputed, int64_t n, int64_t n_genes,
                                     const int32_t *d_group, int32_t n_groups, int32_t method, float *d_out) {
     if (!h) return CM_E_INVALID;
+    if (method == CM_EXPR_SPEARMAN) {
+        CM_TRY(begin_call(h, cm_expr_spearman_ws_bytes(n, n_genes)));
+        return cm_expr_spearman_run(h, d_orig, d_imputed, n, n_genes, d_group, n_groups, d_out);
+    }
     CM_TRY(begin_call(h, cm_expr_metrics_ws_bytes(n, n_genes)));
     return cm_expr_metrics_run(h, d_orig, d_imputed, n, n_genes, d_group, n_groups, method, d_out);
 }
@@ -524,14 +528,18 @@ cm_status cm_expression_metrics(cm_handle_t h, const float *orig, const float *i
                                 const int32_t *group, int32_t n_groups, int32_t method, float *out) {
     if (!h) return CM_E_INVALID;
     if (n < 0 || n_genes < 1) CM_FAIL(h, CM_E_INVALID, "expression metrics: bad shape");
-    CM_TRY(begin_call(h, cm_expr_metrics_ws_bytes(n, n_genes)));
+    CM_TRY(begin_call(h, method == CM_EXPR_SPEARMAN ? cm_expr_spearman_ws_bytes(n, n_genes) : cm_expr_metrics_ws_bytes(n, n_genes)));
     const size_t nb = 4 * (size_t)n * n_genes, ng = group ? (size_t)n_groups : 0;
     DevBuf da, db, dg, dout;
     CM_TRY(da.alloc(h, nb)); CM_TRY(db.alloc(h, nb)); CM_TRY(dout.alloc(h, 4 * (ng + 1) * (size_t)n_genes));
     CM_TRY(h2d(h, da.p, orig, nb)); CM_TRY(h2d(h, db.p, imputed, nb));
     if (group) { CM_TRY(dg.alloc(h, 4 * (size_t)n)); CM_TRY(h2d(h, dg.p, group, 4 * (size_t)n)); }
-    CM_TRY(cm_expr_metrics_run(h, da.as<float>(), db.as<float>(), n, n_genes, group ? dg.as<int32_t>() : nullptr, (int)ng, method,
-                               dout.as<float>()));
+    if (method == CM_EXPR_SPEARMAN)
+        CM_TRY(cm_expr_spearman_run(h, da.as<float>(), db.as<float>(), n, n_genes, group ? dg.as<int32_t>() : nullptr, (int)ng,
+                                    dout.as<float>()));
+    else
+        CM_TRY(cm_expr_metrics_run(h, da.as<float>(), db.as<float>(), n, n_genes, group ? dg.as<int32_t>() : nullptr, (int)ng, method,
+                                   dout.as<float>()));
     CM_TRY(d2h(h, out, dout.p, 4 * (ng + 1) * (size_t)n_genes));
     return sync(h);
 }

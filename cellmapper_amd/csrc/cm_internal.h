@@ -83,6 +83,10 @@ cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32
 cm_status cm_expr_metrics_run(cm_handle_t h, const float *d_a, const float *d_b, int64_t n, int64_t G, const int32_t *d_group,
                               int n_groups, int method, float *d_out);
 size_t cm_expr_metrics_ws_bytes(int64_t n, int64_t G);
+// rank_kernels.hip: Spearman (Pearson of average ranks) per gene
+cm_status cm_expr_spearman_run(cm_handle_t h, const float *d_a, const float *d_b, int64_t n, int64_t G, const int32_t *d_group,
+                               int n_groups, float *d_out);
+size_t cm_expr_spearman_ws_bytes(int64_t n, int64_t G);
 cm_status cm_presence_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
                           const double *d_param, const int32_t *d_group, int32_t n_groups, double *d_out);
 cm_status cm_csr_normalize_run(cm_handle_t h, const int64_t *d_indptr, const double *d_data, int64_t nq, float *d_out);

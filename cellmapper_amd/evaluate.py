@@ -117,9 +117,7 @@ class ExpressionEvaluationMixin:
         """Agreement between imputed and measured expression per gene, overall (``query.var['metric_<method>']``) and,
         with ``groupby``, per group of query cells (``query.varm['metric_<method>']``, genes x groups in order of
         appearance).  ``expression_transfer_metrics`` holds the average over the valid (test) genes."""
-        if method == "spearman":
-            raise NotImplementedError("Method 'spearman' is not available on the hip backend (supported: pearson, rmse, js).")
-        if method not in ("pearson", "js", "jensen-shannon", "rmse"):
+        if method not in ("pearson", "spearman", "js", "jensen-shannon", "rmse"):
             raise NotImplementedError(f"Method '{method}' is not implemented.")
         imputed, original, shared = self._get_aligned_expression_arrays(layer_key)
         groups, codes = None, None

@@ -223,11 +223,13 @@ cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_
  * all cells (output row 0) and over the cells of each group (rows 1..n_groups; group int32 [n] in [0, n_groups) or
  * NULL).  method: 0 = Pearson r (scipy.stats.pearsonr; NaN for a constant column), 1 = RMSE of the z-scored vectors
  * (std 0 -> 1), 2 = Jensen-Shannon distance base 10 of the clipped, normalised vectors (NaN if either sums to 0).
- * out float32 [n_groups + 1, n_genes].  Spearman is not provided.  The _dev form takes device pointers (the imputed
+ * 3 = Spearman rho (scipy.stats.spearmanr, evaluate.py:276-277: Pearson r of the average ranks; NaN for a constant
+ * column; device sort of every gene column).  out float32 [n_groups + 1, n_genes].  The _dev form takes device pointers (the imputed
  * matrix never has to leave the GPU). */
 #define CM_EXPR_PEARSON 0
 #define CM_EXPR_RMSE 1
 #define CM_EXPR_JS 2
+#define CM_EXPR_SPEARMAN 3
 cm_status cm_expression_metrics(cm_handle_t h, const float *orig, const float *imputed, int64_t n, int64_t n_genes,
                                 const int32_t *group, int32_t n_groups, int32_t method, float *out);
 cm_status cm_expression_metrics_dev(cm_handle_t h, const float *d_orig, const float *d_imputed, int64_t n, int64_t n_genes,

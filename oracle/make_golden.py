@@ -181,7 +181,7 @@ def presence_case(cm_mod):
 def expr_eval_case():
     """Per-gene agreement metrics exactly as EvaluationMixin.evaluate_expression_transfer computes them
     (evaluate.py:271-289: metric_func per gene over a cell mask, float32 array), using the reference module's own
-    helpers (_rmse_zscore, _jensen_shannon_divergence; pearsonr as imported there), overall and per group."""
+    helpers (_rmse_zscore, _jensen_shannon_divergence; pearsonr / spearmanr as imported there), overall and per group."""
     import warnings
 
     ev = importlib.import_module("cellmapper.model.evaluate")
@@ -197,6 +197,7 @@ def expr_eval_case():
     labels = np.array(["t%d" % v for v in rng.integers(0, 3, n)])
     funcs = {
         "pearson": lambda a, b: ev.pearsonr(a, b)[0],
+        "spearman": lambda a, b: ev.spearmanr(a, b)[0],
         "rmse": ev._rmse_zscore,
         "js": ev._jensen_shannon_divergence,
     }

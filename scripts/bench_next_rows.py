@@ -28,7 +28,7 @@ a = torch.rand((n, G), device=dev); b = a * 0.5 + torch.rand((n, G), device=dev)
 grp = torch.randint(0, ng, (n,), device=dev, dtype=torch.int32)
 res = torch.empty((ng + 1, G), device=dev)
 torch.cuda.synchronize()
-for method, mid in (("pearson", 0), ("js", 2)):
+for method, mid in (("pearson", 0), ("js", 2), ("spearman", 3)):
     for groups in (0, ng):
         ts = []
         for rep in range(2):
@@ -36,6 +36,6 @@ for method, mid in (("pearson", 0), ("js", 2)):
             h.call("cm_expression_metrics_dev", C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n, G,
                    C.c_void_p(grp.data_ptr()) if groups else None, groups, mid, C.c_void_p(res.data_ptr()))
             h.call("cm_synchronize"); ts.append(time.perf_counter() - t0)
-        gb = 2 * 2 * n * G * 4 * (groups + 1) / 1e9   # two passes over both matrices per cell selection
+        gb = 2 * 2 * n * G * 4 * (groups + 1) / 1e9   # two passes over both matrices per cell selection (spearman: sort-bound, not HBM)
         out[f"eval_{method}_groups{groups}"] = {"seconds": ts[-1], "GB_read": gb, "TB_per_s": gb / ts[-1] / 1e3}
 print(json.dumps(out))

@@ -341,7 +341,7 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
         extract_neighbors_from_distances(big)
 
 
-@pytest.mark.parametrize("method", ["pearson", "rmse", "js"])
+@pytest.mark.parametrize("method", ["pearson", "rmse", "js", "spearman"])
 def test_expression_metrics_match_reference(oracle, method):
     """cm_expression_metrics vs the reference's per-gene values (golden) and, on a larger ragged case, vs the oracle."""
     from cellmapper_amd import _native
@@ -393,6 +393,8 @@ def test_evaluate_expression_transfer_side_effects():
     m = cm.expression_transfer_metrics
     assert m["method"] == "pearson" and m["n_shared_genes"] == G and m["n_test_genes"] == int(valid.sum())
     assert abs(m["average"] - float(np.mean(g["pearson_all"][valid]))) < 1e-5
+    cm.evaluate_expression_transfer(method="spearman")
+    assert np.allclose(query.var["metric_spearman"].to_numpy(), g["spearman_all"], rtol=1e-5, atol=2e-6, equal_nan=True)
     with pytest.raises(NotImplementedError):
-        cm.evaluate_expression_transfer(method="spearman")
+        cm.evaluate_expression_transfer(method="kendall")
 

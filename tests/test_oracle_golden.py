@@ -136,7 +136,7 @@ def test_oracle_precomputed_distance_ingest_edge_cases(oracle):
     assert np.isinf(dist[1]).sum() >= 1
 
 
-@pytest.mark.parametrize("method", ["pearson", "rmse", "js"])
+@pytest.mark.parametrize("method", ["pearson", "rmse", "js", "spearman"])
 def test_oracle_expression_metrics_match_reference(oracle, method):
     """oracle.expression_metrics vs the values the reference's helpers produced (evaluate.py:20-63,271-289), overall and
     per group; genes with a constant / all-zero / all-negative column exercise the NaN and std -> 1 rules."""
