@@ -1101,6 +1101,30 @@ static void ivf_ball(hipStream_t st, const T *X, int d, int metric, const double
     hipLaunchKernelGGL(ivf_ball_radius, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, rad);
 }
 
+// cheap gate before pass A: tiles of the (block, bucket) pairs whose balls overlap (LB = 0) can never be skipped; if they
+// are most of the scan there is nothing to gain and pass A -- whose lists start from +inf thresholds, i.e. pay the
+// start-up churn of a scan -- is not worth running
+__global__ __launch_bounds__(256) void ivf_overlap(const double *__restrict__ bcen, const double *__restrict__ brad,
+                                                   const double *__restrict__ rcen, const double *__restrict__ rrad,
+                                                   const int *__restrict__ r_bstart, int C, int d, int BRt,
+                                                   unsigned long long *__restrict__ total) {
+    __shared__ int s_t[256];
+    const int b = blockIdx.x, j = threadIdx.x;
+    int tiles = 0;
+    if (j < C && r_bstart[j + 1] > r_bstart[j]) {
+        double s2 = 0.0;
+        for (int c = 0; c < d; ++c) { const double t = bcen[(size_t)b * IVF_CSTR + c] - rcen[(size_t)j * IVF_CSTR + c]; s2 = fma(t, t, s2); }
+        if (!(sqrt(s2) > brad[b] + rrad[j])) tiles = (r_bstart[j + 1] - r_bstart[j] + BRt - 1) / BRt;
+    }
+    s_t[j] = tiles;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (j < o) s_t[j] += s_t[j + o];
+        __syncthreads();
+    }
+    if (j == 0) atomicAdd(total, (unsigned long long)s_t[0]);
+}
+
 // pass A: one work item per query block over the tiles of the nearest bucket that holds at least min_rows rows
 __global__ __launch_bounds__(256) void ivf_plan_a(const double *__restrict__ bcen, const double *__restrict__ rcen,
                                                   const int *__restrict__ r_bstart, int C, int d, int min_rows, int n_tiles,
@@ -1577,6 +1601,24 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             }
             ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
                         ivf_bcnt);
+            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
+            hipLaunchKernelGGL(ivf_overlap, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
+                               (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, BRt,
+                               reinterpret_cast<unsigned long long *>(ivf_ctr + 4));
+            {
+                int *ho = h->d_nflag_pinned + 10;
+                CM_HIP(h, hipMemcpyAsync(ho, ivf_ctr + 4, 8, hipMemcpyDeviceToHost, st));
+                CM_HIP(h, hipStreamSynchronize(st));
+                unsigned long long ov;
+                memcpy(&ov, ho, 8);
+                const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
+                if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
+                if (ov * 10ull > full0 * 6ull) {
+                    ivf_try = false;
+                    if (marks) h->staged_ivf_skip = 15;
+                }
+            }
+            if (ivf_try) {
             hipLaunchKernelGGL(ivf_plan_a, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_rcen,
                                (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, BRt, ivf_wla, ivf_jstar);
             const int64_t n_ent = (int64_t)p2.nq_pad * ivf_S;
@@ -1628,6 +1670,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
                 if (marks) h->staged_ivf_skip = 15;
+            }
             }
         }
         if (!pruned) {

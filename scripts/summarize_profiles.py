@@ -73,8 +73,8 @@ def main():
                 f"{bj['roofline']['kernel_ms']:.2f} ms (last timed step); rocprof, same kernel: "
                 + "; ".join(f"`{short(r['Name'])}` avg of the {r['Calls']} calls {float(r['AverageNs'])*1e-6:.2f} ms, max "
                             f"{float(r['MaxNs'])*1e-6:.2f} ms" for r in dom)
-                + " (the short extra call is the 768-query parity check; a level-3 instance appears only if the filter "
-                  "escalated).\n\n")
+                + " (the short extra calls: the pilot on a 2 048-query sample in the warm-up step and the 768-query parity "
+                  "check; a level-3 instance appears only if the filter escalated).\n\n")
         f.write("| kernel | calls | total ns | avg ns | % | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
         for r in rows:
             f.write(f"| {short(r['Name'])} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | "
