@@ -149,6 +149,8 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         value = a.nq * a.steps / elapsed
         flops = 2.0 * qry.shape[0] * (hi - lo) * a.d  # algorithmic flops of the distance contraction on this rank
+        if fb.get("tiles_visited_pct", 0):   # pruned scan: only the visited pairs are work the kernel did
+            flops *= fb["tiles_visited_pct"] / 100.0
         p1 = float(np.mean(p1_ms))
         achieved = flops / (p1 * 1e-3) / 1e12
         # knn_stats[3]: 1 = f32-input MFMA kernel, 2 = split-fp16 MFMA (K<=64), 3 = low-d VALU, 4 = split-fp16 MFMA (K=128)
@@ -162,6 +164,8 @@ def main():
         nprod = 1 if lvl == 5 else min(3, max(1, lvl))   # 5 = bucket-centred hi*hi
         executed = (nprod * 2.0 * qry.shape[0] * (hi - lo) * kpad if f16_path
                     else 2.0 * qry.shape[0] * (hi - lo) * (4 * ((a.d + 4) // 4)))
+        if fb.get("tiles_visited_pct", 0):
+            executed *= fb["tiles_visited_pct"] / 100.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "phase1_hbm_traffic.json")
         if os.path.exists(tfile) and world == 1 and a.nq == 1_500_000 and a.nref == 1_500_000:
@@ -182,7 +186,11 @@ def main():
                        "parallelism": f"q{n_groups}xr{ref_shards}",
                        "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
                        "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"],
-                       "filter_products": fb.get("filter_products", 0)},
+                       "filter_products": fb.get("filter_products", 0),
+                       # bucket pruning of the staged search: per cent of the (query block, reference tile) pairs the
+                       # filter visited; 0 = full scan (what the roofline's brute-force flop count assumes -- i.i.d.
+                       # synthetic rows have no cluster structure to prune)
+                       "tiles_visited_pct": fb.get("tiles_visited_pct", 0)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "kernel_ms": p1,
