@@ -105,12 +105,13 @@ __global__ void prep_rows(const T *__restrict__ X, int64_t n, int d, int KP, int
 // rows centred at the reference mean: the fp16 split and the error bound then scale with the SPREAD of the data, not
 // with its offset from the origin.  (Phase 2 always uses the caller's original rows.)  Deterministic two-stage sum.
 constexpr int CMEAN_BLOCKS = 256;
+constexpr int CMEAN_COLS = 128;   // the staged search handles d <= 128: a lane owns columns c and c + 64
 template <typename T>
 __global__ __launch_bounds__(256) void colmean_partial(const T *__restrict__ X, int64_t n, int d, int metric,
-                                                        double *__restrict__ partial /*[CMEAN_BLOCKS][64]*/) {
-    __shared__ double sh[4][64];
-    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;  // lane = column, 4 waves stride over rows
-    double acc = 0.0;
+                                                        double *__restrict__ partial /*[CMEAN_BLOCKS][CMEAN_COLS]*/) {
+    __shared__ double sh[4][CMEAN_COLS];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;  // lane = column (pair), 4 waves stride over rows
+    double acc0 = 0.0, acc1 = 0.0;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
     for (int64_t i = r0 + w; i < r1; i += 4) {
@@ -121,17 +122,22 @@ __global__ __launch_bounds__(256) void colmean_partial(const T *__restrict__ X, 
             double nrm = sqrt(s);
             scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
         }
-        if (c < d) acc += (double)X[i * d + c] * scale;
+        if (c < d) acc0 += (double)X[i * d + c] * scale;
+        if (c + 64 < d) acc1 += (double)X[i * d + c + 64] * scale;
     }
-    sh[w][c] = acc;
+    sh[w][c] = acc0;
+    sh[w][c + 64] = acc1;
     __syncthreads();
-    if (w == 0) partial[blockIdx.x * 64 + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+    if (w < 2) {
+        const int cc = c + 64 * w;
+        partial[blockIdx.x * CMEAN_COLS + cc] = (sh[0][cc] + sh[1][cc]) + (sh[2][cc] + sh[3][cc]);
+    }
 }
-__global__ void colmean_final(const double *__restrict__ partial, int64_t n, int d, double *__restrict__ mean /*[64]*/) {
+__global__ void colmean_final(const double *__restrict__ partial, int64_t n, int d, double *__restrict__ mean /*[CMEAN_COLS]*/) {
     const int c = threadIdx.x;
-    if (c < 64) {
+    if (c < CMEAN_COLS) {
         double s = 0.0;
-        for (int b = 0; b < CMEAN_BLOCKS; ++b) s += partial[b * 64 + c];
+        for (int b = 0; b < CMEAN_BLOCKS; ++b) s += partial[b * CMEAN_COLS + c];
         mean[c] = (c < d && n > 0) ? s / (double)n : 0.0;
     }
 }
@@ -1372,8 +1378,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     char *Qp = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * (wide ? 512 : 256));
     uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * Kc_max);
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
-    double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * 64);
-    double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * 64);
+    double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * CMEAN_COLS);
+    double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_COLS);
     if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
         !Qp || !kept || !lbuf || !cpart || !d_mean)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
@@ -1383,7 +1389,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
     // centre at the reference mean (translation leaves every distance unchanged), common power-of-two scale
     hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
-    hipLaunchKernelGGL(colmean_final, dim3(1), dim3(64), 0, st, cpart, n_ref, d, d_mean);
+    hipLaunchKernelGGL(colmean_final, dim3(1), dim3(CMEAN_COLS), 0, st, cpart, n_ref, d, d_mean);
     // (the direct / grid filters work on the rows as given: their rounding bound needs max |coordinate| of the raw values)
     const double *mean_ma = lowp ? (const double *)nullptr : (const double *)d_mean;
     hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, mean_ma, words);
@@ -1918,7 +1924,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
-    size_t b = 256 * 1024 + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
+    size_t b = 512 * 1024 + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
     if (use_f16_path(d, k)) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
