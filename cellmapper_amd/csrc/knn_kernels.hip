@@ -1278,6 +1278,17 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)tiles);
 }
 
+// every R-th row of the (sorted) reference image: the sample whose scan seeds the thresholds of the main scan
+// The first tile of the sample image holds `head` rows and padding: the sample scan refreshes its thresholds once, after
+// that tile, so the rows it appends while its thresholds are still +inf are few.
+__global__ void sample_map(const int *__restrict__ rperm, int64_t n_s, int R, int head, int *__restrict__ sperm) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // position in the sample image
+    const int64_t n_img = n_s + (cmk2::BR - head);
+    if (p >= n_img) return;
+    int64_t i = p < head ? p : (p < cmk2::BR ? -1 : p - (cmk2::BR - head));
+    sperm[p] = i < 0 ? -1 : (rperm ? rperm[i * R] : (int)(i * R));
+}
+
 __global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1456,6 +1467,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int4 *ivf_wla = nullptr, *ivf_wlb = nullptr;
     float *ivf_cthr = nullptr;
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
+    // sample-seeded thresholds of the plain full scan (see run_stage)
+    char *seed_img = nullptr;
+    int *seed_map = nullptr, *seed_cand = nullptr;
+    float *seed_thr = nullptr;
+    bool last_seeded = false;   // the last stage ran from seeded thresholds: a failure may hold fewer than k candidates
     // level 0 state: the grid over the reference rows is built on first use
     void *grid_info = nullptr;
     int64_t *grid_start = nullptr;
@@ -1489,6 +1505,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
         int level = level_in;
+        last_seeded = false;
         if (level == 0) {   // uniform-grid candidate search (d <= 3): same outputs as a filter kernel, one list per query
             if (!grid_info) CM_TRY(cm_grid_build<T>(h, d_ref, n_ref, d, k, &grid_info, &grid_start, &grid_xyz, &grid_idx));
             const int Kc0 = k + knn_slack(k);
@@ -1681,6 +1698,51 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         }
         if (!pruned) {
             if (cenl) CM_TRY(side_full_compute());
+            // Sample-seeded thresholds.  A scan that starts from +inf thresholds appends ~K' ln(n/K') rows per query and
+            // merges on a doubling schedule; most of that churn happens while the thresholds are still far from final.
+            // So the hi*hi filter first scans every 64th row of the image with a short list: its K_s-th value is, for
+            // nearly every query, a threshold with a few hundred rows below it in the full set -- the main scan starts
+            // from it, appends a few times K' rows and merges only when a log fills.  Any starting threshold keeps the
+            // invariant behind the certificate (non-candidates have values >= the final threshold); a query whose seed
+            // was too tight simply ends with fewer than k candidates below it and moves on to the next level.
+            const bool seed = marks && !pilot && rerank && !cenl && level != 4 && !w3 && !wide && p2.S == 1 && p2.n_tiles >= 1024 &&
+                              !getenv("CELLMAP_NO_SEED");
+            if (seed) {
+                const int R = 64;
+                const int head = 64;   // real rows in the first tile of the sample image (see sample_map)
+                const int64_t n_s = (n_ref + R - 1) / R, n_simg = n_s + (cmk2::BR - head);
+                const int n_s_tiles = (int)((n_simg + cmk2::BR - 1) / cmk2::BR);
+                // K_s: the seed is the K_s-th smallest value of a 1/R sample; the number of sample rows among the query's k
+                // nearest is ~Poisson(k/R), and the seed is too tight (fewer than k rows below it) iff that number
+                // reaches K_s: K_s = smallest value with P(Poisson(k/R) >= K_s) < 1e-8 -- a retry stage is then a rarity
+                int Ks = 1;
+                {
+                    const double x = (double)k / R;
+                    double p = exp(-x), cum = p;
+                    while (1.0 - cum > 1e-8 && Ks < 64) { p *= x / Ks; cum += p; ++Ks; }
+                }
+                const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
+                if (!seed_img) {
+                    seed_img = (char *)cm_ws_alloc(h, (size_t)n_s_tiles * tb1);
+                    seed_map = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_simg);
+                    seed_cand = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)p2.nq_pad * Ks);
+                    seed_thr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)p2.nq_pad);
+                    if (!seed_img || !seed_map || !seed_cand || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                }
+                hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_simg + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, head, seed_map);
+                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_simg, d,
+                                   p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
+                                   (unsigned *)nullptr, 0, 1, (const int *)seed_map, (float *)nullptr);
+                cmk2::P1Args sa = a;
+                sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1; sa.Kc = Ks;
+                sa.cand = seed_cand; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
+                sa.no_sched = 2;   // (its cost is appends and merges, not rows: one refresh after the short first tile)
+                const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
+                CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, lds_s, sa));
+                a.thr0 = seed_thr;
+                a.no_sched = 1;
+            }
+            last_seeded = seed;
             CM_TRY(launch(a));
         }
         if (marks) cm_mark(h, 2);
@@ -1769,8 +1831,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
         if (stage == 0) { main_Kc = last_Kc; main_S = last_S; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
+        // (after a seeded stage the failures first get an unseeded pass of the same level: the image is in place, and
+        // most of them only had a seed that was too tight)
         const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0
-                         : (level == 0 ? 4 : (level == 4 ? 0 : ((level < 3 || level == 5) ? 3 : (have_direct ? 4 : 0))));
+                         : (last_seeded ? level
+                            : (level == 0 ? 4 : (level == 4 ? 0 : ((level < 3 || level == 5) ? 3 : (have_direct ? 4 : 0)))));
         if (!next) break;
         int64_t nf = 0;
         CM_TRY(read_flags(&nf));
@@ -1788,7 +1853,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (nf == 0) break;
         // the sliced exact scan is cheaper than another stage for a handful of queries -- except after the grid stage,
         // whose give-ups carry no usable bound (no candidates were evaluated for them)
-        if (nf <= 64 && level != 0) break;
+        // ... nor after a seeded stage: a query whose seed was too tight may hold fewer than k candidates (bound = inf)
+        if (nf <= 64 && level != 0 && !last_seeded) break;
         qmap = flag_out;
         nsub = nf;
         if (ivf_try && flag_s && nf >= 65536) {   // group the flagged queries by bucket: the next stage can prune as well
@@ -1936,6 +2002,8 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
+        b += cm_align((size_t)(n_ref / 64 + 512) * 256) + cm_align(4 * (size_t)(n_ref / 64 + 256)) +
+             cm_align(4 * (size_t)nq_pad * 64) + cm_align(4 * (size_t)nq_pad) + 4096;   // threshold seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
         b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
         if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)

@@ -97,6 +97,11 @@ struct P1Args {
     const int *n_wlist_dev = nullptr;
     int n_wlist = 0;
     int thr0_slot0 = 0;
+    // sample-seeded thresholds (knn_run_staged): thr0[q] is an initial threshold per query row (any value is valid: only
+    // rows below the running threshold are ever appended, so "every non-candidate has a filter value >= the final
+    // threshold" holds whatever it started from).  no_sched: no scheduled threshold refreshes, merges only when a log fills.
+    const float *thr0 = nullptr;
+    int no_sched = 0;      // 1: as described; 2: one scheduled refresh after the first tile, none afterwards (sample scan)
     int *wctr = nullptr;   // work-list mode: items beyond the first gridDim.x are handed out through this counter (zeroed
                            // by the caller): runs differ in length by orders of magnitude, a static assignment does not balance
     unsigned perm_mul = 1; // knn_cand_f16: logical tile t is physical tile (t * perm_mul) % n_tiles (perm_mul coprime with
@@ -370,7 +375,7 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
         const bool sched_ = (T) == next_refresh;                                                               \
         if (sched_ || __ballot(cnt[0] > (FULL_) || cnt[1] > (FULL_)) != 0ull) {                                \
             if (sched_) next_refresh = (T0) + 2 * ((T) - (T0) + 1) - 1;                                        \
-            const int lim_ = sched_ ? 0 : (FULL_);                                                             \
+            const int lim_ = sched_ ? sched_lim : (FULL_);                                                     \
             CM2_MERGE_PASS(lim_)                                                                               \
         }                                                                                                      \
     }
@@ -556,6 +561,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             thr[0] = a.cthr[(qbase + c) * a.S];
             thr[1] = a.cthr[(qbase + 32 + c) * a.S];
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));   // (the wait for these loads belongs here, not in the tile loop)
+        } else if (a.thr0) {
+            thr[0] = a.thr0[qbase + c];
+            thr[1] = a.thr0[qbase + 32 + c];
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));
         }
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
         int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
@@ -601,7 +610,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         CM2_DSR128X(y2, yrow, 0, TB, (ST) * 128 + 64);                                                         \
         CM2_DSR128X(y3, yrow, 0, TB, (ST) * 128 + 96);                                                         \
     }
-        int next_refresh = t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
+        const int sched_lim = a.no_sched ? 8 : 0;   // logs shorter than this are left alone by a scheduled refresh
+        int next_refresh = a.no_sched ? (a.no_sched == 2 ? t0 : 0x7fffffff) : t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
         half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0}; al[s] = ah[s]; }
@@ -711,7 +721,22 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                 p1 = acc1;
                 prbase = ptile * BR + st * 32 + 4 * hh;
             }
+            if (a.no_sched) {
+                // Seeded scan: no refresh schedule, and merges that each wave starts on its own leave the other waves
+                // waiting at the next tile barrier.  So a wave whose logs are half full announces it (tile index in an
+                // LDS word behind the ring, visible after the barrier at the top of the next tile) and at the end of
+                // that next tile EVERY wave of the workgroup merges its longer logs together.
+                const unsigned fl_ = ldsbase + RING * TILEB + 16;
+                if (__ballot(cnt[0] > 32 || cnt[1] > 32) != 0ull) {
+                    const int tn_ = t + 1;
+                    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(fl_ + 4 * (tn_ & 1)), "v"(tn_) : "memory");
+                }
+                int f_;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f_) : "v"(fl_ + 4 * (t & 1)) : "memory");
+                if (__builtin_amdgcn_readfirstlane(f_) == t) next_refresh = t;
+            }
             CM2_REFRESH_T(t, t0, CL - 16 * NST);
+            if (a.no_sched) next_refresh = 0x7fffffff;
             ptile += pstep; if (ptile >= a.n_tiles) ptile -= a.n_tiles;
             ptile_a += pstep; if (ptile_a >= a.n_tiles) ptile_a -= a.n_tiles;
         }
@@ -817,6 +842,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     }
         __builtin_amdgcn_s_barrier();
         if (t0 < t1) CM2_DMA_TILE_L(t0, t0 & 1);
+        const int sched_lim = 0;
         int next_refresh = t0;  // tiles are 512 rows: refresh after 1, 2, 4, ... tiles
         for (int t = t0; t < t1; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -948,6 +974,7 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) { p0[e] = INFINITY; py[e] = 0.f; }
         int prbase = 0;
+        const int sched_lim = 0;
         int next_refresh = t0 + 1;
         for (int t = t0; t < t1; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

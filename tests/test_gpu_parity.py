@@ -420,6 +420,27 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
+@pytest.mark.parametrize("d,k,dtype", [(32, 10, np.float32), (50, 30, np.float64)])
+def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtype):
+    """Large unclustered sets (>= 131 072 queries and reference rows): the main scan starts from thresholds seeded by a
+    scan of every 64th reference row and merges only when a log fills; results identical to the oracle, and to the
+    unseeded search."""
+    rng = np.random.default_rng(64)
+    n_ref, nq = 140000, 135000
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["fallback_queries"] <= 64, st
+    sel = rng.choice(nq, 1000, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+    monkeypatch.setenv("CELLMAP_NO_SEED", "1")
+    dist2, idx2 = hip.knn(ref, qry, k)
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+
+
 def test_bucket_pruning_backs_off_on_unclustered_sets(hip, oracle, monkeypatch):
     """Isotropic data: nothing can be ruled out, the plan says so after pass A and the stage runs as a full scan."""
     rng = np.random.default_rng(62)
