@@ -194,6 +194,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "kernel_ms": p1,
+                         # HIP events around the filter stage on the handle's stream: for large sets the stage is two
+                         # launches of this kernel (sample scan that seeds the thresholds, 1/64 of the rows, + main scan)
+                         "kernel_ms_covers": "all launches of the filter kernel in the step (threshold-seeding sample scan + main scan)",
                          "flops_per_launch": flops, "executed_mfma_tflops": executed / (p1 * 1e-3) / 1e12,
                          "executed_frac_of_peak": executed / (p1 * 1e-3) / 1e12 / peak,
                          "f32_mfma_equivalent_frac": achieved / PEAK_F32_MFMA_TFLOPS},
