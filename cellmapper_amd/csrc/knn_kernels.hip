@@ -1705,7 +1705,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // from it, appends a few times K' rows and merges only when a log fills.  Any starting threshold keeps the
             // invariant behind the certificate (non-candidates have values >= the final threshold); a query whose seed
             // was too tight simply ends with fewer than k candidates below it and moves on to the next level.
-            const bool seed = marks && !pilot && rerank && !cenl && level != 4 && !w3 && !wide && p2.S == 1 && p2.n_tiles >= 1024 &&
+            const bool seed = marks && !pilot && rerank && !cenl && level != 4 && !w3 && p2.S == 1 && p2.n_tiles >= 1024 &&
                               !getenv("CELLMAP_NO_SEED");
             if (seed) {
                 const int R = 64;
@@ -1732,7 +1732,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_simg + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, head, seed_map);
                 hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_simg, d,
                                    p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
-                                   (unsigned *)nullptr, 0, 1, (const int *)seed_map, (float *)nullptr);
+                                   (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr);
                 cmk2::P1Args sa = a;
                 sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1; sa.Kc = Ks;
                 sa.cand = seed_cand; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
@@ -2002,7 +2002,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
-        b += cm_align((size_t)(n_ref / 64 + 512) * 256) + cm_align(4 * (size_t)(n_ref / 64 + 256)) +
+        b += cm_align((size_t)(n_ref / 64 + 512) * 264) + cm_align(4 * (size_t)(n_ref / 64 + 256)) +
              cm_align(4 * (size_t)nq_pad * 64) + cm_align(4 * (size_t)nq_pad) + 4096;   // threshold seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
         b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort

@@ -420,7 +420,7 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
-@pytest.mark.parametrize("d,k,dtype", [(32, 10, np.float32), (50, 30, np.float64)])
+@pytest.mark.parametrize("d,k,dtype", [(32, 10, np.float32), (50, 30, np.float64), (100, 15, np.float32)])
 def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtype):
     """Large unclustered sets (>= 131 072 queries and reference rows): the main scan starts from thresholds seeded by a
     scan of every 64th reference row and merges only when a log fills; results identical to the oracle, and to the
