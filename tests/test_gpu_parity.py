@@ -586,3 +586,54 @@ def test_pipeline_matches_oracle_end_to_end(hip, oracle):
     assert differ.mean() < 1e-3  # only where the top-2 class weights are within rounding of each other
     np.testing.assert_allclose(hip.spmm_dense(indptr, cols, vals, obsm), o["obsm_pred"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(hip.spmm_dense(indptr, cols, vals, X), o["layer_pred"], rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties_config2(oracle, monkeypatch):
+    """BASELINE configs[1] at full size (1.5 M x 1.5 M cells, d=50, k=30), through the device tier of the C ABI, checked by
+    size-independent properties: rows sorted, indices valid and distinct, self-mapping returns every cell as its own
+    nearest neighbour at distance 0, two different candidate-generation paths (seeded / unseeded thresholds) give
+    bit-identical outputs, and a random sample of rows equals the oracle."""
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+
+    pipe = DevicePipeline(0)
+    torch.cuda.set_stream(pipe.stream)
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(11)
+    n, d, k = 1_500_000, 50, 30
+    ref = torch.randn((n, d), generator=g, device=pipe.device)
+    qry = torch.randn((n, d), generator=g, device=pipe.device)
+    dist, idx = pipe.knn(ref, qry, k)
+    torch.cuda.synchronize()
+    st = pipe.h.knn_stats()
+    assert st["fallback_queries"] <= 64, st
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and bool((dist >= 0).all())
+    assert bool(((idx >= 0) & (idx < n)).all())
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())            # k distinct neighbours per row
+    monkeypatch.setenv("CELLMAP_NO_SEED", "1")                 # plain scan from +inf thresholds, refresh schedule
+    dist2, idx2 = pipe.knn(ref, qry, k)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    monkeypatch.delenv("CELLMAP_NO_SEED")
+    rng = np.random.default_rng(12)
+    sel = np.sort(rng.choice(n, 384, replace=False))
+    od, oi = oracle.knn_euclidean(ref.cpu().numpy(), qry[torch.as_tensor(sel, device=pipe.device)].cpu().numpy(), k)
+    assert np.array_equal(idx[torch.as_tensor(sel, device=pipe.device)].cpu().numpy(), oi)
+    assert np.array_equal(dist[torch.as_tensor(sel, device=pipe.device)].cpu().numpy(), od)
+    del dist2, idx2
+    sd, si = pipe.knn(ref, ref, k)                             # self-mapping
+    torch.cuda.synchronize()
+    assert bool((si[:, 0] == torch.arange(n, device=pipe.device)).all()) and bool((sd[:, 0] == 0).all())
+    # transfer at full size: a constant reference label comes back for every query with confidence 1 (rows of the
+    # mapping matrix sum to 1 within float32 rounding); random labels: confidence in (0, 1], codes in range
+    const = torch.full((n,), 3, dtype=torch.int32, device=pipe.device)
+    out = pipe.map_labels(ref, qry, k, const, 20, kernel="gaussian")
+    code, conf = out[0], out[1]
+    torch.cuda.synchronize()
+    assert bool((code == 3).all()) and bool(((conf - 1).abs() < 1e-5).all())
+    labels = torch.randint(0, 20, (n,), generator=g, device=pipe.device, dtype=torch.int32)
+    out = pipe.map_labels(ref, qry, k, labels, 20, kernel="gaussian")
+    code, conf = out[0], out[1]
+    torch.cuda.synchronize()
+    assert bool(((code >= 0) & (code < 20)).all()) and bool(((conf > 0) & (conf <= 1 + 1e-5)).all())
