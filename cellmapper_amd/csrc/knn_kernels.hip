@@ -1172,7 +1172,8 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
                                                   float c_eps, int level, const int4 *__restrict__ wl_a,
                                                   const int *__restrict__ jstar, int4 *__restrict__ wl_b,
-                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len) {
+                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb) {
+    // sb <= IVF_SB: runs (candidate lists) per block this stage may use -- the re-rank holds (sb + 1) * K' candidates
     // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
     // relative error -c_eps and the float64 -> float32 input rounding dlt per coordinate (see knn_rerank)
     __shared__ double s_red[256];
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
         if (u1 > a1) { p0[np] = a1; p1[np] = u1; ++np; }
     }
     // at most IVF_SB runs: close the smallest gaps (never the one that holds the pass-A tiles)
-    while (np > IVF_SB) {
+    while (np > sb) {
         int bi = -1, bg = 0x7fffffff;
         for (int i = 0; i + 1 < np; ++i) {
             const int gap = p0[i + 1] - p1[i];
@@ -1261,7 +1262,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     }
     // long runs are halved while list slots are left: a block that cannot rule out much would otherwise occupy one
     // compute unit for a whole scan while the others idle
-    while (np > 0 && np < IVF_SB) {
+    while (np > 0 && np < sb) {
         int bi = 0;
         for (int i = 1; i < np; ++i) if (p1[i] - p0[i] > p1[bi] - p0[bi]) bi = i;
         const int len = p1[bi] - p0[bi];
@@ -1597,7 +1598,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (w3) return cm_p1f16w_launch(h, p2.grid, p2.lds, x);
             return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);
         };
-        if (ivf_try && full_set && !pilot && rerank && !w3 && 3 * p2.Kc <= RR_NCMAX && nsub >= 65536) {
+        // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
+        // must never be dropped for holding too many (its only way out would be the exact scan with a loose bound)
+        const int ivf_sb = std::min(IVF_SB, RR_NCMAX / p2.Kc - 1);
+        if (ivf_try && full_set && !pilot && rerank && !w3 && ivf_sb >= 2 && nsub >= 65536) {
             const int BRt = level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR;   // reference rows per tile of this level's image
 
             // ---- bucket pruning: pass A over every block's nearest bucket, plan, pass B over what cannot be ruled out
@@ -1665,7 +1669,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                (const float *)ivf_cthr, ivf_S, (const float *)qnorm, (const float *)qlo,
                                cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
                                (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
-                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256);
+                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256, ivf_sb);
             CM_HIP(h, hipGetLastError());
             int *hc = h->d_nflag_pinned + 4;
             CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1688,7 +1692,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 // re-rank capacity: the lists are mostly empty; a query that overflows it is left to the next level -- on
                 // the last level that would be the exact scan, so there the capacity covers every list
                 const bool last_level = level == 4 || (level == 3 && !have_direct);
-                rr_ncap = std::min(RR_NCMAX, (last_level ? ivf_S : 6) * p2.Kc);
+                rr_ncap = std::min(RR_NCMAX, (last_level ? ivf_sb + 1 : 6) * p2.Kc);
                 if (marks) ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the staged search's optional machinery (run on the GPU box): for random shapes around the
+size thresholds, metrics, dtypes and cluster structures, the default search (bucket pruning, seeded thresholds, hints)
+must return bit-identical neighbours and distances to the search with all of it switched off
+(CELLMAP_NO_IVF / CELLMAP_NO_SEED / CELLMAP_NO_HINT).  Prints one line per case; exits non-zero on the first mismatch."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+    pipe = DevicePipeline(0); torch.cuda.set_stream(pipe.stream)
+    rng = np.random.default_rng(a.seed)
+    g = torch.Generator(device=pipe.device); g.manual_seed(a.seed)
+    bad = 0
+    for case in range(a.cases):
+        d = int(rng.choice([16, 20, 24, 32, 40, 50, 61, 64, 100, 128]))
+        k = int(rng.choice([1, 5, 10, 15, 30, 50, 64, 100]))
+        n_ref = int(rng.choice([70_000, 131_072, 140_000, 200_000, 300_000, 500_000]))
+        nq = int(rng.choice([66_000, 100_000, 131_072, 135_000, 200_000, 300_000]))
+        metric = "cosine" if rng.random() < 0.25 else "euclidean"
+        dt = torch.float64 if rng.random() < 0.25 else torch.float32
+        ncl = int(rng.choice([0, 0, 8, 40, 200]))
+        sigma = float(rng.choice([0.05, 0.3, 1.0, 2.0]))
+        def mk(n):
+            x = torch.randn((n, d), generator=g, device=pipe.device, dtype=torch.float32)
+            if ncl:
+                lab = torch.randint(0, ncl, (n,), generator=g, device=pipe.device)
+                x = cen[lab] + sigma * x
+            return x.to(dt)
+        cen = torch.randn((max(ncl, 1), d), generator=g, device=pipe.device) * 5.0
+        ref, qry = mk(n_ref), mk(nq)
+        for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
+            os.environ.pop(v, None)
+        t0 = time.perf_counter()
+        d1, i1 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
+        t1 = time.perf_counter()
+        st1 = pipe.h.knn_stats()
+        for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
+            os.environ[v] = "1"
+        d2, i2 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
+        t2 = time.perf_counter()
+        st2 = pipe.h.knn_stats()
+        ok = bool(torch.equal(i1, i2)) and bool(torch.equal(d1, d2))
+        if not ok and metric == "cosine":   # float32 cosine distances: ties at rounding level may swap equal-valued neighbours
+            ok = bool(torch.equal(d1, d2)) and bool((torch.sort(i1, 1).values == torch.sort(i2, 1).values).float().mean() > 0.9999)
+        print(json.dumps(dict(case=case, d=d, k=k, n_ref=n_ref, nq=nq, metric=metric, f64=dt == torch.float64, clusters=ncl,
+                              sigma=sigma, ok=ok, ms_default=round((t1 - t0) * 1e3, 1), ms_plain=round((t2 - t1) * 1e3, 1),
+                              level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], fb=st1["fallback_queries"],
+                              fb_plain=st2["fallback_queries"])), flush=True)
+        if not ok:
+            bad += 1
+            nbad = int((i1 != i2).any(dim=1).sum())
+            print("MISMATCH rows:", nbad, flush=True)
+        del ref, qry, d1, i1, d2, i2
+    sys.exit(1 if bad else 0)
+
+
+main()

@@ -441,6 +441,24 @@ def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtyp
     assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
 
 
+def test_bucket_pruning_large_k_on_the_last_level(hip, oracle, monkeypatch):
+    """k = 100 on very tight float64 clusters: the direct-difference level is the main stage and prunes; with K' = 125 the
+    re-rank can rank 8 lists per query, so the plan must not hand out more -- a query dropped for holding too many
+    candidates on the last level would go to the exact scan with a loose bound (found by scripts/fuzz_paths.py)."""
+    rng = np.random.default_rng(65)
+    d, k, n_ref, nq = 50, 100, 300000, 100000
+    cen = rng.standard_normal((40, d)) * 5.0
+    ref = cen[rng.integers(0, 40, n_ref)] + 0.05 * rng.standard_normal((n_ref, d))
+    qry = cen[rng.integers(0, 40, nq)] + 0.05 * rng.standard_normal((nq, d))
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["tiles_visited_pct"] > 0 and st["fallback_queries"] <= 64, st
+    sel = rng.choice(nq, 600, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 def test_bucket_pruning_backs_off_on_unclustered_sets(hip, oracle, monkeypatch):
     """Isotropic data: nothing can be ruled out, the plan says so after pass A and the stage runs as a full scan."""
     rng = np.random.default_rng(62)
