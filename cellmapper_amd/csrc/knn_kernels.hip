@@ -1640,7 +1640,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 memcpy(&ov, ho, 8);
                 const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
                 if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
-                if (ov * 10ull > full0 * 6ull) {
+                if (ov * 8ull > full0) {   // (see the threshold after the plan)
                     ivf_try = false;
                     if (marks) h->staged_ivf_skip = 15;
                 }
@@ -1680,7 +1680,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (dbg & 16)
                 fprintf(stderr, "[cellmap dbg] bucket pruning: %llu of %llu (block, tile) pairs to visit, %d pass-B runs for %d blocks\n",
                         tiles, full, hc[0], p2.nqb);
-            if (tiles * 10ull <= full * 6ull) {
+            // Pruning pays when little is left: every list starts its own threshold history (pass A from +inf) and the
+            // re-rank ranks several lists per query, so at 15-25 % of the pairs the pruned stage measured SLOWER than the
+            // full scan (scripts/fuzz_paths.py); at an eighth and below it wins.
+            if (tiles * 8ull <= full) {
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
                     b.wctr = ivf_ctr + 9;
