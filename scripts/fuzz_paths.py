@@ -22,7 +22,7 @@ def main():
         d = int(rng.choice([16, 20, 24, 32, 40, 50, 61, 64, 100, 128]))
         k = int(rng.choice([1, 5, 10, 15, 30, 50, 64, 100]))
         n_ref = int(rng.choice([70_000, 131_072, 140_000, 200_000, 300_000, 500_000]))
-        nq = int(rng.choice([66_000, 100_000, 131_072, 135_000, 200_000, 300_000]))
+        nq = int(rng.choice([3_000, 30_000, 66_000, 100_000, 131_072, 135_000, 200_000, 300_000]))
         metric = "cosine" if rng.random() < 0.25 else "euclidean"
         dt = torch.float64 if rng.random() < 0.25 else torch.float32
         ncl = int(rng.choice([0, 0, 8, 40, 200]))

@@ -422,7 +422,7 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
 
 @pytest.mark.parametrize("d,k,dtype", [(32, 10, np.float32), (50, 30, np.float64), (100, 15, np.float32)])
 def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtype):
-    """Large unclustered sets (>= 131 072 queries and reference rows): the main scan starts from thresholds seeded by a
+    """Unclustered sets over >= 1 024 reference tiles: the main scan starts from thresholds seeded by a
     scan of every 64th reference row and merges only when a log fills; results identical to the oracle, and to the
     unseeded search."""
     rng = np.random.default_rng(64)
