@@ -18,10 +18,12 @@ struct cm_handle_s {
     size_t ws_cap = 0;
     size_t ws_off = 0;
     int64_t knn_stats[4] = {0, 0, 0, 0};
+    int n_cu = 0;   // compute units of the device (lazily queried)
     // staged search: the filter level that certified most queries on the previous call with this (d, k, metric); lets
     // repeated calls on similar data skip the pilot (a stale hint only costs time: the ladder still escalates)
     int staged_hint_level = 0, staged_hint_d = 0, staged_hint_k = 0, staged_hint_metric = 0;
-    int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay
+    int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay ...
+    int64_t staged_ivf_nref = 0, staged_ivf_nq = 0;   // ... on a problem of these sizes
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;

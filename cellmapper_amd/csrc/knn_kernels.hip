@@ -776,9 +776,11 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     p->nq_pad = (nq + qb - 1) / qb * qb;
     p->nqb = (int)(p->nq_pad / qb);
     p->n_tiles = (int)((n_ref + tile_rows - 1) / tile_rows);
-    int ncu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    if (h->n_cu <= 0) {   // (queried once per handle: the call costs a fraction of a millisecond, a stage of the search runs it)
+        int v = 0;
+        h->n_cu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && v > 0) ? v : 256;
+    }
+    const int ncu = h->n_cu;
     const int resident = path == 3 ? ncu : ncu * (8 / cmk2::NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
     int S = 1;
     if (p->nqb < resident) {
@@ -1459,7 +1461,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     bool side_full = false;   // side values computed for every (bucket, reference row) pair
     // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
-    if (!hint_same) h->staged_ivf_skip = 0;
+    // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
+    if (!hint_same || h->staged_ivf_nref != n_ref || h->staged_ivf_nq != nq) h->staged_ivf_skip = 0;
     bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !getenv("CELLMAP_NO_IVF");
     if (ivf_try && h->staged_ivf_skip > 0 && !getenv("CELLMAP_NO_HINT")) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
@@ -1642,7 +1645,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
                 if (ov * 8ull > full0) {   // (see the threshold after the plan)
                     ivf_try = false;
-                    if (marks) h->staged_ivf_skip = 15;
+                    if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
                 }
             }
             if (ivf_try) {
@@ -1699,7 +1702,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (marks) ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
-                if (marks) h->staged_ivf_skip = 15;
+                if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
             }
             }
         }
