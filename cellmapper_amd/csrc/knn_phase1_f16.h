@@ -723,11 +723,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             }
             if (a.no_sched) {
                 // Seeded scan: no refresh schedule, and merges that each wave starts on its own leave the other waves
-                // waiting at the next tile barrier.  So a wave whose logs are half full announces it (tile index in an
+                // waiting at the next tile barrier.  So a wave with a log more than 48 entries long announces it (tile index in an
                 // LDS word behind the ring, visible after the barrier at the top of the next tile) and at the end of
                 // that next tile EVERY wave of the workgroup merges its longer logs together.
                 const unsigned fl_ = ldsbase + RING * TILEB + 16;
-                if (__ballot(cnt[0] > 32 || cnt[1] > 32) != 0ull) {
+                if (__ballot(cnt[0] > 48 || cnt[1] > 48) != 0ull) {   // (48: measured 32 / 48 / 56 -- flat above 48; a tile adds <= 64 per log)
                     const int tn_ = t + 1;
                     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(fl_ + 4 * (tn_ & 1)), "v"(tn_) : "memory");
                 }
