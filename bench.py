@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--ref-shards", type=int, default=0,
                     help="reference shards R (world = query groups x R); 0 = default (2 when world is even), world = pure reference sharding")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (+ --share-gpu) rehearses the N > 1 path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--cpu-sample", type=int, default=768, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--check", type=int, default=256, help="queries verified against the CPU oracle (0 = skip)")
     return ap.parse_args()
@@ -73,11 +76,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from cellmapper_amd.device import DevicePipeline
     from cellmapper_amd.sharded import HipOps, grid_2d, make_groups, shard_bounds, sharded_map_labels
@@ -112,12 +120,15 @@ def main():
     ops = HipOps(pipe)
     torch.cuda.set_stream(pipe.stream)  # library kernels, torch ops and RCCL collectives share one stream
 
+    q_bounds = [None]   # this rank's slice of its query group in the last sharded step
+
     def step():
         if world == 1:
             return pipe.map_labels(ref, qry, a.k, codes, a.ncat, kernel=a.kernel)
-        code, conf, _, _, _ = sharded_map_labels(ops, dist, ref, lo, ref_full_rows, qry, a.k, codes, a.ncat,
-                                                 kernel=a.kernel, exchange=a.exchange, group=pg, ref_world=ref_shards,
-                                                 ref_rank=ref_rank)
+        code, conf, qb, _, _ = sharded_map_labels(ops, dist, ref, lo, ref_full_rows, qry, a.k, codes, a.ncat,
+                                                  kernel=a.kernel, exchange=a.exchange, group=pg, ref_world=ref_shards,
+                                                  ref_rank=ref_rank)
+        q_bounds[0] = qb
         return code, conf
 
     for _ in range(a.warmup):
@@ -202,6 +213,24 @@ def main():
                          "f32_mfma_equivalent_frac": achieved / PEAK_F32_MFMA_TFLOPS},
             "stage_ms_last_step": stages,
         }
+    # rehearsal of the N > 1 path on a one-GPU box (--share-gpu): every rank checks its slice of the sharded result against
+    # the same queries mapped onto the FULL reference by the single-GPU pipeline (identical labels, confidences to 1e-5)
+    if world > 1 and a.share_gpu:
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(0)
+        ref_full = torch.randn((ref_full_rows, a.d), generator=g2, dtype=torch.float32, device=dev) if ref_full_rows <= 250_000 else \
+            torch.cat([torch.randn((min(ref_full_rows, c0 + 250_000) - c0, a.d), generator=g2, dtype=torch.float32, device=dev)
+                       for c0 in range(0, ref_full_rows, 250_000)])
+        qry_full = torch.randn((a.nq, a.d), generator=g2, dtype=torch.float32, device=dev)   # (same stream order as above)
+        ql, qh = q_bounds[0]
+        one = pipe.map_labels(ref_full, qry_full, a.k, codes, a.ncat, kernel=a.kernel)   # (the kernel bandwidth is global)
+        torch.cuda.synchronize()
+        sl = slice(gq_lo + ql, gq_lo + qh)
+        same = bool(torch.equal(one[0][sl], out[0])) and bool(torch.allclose(one[1][sl], out[1], rtol=1e-5, atol=1e-6))
+        print(f"[rehearsal] rank {rank}: sharded slice [{ql}, {qh}) of group {qgroup} vs single-GPU map of all queries: "
+              f"{'identical' if same else 'MISMATCH'}", file=sys.stderr, flush=True)
+        if not same:
+            sys.exit(3)
     # parity spot check + CPU baseline on rank 0 at N=1 only (bounded sample, outside the timed region)
     if rank == 0 and world == 1 and (a.cpu_sample > 0 or a.check > 0):
         ref_np = ref.cpu().numpy()
