@@ -1716,6 +1716,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // invariant behind the certificate (non-candidates have values >= the final threshold); a query whose seed
             // was too tight simply ends with fewer than k candidates below it and moves on to the next level.
             const bool seed = marks && !pilot && rerank && !cenl && level != 4 && !w3 && p2.n_tiles >= 1024 &&
+                              !forced && !(flags & CM_KNN_FORCE_FALLBACK) &&   // (pinned levels do not escalate: a seed failure would have nowhere to go)
                               !getenv("CELLMAP_NO_SEED");
             if (seed) {
                 const int R = 64;
