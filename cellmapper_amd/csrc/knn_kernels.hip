@@ -1463,7 +1463,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
     if (!hint_same || h->staged_ivf_nref != n_ref || h->staged_ivf_nq != nq) h->staged_ivf_skip = 0;
-    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !getenv("CELLMAP_NO_IVF");
+    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !getenv("CELLMAP_NO_IVF");
     if (ivf_try && h->staged_ivf_skip > 0 && !getenv("CELLMAP_NO_HINT")) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
