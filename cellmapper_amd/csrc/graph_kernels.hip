@@ -59,81 +59,92 @@ __global__ void param_kernel(const double *__restrict__ m, int kernel, double *_
     }
 }
 
-// ------------------------------------------------------------------ K1-K3 fused, one wave per row ----
+// ------------------------------------------------------------------ K1-K3 fused, one lane group per row ----
+// G = 32 (k <= 32: two rows per wave) or 64 lanes per row.  Same arithmetic as a COO -> CSR conversion followed by
+// scipy's row normalisation: duplicates summed into their first occurrence in stored order, columns ascending, float64
+// row sum accumulated in column order.
+template <int G>
 __global__ __launch_bounds__(256) void weights_rows(const double *__restrict__ dist, const int64_t *__restrict__ idx,
                                                      int64_t nq, int k, int kernel, const double *__restrict__ param_p,
                                                      double eps, int32_t *__restrict__ cols, float *__restrict__ vals,
                                                      int32_t *__restrict__ cntp, double *__restrict__ conn) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // per wave: wv[k] double, sw[k] double, col[k] int, scol[k] int, head[k] int
-    unsigned char *base = smem + (size_t)w * ((size_t)k * (8 + 8 + 4 + 4 + 4) + 32);
+    constexpr int RPB = 256 / G;   // rows per workgroup
+    const int gl = threadIdx.x % G, g = threadIdx.x / G;
+    // per row: wv[k] double, sw[k] double, col[k] int, scol[k] int, head[k] int
+    unsigned char *base = smem + (size_t)g * ((size_t)k * (8 + 8 + 4 + 4 + 4) + 32);
     base = (unsigned char *)(((uintptr_t)base + 15) & ~(uintptr_t)15);
     double *wv = (double *)base;
     double *sw = wv + k;
     int *col = (int *)(sw + k);
     int *scol = col + k;
     int *head = scol + k;
-    const int64_t i = (int64_t)blockIdx.x * 4 + w;
-    if (i >= nq) return;
+    const int64_t i = (int64_t)blockIdx.x * RPB + g;
+    const bool live = i < nq;   // (all lanes of a wave stay in the kernel: the wave barriers below are wave-wide)
     const double param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? *param_p : 0.0;
     const double two_s2 = 2.0 * (param * param);
-    for (int t = lane; t < k; t += 64) {
-        double dd = dist[i * k + t];
-        int64_t c = idx[i * k + t];
-        bool valid = (c != -1) && isfinite(dd);
-        double wt = 0.0;
-        if (valid) {
-            switch (kernel) {
-            case CM_KERNEL_GAUSSIAN: wt = exp(-(dd * dd) / two_s2); break;
-            case CM_KERNEL_SCARCHES: wt = exp(-dd / param); break;
-            case CM_KERNEL_INVERSE_DISTANCE: wt = 1.0 / (dd + eps); break;
-            case CM_KERNEL_IDENTITY: wt = dd; break;
-            default: wt = 1.0;
+    if (live)
+        for (int t = gl; t < k; t += G) {
+            double dd = dist[i * k + t];
+            int64_t c = idx[i * k + t];
+            bool valid = (c != -1) && isfinite(dd);
+            double wt = 0.0;
+            if (valid) {
+                switch (kernel) {
+                case CM_KERNEL_GAUSSIAN: wt = exp(-(dd * dd) / two_s2); break;
+                case CM_KERNEL_SCARCHES: wt = exp(-dd / param); break;
+                case CM_KERNEL_INVERSE_DISTANCE: wt = 1.0 / (dd + eps); break;
+                case CM_KERNEL_IDENTITY: wt = dd; break;
+                default: wt = 1.0;
+                }
             }
+            wv[t] = wt;
+            col[t] = valid ? (int)c : -1;
         }
-        wv[t] = wt;
-        col[t] = valid ? (int)c : -1;
-    }
     __builtin_amdgcn_wave_barrier();
     // head = first occurrence of its column (duplicates are summed into it, like COO -> CSR does)
-    for (int t = lane; t < k; t += 64) {
-        int c = col[t];
-        int hd = c >= 0;
-        for (int j = 0; j < t && hd; ++j) hd = (col[j] != c);
-        head[t] = hd;
-    }
+    if (live)
+        for (int t = gl; t < k; t += G) {
+            int c = col[t];
+            int hd = c >= 0;
+            for (int j = 0; j < t && hd; ++j) hd = (col[j] != c);
+            head[t] = hd;
+        }
     __builtin_amdgcn_wave_barrier();
     int myheads = 0;
-    for (int t = lane; t < k; t += 64) {
-        if (!head[t]) continue;
-        int c = col[t];
-        int rk = 0;
-        double sum = 0.0;
-        for (int j = 0; j < k; ++j) {
-            int cj = col[j];
-            rk += (head[j] && cj < c) ? 1 : 0;
-            if (cj == c) sum += wv[j];
+    if (live)
+        for (int t = gl; t < k; t += G) {
+            if (!head[t]) continue;
+            int c = col[t];
+            int rk = 0;
+            double sum = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < k; ++j) {
+                int cj = col[j];
+                rk += (head[j] && cj < c) ? 1 : 0;
+                if (cj == c) sum += wv[j];
+            }
+            scol[rk] = c;
+            sw[rk] = sum;
+            ++myheads;
         }
-        scol[rk] = c;
-        sw[rk] = sum;
-        ++myheads;
-    }
     int m = myheads;
-    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    for (int o = G / 2; o > 0; o >>= 1) m += __shfl_xor(m, o);
     __builtin_amdgcn_wave_barrier();
+    if (!live) return;
     // float64 row sum in CSR order (scipy csr_matvec against ones), zero -> 1, multiply by the reciprocal
     double s = 0.0;
+#pragma unroll 8
     for (int r = 0; r < m; ++r) s = s + sw[r] * 1.0;
     if (s == 0.0) s = 1.0;
     const double rinv = 1.0 / s;
-    for (int r = lane; r < k; r += 64) {
+    for (int r = gl; r < k; r += G) {
         bool on = r < m;
         cols[i * k + r] = on ? scol[r] : 0;
         vals[i * k + r] = on ? (float)(sw[r] * rinv) : 0.f;
         if (conn) conn[i * k + r] = on ? sw[r] : 0.0;
     }
-    if (lane == 0) cntp[i] = m;
+    if (gl == 0) cntp[i] = m;
 }
 
 // Presence scores (evaluate.py:426-521): column sums of the un-normalised gaussian connectivities, overall (column 0)
@@ -227,14 +238,17 @@ __global__ void ell_compact(const int32_t *__restrict__ cols, const float *__res
 // ------------------------------------------------------------------ A0: label vote, one wave per row -
 // Per category float32 sums accumulated in ascending column order (scipy csr_matmat), zero sums dropped,
 // argmax ties -> lowest category code (scipy sparse argmax on sorted columns), empty -> (0, 0).
+// G lanes per row: 32 for padded rows of at most 32 entries (two rows per wave), else 64.
+template <int G>
 __global__ __launch_bounds__(256) void vote_rows(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                   const float *__restrict__ vals, int64_t nq, int ell_k,
                                                   const int32_t *__restrict__ cnt, const int32_t *__restrict__ codes,
                                                   int32_t *__restrict__ out_code, float *__restrict__ out_conf) {
-    __shared__ int s_code[4][W_KMAX];
-    __shared__ float s_w[4][W_KMAX];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    constexpr int RPB = 256 / G, CAP = G == 32 ? 32 : W_KMAX;
+    __shared__ int s_code[RPB][CAP];
+    __shared__ float s_w[RPB][CAP];
+    const int lane = threadIdx.x % G, w = threadIdx.x / G;
+    const int64_t i = (int64_t)blockIdx.x * RPB + w;
     if (i >= nq) return;
     int64_t p0;
     int n;
@@ -242,10 +256,10 @@ __global__ __launch_bounds__(256) void vote_rows(const int64_t *__restrict__ ind
     else { p0 = i * ell_k; n = cnt ? cnt[i] : ell_k; }
     float best = 0.f;
     int bcode = 0x7fffffff;
-    if (n <= W_KMAX) {
-        for (int t = lane; t < n; t += 64) { s_code[w][t] = codes[cols[p0 + t]]; s_w[w][t] = vals[p0 + t]; }
+    if (n <= CAP) {
+        for (int t = lane; t < n; t += G) { s_code[w][t] = codes[cols[p0 + t]]; s_w[w][t] = vals[p0 + t]; }
         __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < n; t += 64) {
+        for (int t = lane; t < n; t += G) {
             int c = s_code[w][t];
             bool first = true;
             for (int j = 0; j < t && first; ++j) first = (s_code[w][j] != c);
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256) void vote_rows(const int64_t *__restrict__ ind
             if (sum != 0.f && (sum > best || (sum == best && c < bcode) || bcode == 0x7fffffff)) { best = sum; bcode = c; }
         }
     } else {  // long rows (user-supplied mapping matrices): same algorithm straight from global memory
-        for (int t = lane; t < n; t += 64) {
+        for (int t = lane; t < n; t += G) {
             int c = codes[cols[p0 + t]];
             bool first = true;
             for (int j = 0; j < t && first; ++j) first = (codes[cols[p0 + j]] != c);
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256) void vote_rows(const int64_t *__restrict__ ind
             if (sum != 0.f && (sum > best || (sum == best && c < bcode) || bcode == 0x7fffffff)) { best = sum; bcode = c; }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = G / 2; o > 0; o >>= 1) {
         float ob = __shfl_xor(best, o);
         int oc = __shfl_xor(bcode, o);
         bool take = (oc != 0x7fffffff) && (bcode == 0x7fffffff || ob > best || (ob == best && oc < bcode));
@@ -434,9 +448,15 @@ cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_i
     if (k < 1 || k > W_KMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "mapping matrix: %d neighbours per row exceeds the supported %d", k, W_KMAX);
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     if (nq == 0) return CM_OK;
-    size_t lds = 4 * ((size_t)k * 28 + 32) + 16;
-    hipLaunchKernelGGL(weights_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
-                       d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    if (k <= 32) {   // two rows per wave
+        const size_t lds = 8 * ((size_t)k * 28 + 32) + 16;
+        hipLaunchKernelGGL(weights_rows<32>, dim3((unsigned)((nq + 7) / 8)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
+                           d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    } else {
+        const size_t lds = 4 * ((size_t)k * 28 + 32) + 16;
+        hipLaunchKernelGGL(weights_rows<64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
+                           d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
@@ -489,8 +509,12 @@ cm_status cm_vote_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_c
                       float *d_out_conf) {
     if (n_cat < 1) CM_FAIL(h, CM_E_INVALID, "label vote: n_cat must be >= 1");
     if (nq == 0) return CM_OK;
-    hipLaunchKernelGGL(vote_rows, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_cols, d_vals, nq, ell_k,
-                       d_cnt, d_codes, d_out_code, d_out_conf);
+    if (!d_indptr && ell_k <= 32)   // padded rows of the k-NN path: two rows per wave
+        hipLaunchKernelGGL(vote_rows<32>, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, h->stream, d_indptr, d_cols, d_vals, nq, ell_k,
+                           d_cnt, d_codes, d_out_code, d_out_conf);
+    else
+        hipLaunchKernelGGL(vote_rows<64>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_cols, d_vals, nq, ell_k,
+                           d_cnt, d_codes, d_out_code, d_out_conf);
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
