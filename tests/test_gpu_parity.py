@@ -655,3 +655,30 @@ def test_full_size_properties_config2(oracle, monkeypatch):
     code, conf = out[0], out[1]
     torch.cuda.synchronize()
     assert bool(((code >= 0) & (code < 20)).all()) and bool(((conf > 0) & (conf <= 1 + 1e-5)).all())
+
+
+@pytest.mark.parametrize("k", [8, 30, 32, 33, 64, 100])
+def test_weights_and_vote_row_groupings(hip, oracle, k):
+    """Mapping matrix and label vote over ragged rows (padding, duplicate columns, unsorted columns) for row lengths on
+    both sides of the 32-entry boundary (two rows per wave below it, one above): identical structure, float64
+    connectivities to 1e-14, normalised float32 weights to 2e-7, vote equal to the oracle's."""
+    rng = np.random.default_rng(70 + k)
+    nq, n_ref = 5003, 4000
+    idx = rng.integers(0, n_ref, (nq, k)).astype(np.int64)
+    idx[rng.random((nq, k)) < 0.05] = -1                       # padding in arbitrary positions
+    dup = rng.random(nq) < 0.3                                  # rows with a duplicated column
+    idx[dup, k - 1] = idx[dup, 0]
+    dist = np.sort(rng.random((nq, k)) * 3.0, axis=1)
+    dist[idx < 0] = np.inf
+    for kern in ("gaussian", "inverse_distance"):
+        indptr, cols, vals, conn, _ = hip.mapping_matrix(dist, idx, n_ref, kern, want_conn=True)
+        w, _ = oracle.kernel_weights(dist, idx, kern)
+        oip, oc, ov32, ov64 = oracle.mapping_matrix(w, dist, idx, n_ref)
+        assert np.array_equal(indptr, oip) and np.array_equal(cols, oc)
+        np.testing.assert_allclose(conn, ov64, rtol=1e-14)
+        np.testing.assert_allclose(vals, ov32, rtol=2e-7)
+        codes = rng.integers(0, 11, n_ref).astype(np.int32)
+        code, conf = hip.label_vote(indptr, cols, vals, codes, 11)
+        ocode, oconf = oracle.label_vote(oip, oc, ov32, codes, 11)
+        np.testing.assert_allclose(conf, oconf, rtol=1e-5)
+        assert (code != ocode).mean() < 2e-3                    # top-2 class sums within float32 rounding
