@@ -24,7 +24,7 @@ CM_F32, CM_F64 = 0, 1
 METRICS = {"euclidean": 0, "l2": 0, "cosine": 1}
 FORMS = {"auto": 0, "gemm": 1, "direct": 2}
 KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
-CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK = 1, 2
+CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK, CM_KNN_F64_OUT = 1, 2, 4
 
 _STATUS_EXC = {1: ValueError, 2: MemoryError, 3: RuntimeError, 4: ValueError, 5: NotImplementedError, 6: RuntimeError}
 
@@ -33,7 +33,7 @@ _lib_lock = threading.Lock()
 
 EXPORTS = [
     "cm_version", "cm_device_count", "cm_create", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
-    "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
+    "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
@@ -66,6 +66,7 @@ def load_library():
         lib.cm_knn.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp]
         lib.cm_knn_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i64, i32, vp, vp]
         lib.cm_knn_merge_dev.argtypes = [vp, vp, vp, i32, i64, i32, i32, vp, vp]
+        lib.cm_knn_merge_strided_dev.argtypes = [vp, vp, vp, i32, i64, i64, i32, i32, vp, vp]
         lib.cm_mapping_matrix.argtypes = [vp, vp, vp, i64, i32, i64, i32, dbl, vp, vp, vp, vp, vp, vp]
         lib.cm_dist_moments_dev.argtypes = [vp, vp, vp, i64, vp, vp]
         lib.cm_kernel_param_dev.argtypes = [vp, vp, i32, vp]
@@ -83,6 +84,12 @@ def load_library():
         lib.cm_presence_scores.argtypes = [vp, vp, vp, i64, i32, i64, vp, i32, vp]
         lib.cm_set_profiling.argtypes = [vp, i32]
         lib.cm_stage_times.argtypes = [vp, vp]
+        lib.cm_ingest_distances.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
+        lib.cm_expression_metrics.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
+        lib.cm_expression_metrics_dev.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
+        lib.cm_debug_mfma_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+        lib.cm_version.argtypes = []
+        lib.cm_device_count.argtypes = []
         for name in EXPORTS:
             fn = getattr(lib, name)
             if name not in ("cm_version", "cm_device_count", "cm_last_error"):
@@ -148,13 +155,15 @@ class Handle:
         return {names[i]: float(out[i]) for i in range(1, 8)}
 
     def knn_stats(self):
-        out = np.zeros(4, np.int64)
+        out = np.zeros(8, np.int64)
         self.call("cm_knn_stats", _ptr(out))
         # out[3]: 1 = f32-input MFMA, 2 = split-fp16 MFMA (K<=64), 3 = low-d VALU, 4 = split-fp16 MFMA (K=128)
         return dict(fallback_queries=int(out[0]), candidates=int(out[1]), ref_splits=int(out[2]) % 100,
                     filter_products=int(out[2]) // 100, lowd_path=int(out[3]) % 100,
                     # bucket pruning: (query block, reference tile) pairs visited, per cent of a full scan (0 = not used)
-                    tiles_visited_pct=int(out[3]) // 100)
+                    tiles_visited_pct=int(out[3]) // 100,
+                    # 1 = a query's exact-fallback list overflowed (results truncated): device-tier callers must check
+                    fallback_overflow=int(out[4]))
 
     # ------------------------------------------------------------------ host tier (numpy in / numpy out)
     def knn(self, ref: np.ndarray, qry: np.ndarray, k: int, metric: str = "euclidean", form: str = "auto"):

@@ -94,7 +94,7 @@ void *cm_ws_alloc(cm_handle_t h, size_t bytes) {
 
 extern "C" {
 
-int cm_version(void) { return 100; }
+int cm_version(void) { return 200; }
 
 int cm_device_count(void) {
     int n = 0;
@@ -178,10 +178,12 @@ cm_status cm_synchronize(cm_handle_t h) {
     return check_fallback_overflow(h);
 }
 
-cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]) {
+cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]) {
     if (!h || !out) return CM_E_INVALID;
     h->knn_stats[0] = h->d_nflag_pinned[0];
     for (int i = 0; i < 4; ++i) out[i] = h->knn_stats[i];
+    out[4] = h->d_nflag_pinned[1];   // exact-fallback overflow (valid once the stream has been synchronised)
+    out[5] = out[6] = out[7] = 0;
     return CM_OK;
 }
 
@@ -196,7 +198,14 @@ cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
 cm_status cm_knn_merge_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
                            int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx) {
     CM_TRY(begin_call(h, 0));
-    return cm_knn_merge_run(h, d_dist, d_idx, nparts, nq, k, sqrt_out, d_out_dist, d_out_idx);
+    return cm_knn_merge_run(h, d_dist, d_idx, nparts, nq * k, nq, k, sqrt_out, d_out_dist, d_out_idx);
+}
+
+cm_status cm_knn_merge_strided_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts,
+                                   int64_t part_stride, int64_t nq, int32_t k, int32_t sqrt_out, double *d_out_dist,
+                                   int64_t *d_out_idx) {
+    CM_TRY(begin_call(h, 0));
+    return cm_knn_merge_run(h, d_dist, d_idx, nparts, part_stride, nq, k, sqrt_out, d_out_dist, d_out_idx);
 }
 
 cm_status cm_dist_moments_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n,
@@ -244,8 +253,6 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
     size_t nk = (size_t)nq * k;
     size_t extra = cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024;
     CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype) + extra));
-    if (metric == CM_METRIC_COSINE && dtype == CM_F32)
-        CM_FAIL(h, CM_E_UNSUPPORTED, "fused pipeline: cosine on float32 returns float32 distances; use the staged calls");
     double *dist = d_out_dist ? d_out_dist : (double *)cm_ws_alloc(h, 8 * nk);
     int64_t *idx = d_out_idx ? d_out_idx : (int64_t *)cm_ws_alloc(h, 8 * nk);
     int32_t *cols = (int32_t *)cm_ws_alloc(h, 4 * nk);
@@ -254,7 +261,8 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
     double *m3 = (double *)cm_ws_alloc(h, 64);
     if (!dist || !idx || !cols || !vals || !cnt || !m3) CM_FAIL(h, CM_E_NOMEM, "fused pipeline: device workspace exhausted");
     double *param = m3 + 5;
-    CM_TRY(cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, CM_FORM_AUTO, 0, 0, dist, idx));
+    // (cosine on float32 input: the fused pipeline keeps the float64 values the search ranked by, CM_KNN_F64_OUT)
+    CM_TRY(cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, CM_FORM_AUTO, 0, CM_KNN_F64_OUT, dist, idx));
     CM_TRY(kernel_param_dev(h, dist, idx, (int64_t)nk, kernel, m3, param));
     cm_mark(h, 5);
     CM_TRY(cm_weights_run(h, dist, idx, nq, k, n_ref, kernel, param, epsilon, cols, vals, cnt, nullptr));

@@ -64,8 +64,8 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
                      void *d_out_dist, int64_t *d_out_idx);
-cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
-                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx);
+cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t part_stride,
+                           int64_t nq, int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx);
 
 // ---- graph kernel + transfers (graph_kernels.hip) ----
 cm_status cm_moments_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, const double *d_center,

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (rk < k) {
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
-            if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
+            if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
             else reinterpret_cast<double *>(out_dist)[io * k + rk] = o;
             out_idx[io * k + rk] = (int64_t)id + idx_offset;
             if (rk == k - 1) s_kth[w] = v;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
             if (rk < k) {
                 double o = v;
                 if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
-                if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+                if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
                 else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
                 out_idx[i * k + rk] = (int64_t)id + idx_offset;
             }
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
             if (rk < k) {
                 double o = v;
                 if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
-                if (metric == CM_METRIC_COSINE) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+                if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
                 else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
                 out_idx[i * k + rk] = (int64_t)id + idx_offset;
             }
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
 // ------------------------------------------------------------------ shard merge ---------------------
 // parts [nparts, nq, k] -> the k smallest by (distance, global index).  One wave per query.
 __global__ __launch_bounds__(256) void knn_merge(const double *__restrict__ pd, const int64_t *__restrict__ pi,
-                                                  int nparts, int64_t nq, int k, int sqrt_out,
+                                                  int nparts, int64_t part_stride, int64_t nq, int k, int sqrt_out,
                                                   double *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
     __shared__ double s_v[4][MG_NCMAX];
     __shared__ int64_t s_i[4][MG_NCMAX];
@@ -672,8 +672,8 @@ __global__ __launch_bounds__(256) void knn_merge(const double *__restrict__ pd, 
     const int nc = nparts * k;
     for (int s = lane; s < nc; s += 64) {
         int p = s / k, t = s - p * k;
-        s_v[w][s] = pd[((int64_t)p * nq + i) * k + t];
-        s_i[w][s] = pi[((int64_t)p * nq + i) * k + t];
+        s_v[w][s] = pd[(int64_t)p * part_stride + i * k + t];
+        s_i[w][s] = pi[(int64_t)p * part_stride + i * k + t];
     }
     __builtin_amdgcn_wave_barrier();
     for (int s = lane; s < nc; s += 64) {
@@ -2054,11 +2054,12 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     CM_FAIL(h, CM_E_INVALID, "k-NN: unknown dtype id %d", dtype);
 }
 
-cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
-                           int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx) {
+cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t part_stride,
+                           int64_t nq, int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx) {
     if (nparts < 1 || k < 1 || nparts * k > MG_NCMAX) CM_FAIL(h, CM_E_INVALID, "merge: nparts*k = %d exceeds %d", nparts * k, MG_NCMAX);
+    if (part_stride < nq * k) CM_FAIL(h, CM_E_INVALID, "merge: part stride %lld is smaller than nq*k = %lld", (long long)part_stride, (long long)(nq * k));
     if (nq == 0) return CM_OK;
-    hipLaunchKernelGGL(knn_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_dist, d_idx, nparts, nq, k,
+    hipLaunchKernelGGL(knn_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_dist, d_idx, nparts, part_stride, nq, k,
                        sqrt_out, d_out_dist, d_out_idx);
     CM_HIP(h, hipGetLastError());
     return CM_OK;

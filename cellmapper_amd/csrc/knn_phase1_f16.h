@@ -15,7 +15,7 @@
 //   * |y|^2 rides in three spare feature slots as fp16 digits (exact to 2^-33), -2 and the scale are folded into
 //     the rows, so the accumulator is the ranking value |y|^2 - 2 q.y with no epilogue arithmetic;
 //   * 128-row reference tiles are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4; no VGPR staging, no
-//     ds_write pass) into a 2-deep ring, one s_barrier per tile; the global tile image is byte-identical to the LDS
+//     ds_write pass) into a ring of 8 hi-only / 4 full tiles, one s_barrier per tile; the global tile image is byte-identical to the LDS
 //     image, rows XOR-swizzled by 16-byte granule so the fragment ds_read_b128s are bank-conflict free;
 //   * queries sit on the accumulator's lane (column) index: each lane owns 2 queries x 16 rows per tile, the filter is
 //     a v_min3 tree + one compare against a threshold register; a passing value is appended with a plain 8-byte store

@@ -32,6 +32,14 @@ class DevicePipeline:
         if self.stream is not None:
             self.h.set_stream(self.stream.cuda_stream)
 
+    def synchronize(self):
+        """Wait for the stream and surface what the asynchronous device tier could not return as a status: a query whose
+        exact-fallback list overflowed has a truncated neighbour list (cm_knn_stats out[4])."""
+        self.torch.cuda.synchronize(self.device)
+        if self.h.knn_stats()["fallback_overflow"]:
+            raise NotImplementedError("k-NN exact fallback overflow: more than 2048 reference rows tie within a query's "
+                                      "k-th distance")
+
     def _dtype_id(self, t):
         if t.dtype == self.torch.float32:
             return CM_F32
@@ -39,13 +47,21 @@ class DevicePipeline:
             return CM_F64
         raise ValueError(f"unsupported dtype {t.dtype}")
 
-    def knn(self, ref, qry, k, metric="euclidean", form="auto", idx_offset=0, squared=False, force_fallback=False):
+    def knn(self, ref, qry, k, metric="euclidean", form="auto", idx_offset=0, squared=False, force_fallback=False,
+            f64_out=False, out=None):
+        """``out=(dist, idx)``: caller-provided contiguous [nq, k] tensors (e.g. planes of a packed exchange buffer)."""
         t = self.torch
         nq = qry.shape[0]
-        out_dt = t.float64 if METRICS[metric] == 0 else ref.dtype
-        dist = t.empty((nq, k), dtype=out_dt, device=self.device)
-        idx = t.empty((nq, k), dtype=t.int64, device=self.device)
-        flags = (1 if squared else 0) | (2 if force_fallback else 0)
+        out_dt = t.float64 if (METRICS[metric] == 0 or f64_out) else ref.dtype
+        if out is None:
+            dist = t.empty((nq, k), dtype=out_dt, device=self.device)
+            idx = t.empty((nq, k), dtype=t.int64, device=self.device)
+        else:
+            dist, idx = out
+            if dist.dtype != out_dt or idx.dtype != t.int64 or tuple(dist.shape) != (nq, k) or tuple(idx.shape) != (nq, k) \
+                    or not (dist.is_contiguous() and idx.is_contiguous()):
+                raise ValueError("knn(out=...): need contiguous [nq, k] tensors (distance dtype %s, indices int64)" % out_dt)
+        flags = (1 if squared else 0) | (2 if force_fallback else 0) | (4 if f64_out else 0)
         self.h.call("cm_knn_dev", _dp(ref), ref.shape[0], _dp(qry), nq, ref.shape[1], self._dtype_id(ref), int(k),
                     METRICS[metric], FORMS[form], int(idx_offset), flags, _dp(dist), _dp(idx))
         return dist, idx
@@ -58,6 +74,22 @@ class DevicePipeline:
         oi = t.empty((nq, k), dtype=t.int64, device=self.device)
         self.h.call("cm_knn_merge_dev", _dp(dist_parts), _dp(idx_parts), int(nparts), int(nq), int(k),
                     1 if sqrt_out else 0, _dp(od), _dp(oi))
+        return od, oi
+
+    def merge_strided(self, buf, nparts, part_stride, dist_off, idx_off, nq, k, sqrt_out=True):
+        """Merge ``nparts`` lists per query out of ONE packed buffer of 8-byte words (the received exchange buffer):
+        part p's distance rows start at word ``dist_off + p*part_stride``, its index rows at ``idx_off + p*part_stride``."""
+        t = self.torch
+        if buf.element_size() != 8 or not buf.is_contiguous():
+            raise ValueError("merge_strided: need a contiguous buffer of 8-byte words")
+        need = (nparts - 1) * part_stride + max(dist_off, idx_off) + nq * k
+        if need > buf.numel():
+            raise ValueError(f"merge_strided: buffer of {buf.numel()} words is too small (need {need})")
+        od = t.empty((nq, k), dtype=t.float64, device=self.device)
+        oi = t.empty((nq, k), dtype=t.int64, device=self.device)
+        base = buf.data_ptr()
+        self.h.call("cm_knn_merge_strided_dev", C.c_void_p(base + 8 * dist_off), C.c_void_p(base + 8 * idx_off),
+                    int(nparts), int(part_stride), int(nq), int(k), 1 if sqrt_out else 0, _dp(od), _dp(oi))
         return od, oi
 
     def moments(self, dist, idx, center=None):

@@ -8,7 +8,8 @@ host like upstream.
 
 ``evaluate_expression_transfer`` mirrors ``evaluate.py:236-323``: the per-gene agreement between measured and imputed
 expression (Pearson r, z-scored RMSE, Jensen-Shannon distance) is one column-moment kernel family
-(``cm_expression_metrics``) instead of a Python loop over genes calling scipy; Spearman is not provided.  The label
+(``cm_expression_metrics``) instead of a Python loop over genes calling scipy; Spearman rho ranks every gene column
+on the device (``rank_kernels.hip``).  The label
 evaluation metrics of the reference's mixin (sklearn classification reports, plots) are out of scope.
 """
 from __future__ import annotations

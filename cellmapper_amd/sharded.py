@@ -6,9 +6,10 @@ rows ``[lo, hi)`` of its shard (contiguous split), the full label-code vector, a
 
 1. local exact top-k of every query against the rank's shard, with GLOBAL reference indices (``idx_offset``)
    and squared float64 distances;
-2. ONE exchange over RCCL/xGMI: an all-to-all by query slice -- rank j receives, from every rank, the local
-   top-k of query slice j -- ``[world, nq/world, k]`` (8x less traffic than an all-gather of the full lists;
-   ``exchange="allgather"`` is the all-gather variant of the north-star wording);
+2. ONE collective over RCCL/xGMI on a packed buffer (distances and indices travel together): an all-to-all by
+   query slice -- rank j receives, from every rank, the local top-k of query slice j -- ``[world, 2, nq/world, k]``
+   (8x less traffic than an all-gather of the full lists; ``exchange="allgather"`` is the all-gather variant of the
+   north-star wording);
 3. k-way merge by (distance, global index): the same tie rule as the single-GPU search, so indices stay exact;
 4. the global kernel bandwidth needs the mean (and for scarches the variance) of ALL nq*k distances: a
    3-double all-reduce;
@@ -43,11 +44,21 @@ class HipOps:
         self.p = pipeline
         self.t = pipeline.torch
 
-    def local_knn(self, ref_shard, qry, k, metric, idx_offset):
-        return self.p.knn(ref_shard, qry, k, metric=metric, idx_offset=idx_offset, squared=True)
+    def local_knn_packed(self, ref_shard, qry, k, metric, idx_offset, nq_pad):
+        """Local exact top-k written straight into the PACKED exchange buffer ``[2, nq_pad, k]`` of 8-byte words:
+        plane 0 = float64 ranking values (squared for euclidean, float64 cosine distances), plane 1 = int64 global indices.
+        One buffer = one collective per exchange.  Padded rows are zero (never merged: slices are cut at nq)."""
+        t = self.t
+        nq = qry.shape[0]
+        buf = t.zeros((2, nq_pad, k), dtype=t.int64, device=qry.device) if nq_pad != nq else \
+            t.empty((2, nq_pad, k), dtype=t.int64, device=qry.device)
+        self.p.knn(ref_shard, qry, k, metric=metric, idx_offset=idx_offset, squared=True, f64_out=True,
+                   out=(buf[0].view(t.float64)[:nq], buf[1][:nq]))
+        return buf
 
-    def merge(self, dparts, iparts, k):
-        return self.p.merge(dparts.contiguous(), iparts.contiguous(), k, sqrt_out=True)
+    def merge_packed(self, buf, nparts, part_stride, dist_off, idx_off, nq, k, metric):
+        """k-way merge of ``nparts`` lists per query living in one packed buffer (offsets / stride in 8-byte words)."""
+        return self.p.merge_strided(buf, nparts, part_stride, dist_off, idx_off, nq, k, sqrt_out=(metric != "cosine"))
 
     def moments(self, dist, idx, center=None):
         return self.p.moments(dist, idx, center)
@@ -60,14 +71,8 @@ class HipOps:
         indptr, oc, ov = self.p.to_csr(cols, vals, cnt)
         return self.p.label_vote(indptr, oc, ov, codes, n_cat)
 
-    def empty_like_parts(self, world, n, k, like):
-        return self.t.empty((world, n, k), dtype=like.dtype, device=like.device)
-
-    def pad_rows(self, x, n):
-        if x.shape[0] == n:
-            return x
-        pad = self.t.zeros((n - x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        return self.t.cat([x, pad], 0)
+    def empty_words(self, n, like):
+        return self.t.empty((n,), dtype=self.t.int64, device=like.device)
 
 
 def grid_2d(world: int, ref_shards: int | None = None):
@@ -103,6 +108,9 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int):
     return mine
 
 
+SUPPORTED_METRICS = ("euclidean", "cosine")
+
+
 def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, codes, n_cat, metric="euclidean",
                        kernel="gaussian", epsilon=1e-8, exchange="alltoall", group=None, ref_world=None, ref_rank=None):
     """Run one sharded step.  Returns ``(code, conf, (q_lo, q_hi), dist, idx)`` for this rank's query slice.
@@ -111,36 +119,40 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
     ``qry`` holds the queries of this rank's QUERY GROUP; ``group`` / ``ref_world`` / ``ref_rank`` describe the
     reference-shard group the exchange runs in (default: the whole world = pure reference sharding).  The bandwidth
     statistics are always reduced over the whole world.  ``(q_lo, q_hi)`` is relative to ``qry``.
+
+    The exchange is ONE collective on a packed buffer (ranking values and global indices travel together as 8-byte
+    words): ``all_to_all_single`` of ``[world][2][per][k]`` (default), or ``all_gather_into_tensor`` of ``[2][nq_pad][k]``.
+    Shard-local lists carry the float64 values the single-GPU search ranks by (squared euclidean; float64 cosine even
+    for float32 input), so the merged order -- and therefore every index -- equals the unsharded result.
     """
+    if metric not in SUPPORTED_METRICS:
+        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, cosine).")
     n_all = dist_mod.get_world_size()
     world = n_all if ref_world is None else ref_world
     rank = dist_mod.get_rank() if ref_rank is None else ref_rank
     nq = qry.shape[0]
     per = (nq + world - 1) // world
     nq_pad = per * world
-    d2, gi = ops.local_knn(ref_shard, qry, k, metric, shard_lo)  # [nq, k] squared float64, global int64 indices
+    send = ops.local_knn_packed(ref_shard, qry, k, metric, shard_lo, nq_pad)   # [2, nq_pad, k] 8-byte words
+    pk = per * k
     if world == 1:
-        dist, idx = ops.merge(d2[None], gi[None], k)
         q_lo, q_hi = 0, nq
+        dist, idx = ops.merge_packed(send, 1, 2 * nq_pad * k, 0, nq_pad * k, nq, k, metric)
     else:
-        d2p, gip = ops.pad_rows(d2, nq_pad), ops.pad_rows(gi, nq_pad)
+        q_lo, q_hi = slice_bounds(nq, world, rank)
+        n_mine = max(q_hi - q_lo, 0)
         if exchange == "alltoall":
-            rd = ops.empty_like_parts(world, per, k, d2p)
-            ri = ops.empty_like_parts(world, per, k, gip)
-            dist_mod.all_to_all_single(rd.view(world * per, k), d2p.view(world * per, k), group=group)
-            dist_mod.all_to_all_single(ri.view(world * per, k), gip.view(world * per, k), group=group)
+            # chunk j of the send buffer = what rank j merges: [2][per][k] of query slice j
+            packed = send.view(2, world, pk).transpose(0, 1).contiguous().view(-1)
+            recv = ops.empty_words(world * 2 * pk, send)
+            dist_mod.all_to_all_single(recv, packed, group=group)
+            dist, idx = ops.merge_packed(recv, world, 2 * pk, 0, pk, n_mine, k, metric)
         elif exchange == "allgather":
-            gd = ops.empty_like_parts(world, nq_pad, k, d2p)
-            gg = ops.empty_like_parts(world, nq_pad, k, gip)
-            dist_mod.all_gather_into_tensor(gd.view(world * nq_pad, k), d2p, group=group)
-            dist_mod.all_gather_into_tensor(gg.view(world * nq_pad, k), gip, group=group)
-            rd = gd[:, rank * per:(rank + 1) * per]
-            ri = gg[:, rank * per:(rank + 1) * per]
+            recv = ops.empty_words(world * 2 * nq_pad * k, send)
+            dist_mod.all_gather_into_tensor(recv, send.view(-1), group=group)
+            dist, idx = ops.merge_packed(recv, world, 2 * nq_pad * k, rank * pk, nq_pad * k + rank * pk, n_mine, k, metric)
         else:
             raise ValueError(f"unknown exchange '{exchange}'")
-        q_lo, q_hi = slice_bounds(nq, world, rank)
-        n_mine = q_hi - q_lo
-        dist, idx = ops.merge(rd[:, :max(n_mine, 0)], ri[:, :max(n_mine, 0)], k)
     # global bandwidth: all-reduce the moments of the merged distances
     param = None
     if kernel in ("gaussian", "scarches"):

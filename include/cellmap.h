@@ -65,6 +65,8 @@ typedef enum {
 /* cm_knn_dev flags */
 #define CM_KNN_SQUARED 1      /* return squared (euclidean) distances; used by the sharded merge */
 #define CM_KNN_FORCE_FALLBACK 2 /* testing: send every query through the exact float64 fallback */
+#define CM_KNN_F64_OUT 4      /* cosine on float32 input: write float64 distances (the values the search ranked by) instead
+                                 of sklearn's float32; the sharded merge needs them to reproduce the single-GPU order */
 
 int cm_version(void);
 int cm_device_count(void);
@@ -85,8 +87,11 @@ cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
 /* counters of the last cm_knn / cm_knn_dev call: out[0] = queries sent to the exact fallback,
  * out[1] = candidate-list size K', out[2] = reference splits + 100 * (filter level the full set started at),
  * out[3] = filter family (1 f32-input MFMA, 2 split-fp16 MFMA K <= 64, 3 direct VALU / grid, 4 split-fp16 MFMA K = 128)
- *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning) */
-cm_status cm_knn_stats(cm_handle_t h, int64_t out[4]);
+ *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning),
+ * out[4] = 1 if the exact fallback overflowed (more than 2048 rows within a query's bound: that query's list is
+ *          truncated; cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that
+ *          synchronise the stream themselves must check it), out[5..7] reserved (0).  Read after the stream is idle. */
+cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
 
 /* ---------------------------------------------------------------- K0: exact k-NN ------------------
  * Replaces Neighbors.compute_neighbors' backend call (knn.py:428-440, sklearn branch;
@@ -100,7 +105,8 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
                  int32_t dtype, int32_t k, int32_t metric, int32_t form, void *out_dist, int64_t *out_idx);
 
 /* Device tier of the same.  idx_offset is added to every returned index (reference shard offset,
- * SURVEY.md 8e).  out_dist is float64 [nq,k] for euclidean (squared if CM_KNN_SQUARED), input dtype for cosine. */
+ * SURVEY.md 8e).  out_dist is float64 [nq,k] for euclidean (squared if CM_KNN_SQUARED), input dtype for cosine
+ * (float64 with CM_KNN_F64_OUT). */
 cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
                      void *d_out_dist, int64_t *d_out_idx);
@@ -110,6 +116,12 @@ cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
  * Keeps the k smallest by (distance, index) -- the same tie rule as a single-GPU search. */
 cm_status cm_knn_merge_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts, int64_t nq,
                            int32_t k, int32_t sqrt_out, double *d_out_dist, int64_t *d_out_idx);
+/* The same on the PACKED exchange buffer of the multi-GPU path (one collective carries distances and indices): part p's
+ * rows start at d_dist + p * part_stride and d_idx + p * part_stride (strides in 8-byte elements, >= nq*k), e.g. a
+ * received all-to-all buffer [nparts][2][nq][k] has d_idx = d_dist + nq*k and part_stride = 2*nq*k. */
+cm_status cm_knn_merge_strided_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int32_t nparts,
+                                   int64_t part_stride, int64_t nq, int32_t k, int32_t sqrt_out, double *d_out_dist,
+                                   int64_t *d_out_idx);
 
 /* ------------------------------------------- K1-K3: graph kernel -> row-normalised mapping matrix ---
  * Replaces NeighborsResults.knn_graph_connectivities (knn.py:134-164, _compute_kernel_values :166-226,

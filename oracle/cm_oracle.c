@@ -86,87 +86,120 @@ static int pair_cmp(const void *a, const void *b) {
  *       (_argkmin.pyx.tp `_compute_and_reduce_distances_on_chunks`, _middle_term_computer GEMM alpha=-2)
  *   form 1 ("direct", sklearn kd_tree for d <= 15): float64 sum_j (q_j - y_j)^2, sqrt.
  * Output rows are sorted ascending by (distance, index).  qry is "X" and ref is "Y" in sklearn's naming. */
+/* The scan is cache-blocked (round 2; the per-pair arithmetic and the per-query visiting order are unchanged, so the
+ * golden vectors still pin it): the reference is re-laid once into feature-major tiles Rt[tile][c][CMO_RB] (set-up,
+ * timed separately: cmo_last_setup_seconds), a thread owns a block of CMO_QB queries and walks the tiles in ascending
+ * order, so a tile is read from DRAM once per CMO_QB queries instead of once per query; inside a tile the dot products
+ * of one query with CMO_RB rows advance together, one fused multiply-add per (row, feature) in ascending feature order
+ * -- the same chain as before, vectorised ACROSS rows by the compiler (target_clones: AVX-512 / AVX2+FMA / baseline). */
+#define CMO_RB 256
+#define CMO_QB 32
+static double g_last_setup_s = 0.0;
+double cmo_last_setup_seconds(void) { return g_last_setup_s; }
+static double now_s(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+__attribute__((target_clones("avx512f", "avx2,fma", "default")))
+static void tile_gemm_form(const double *restrict q, const double *restrict Rt, const double *restrict yn, int32_t d,
+                           double xn, double *restrict d2) {
+    double acc[CMO_RB];
+    for (int j = 0; j < CMO_RB; j++) acc[j] = 0.0;
+    for (int32_t c = 0; c < d; c++) {
+        const double qc = q[c];
+        const double *restrict y = Rt + (size_t)c * CMO_RB;
+        for (int j = 0; j < CMO_RB; j++) acc[j] = fma(qc, y[j], acc[j]);
+    }
+    for (int j = 0; j < CMO_RB; j++) {
+        double v = (xn + (-2.0 * acc[j])) + yn[j];
+        d2[j] = v > 0.0 ? v : 0.0; /* max(0., d2), also squashes -0. and NaN */
+    }
+}
+
+__attribute__((target_clones("avx512f", "avx2,fma", "default")))
+static void tile_direct_form(const double *restrict q, const double *restrict Rt, int32_t d, double *restrict d2) {
+    for (int j = 0; j < CMO_RB; j++) d2[j] = 0.0;
+    for (int32_t c = 0; c < d; c++) {
+        const double qc = q[c];
+        const double *restrict y = Rt + (size_t)c * CMO_RB;
+        for (int j = 0; j < CMO_RB; j++) { double t = qc - y[j]; d2[j] = d2[j] + t * t; }
+    }
+}
+
 int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d, int32_t is_f64,
                       int32_t k, int32_t form, double *out_dist, int64_t *out_idx) {
     if (k < 1 || k > n_ref || d < 1 || nq < 0) return CMO_EINVAL;
-    /* float32 input is upcast to float64 first, as sklearn does per chunk (_middle_term_computer.pyx.tp) */
-    const double *R = (const double *)ref;
-    double *Rup = NULL;
-    if (!is_f64) {
-        Rup = (double *)malloc(sizeof(double) * (size_t)n_ref * (size_t)d);
-        if (!Rup) return CMO_ENOMEM;
+    const double t_setup0 = now_s();
+    /* float32 input is upcast to float64 first, as sklearn does per chunk (_middle_term_computer.pyx.tp); padded rows
+     * of the last tile are never pushed (j < n_ref below) */
+    const int64_t n_tiles = (n_ref + CMO_RB - 1) / CMO_RB;
+    double *Rt = (double *)malloc(sizeof(double) * (size_t)n_tiles * CMO_RB * (size_t)d);
+    double *yn = (double *)malloc(sizeof(double) * (size_t)n_tiles * CMO_RB);
+    if (!Rt || !yn) { free(Rt); free(yn); return CMO_ENOMEM; }
 #pragma omp parallel for schedule(static)
-        for (int64_t t = 0; t < n_ref * (int64_t)d; t++) Rup[t] = (double)((const float *)ref)[t];
-        R = Rup;
-    }
-    double *yn = NULL;
-    if (form == 0) {
-        yn = (double *)malloc(sizeof(double) * (size_t)n_ref);
-        if (!yn) { free(Rup); return CMO_ENOMEM; }
-#pragma omp parallel for schedule(static)
-        for (int64_t j = 0; j < n_ref; j++) {
+    for (int64_t t = 0; t < n_tiles; t++) {
+        double *T = Rt + (size_t)t * CMO_RB * d;
+        for (int j = 0; j < CMO_RB; j++) {
+            const int64_t r = t * CMO_RB + j;
             double s = 0.0;
-            for (int32_t c = 0; c < d; c++) { double v = R[j * d + c]; s = fma(v, v, s); }
-            yn[j] = s;
+            for (int32_t c = 0; c < d; c++) {
+                double v = r < n_ref ? ld(ref, is_f64, r * d + c) : 0.0;
+                T[(size_t)c * CMO_RB + j] = v;
+                s = fma(v, v, s);
+            }
+            yn[r] = s;
         }
     }
+    g_last_setup_s = now_s() - t_setup0;
     int err = 0;
+    const int64_t n_qblocks = (nq + CMO_QB - 1) / CMO_QB;
 #pragma omp parallel
     {
-        pair_t *h = (pair_t *)malloc(sizeof(pair_t) * (size_t)k);
-        double *q = (double *)malloc(sizeof(double) * (size_t)d);
+        pair_t *h = (pair_t *)malloc(sizeof(pair_t) * (size_t)k * CMO_QB);
+        double *q = (double *)malloc(sizeof(double) * (size_t)d * CMO_QB);
+        double xn[CMO_QB], d2[CMO_RB];
         if (!h || !q) {
 #pragma omp atomic write
             err = CMO_ENOMEM;
         } else {
-#pragma omp for schedule(dynamic, 4)
-            for (int64_t i = 0; i < nq; i++) {
-                double xn = 0.0;
-                for (int32_t c = 0; c < d; c++) { q[c] = ld(qry, is_f64, i * d + c); xn = fma(q[c], q[c], xn); }
-                for (int32_t t = 0; t < k; t++) { h[t].v = INFINITY; h[t].i = INT64_MAX; }
-                int64_t j = 0;
-                if (form == 0) {
-                    /* four reference rows at a time: four independent fma chains (per-pair arithmetic unchanged) */
-                    for (; j + 4 <= n_ref; j += 4) {
-                        const double *y0 = R + j * d, *y1 = y0 + d, *y2 = y1 + d, *y3 = y2 + d;
-                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                        for (int32_t c = 0; c < d; c++) {
-                            double qc = q[c];
-                            a0 = fma(qc, y0[c], a0); a1 = fma(qc, y1[c], a1);
-                            a2 = fma(qc, y2[c], a2); a3 = fma(qc, y3[c], a3);
-                        }
-                        double dots[4] = { a0, a1, a2, a3 };
-                        for (int u = 0; u < 4; u++) {
-                            double d2 = (xn + (-2.0 * dots[u])) + yn[j + u];
-                            if (!(d2 > 0.0)) d2 = 0.0; /* max(0., d2), also squashes -0. */
-                            if (d2 <= h[0].v) { pair_t x = { d2, j + u }; heap_push(h, k, x); }
-                        }
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t b = 0; b < n_qblocks; b++) {
+                const int64_t i0 = b * CMO_QB;
+                const int nb = (int)((nq - i0) < CMO_QB ? (nq - i0) : CMO_QB);
+                for (int u = 0; u < nb; u++) {
+                    double s = 0.0;
+                    for (int32_t c = 0; c < d; c++) { double v = ld(qry, is_f64, (i0 + u) * d + c); q[u * d + c] = v; s = fma(v, v, s); }
+                    xn[u] = s;
+                    for (int32_t t = 0; t < k; t++) { h[(size_t)u * k + t].v = INFINITY; h[(size_t)u * k + t].i = INT64_MAX; }
+                }
+                for (int64_t t = 0; t < n_tiles; t++) {
+                    const double *T = Rt + (size_t)t * CMO_RB * d;
+                    const int64_t j0 = t * CMO_RB;
+                    const int nr = (int)((n_ref - j0) < CMO_RB ? (n_ref - j0) : CMO_RB);
+                    for (int u = 0; u < nb; u++) {
+                        pair_t *hu = h + (size_t)u * k;
+                        if (form == 0) tile_gemm_form(q + u * d, T, yn + j0, d, xn[u], d2);
+                        else tile_direct_form(q + u * d, T, d, d2);
+                        for (int j = 0; j < nr; j++)   /* rows in ascending index order, as sklearn scans them */
+                            if (d2[j] <= hu[0].v) { pair_t x = { d2[j], j0 + j }; heap_push(hu, k, x); }
                     }
                 }
-                for (; j < n_ref; j++) {
-                    double d2;
-                    const double *y = R + j * d;
-                    if (form == 0) {
-                        double dot = 0.0;
-                        for (int32_t c = 0; c < d; c++) dot = fma(q[c], y[c], dot);
-                        d2 = (xn + (-2.0 * dot)) + yn[j];
-                        if (!(d2 > 0.0)) d2 = 0.0;
-                    } else {
-                        d2 = 0.0;
-                        for (int32_t c = 0; c < d; c++) { double t = q[c] - y[c]; d2 = d2 + t * t; }
-                    }
-                    pair_t x = { d2, j };
-                    heap_push(h, k, x);
+                for (int u = 0; u < nb; u++) {
+                    pair_t *hu = h + (size_t)u * k;
+                    qsort(hu, (size_t)k, sizeof(pair_t), pair_cmp);
+                    for (int32_t t = 0; t < k; t++) { out_dist[(i0 + u) * k + t] = sqrt(hu[t].v); out_idx[(i0 + u) * k + t] = hu[t].i; }
                 }
-                qsort(h, (size_t)k, sizeof(pair_t), pair_cmp);
-                for (int32_t t = 0; t < k; t++) { out_dist[i * k + t] = sqrt(h[t].v); out_idx[i * k + t] = h[t].i; }
             }
         }
         free(h);
         free(q);
     }
     free(yn);
-    free(Rup);
+    free(Rt);
     return err;
 }
 

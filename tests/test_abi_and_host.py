@@ -31,6 +31,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.cm_version() >= 100
 
 
+def test_every_export_declares_argtypes():
+    """ctypes marshals undeclared integer arguments as 32-bit C int: every bound symbol must carry argtypes whose length
+    matches the parameter count of its declaration in include/cellmap.h."""
+    from cellmapper_amd import _native
+
+    lib = _native.load_library()
+    src = open(os.path.join(ROOT, "include", "cellmap.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name in _native.EXPORTS:
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None, f"{name} has no ctypes argtypes"
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, src, flags=re.S)
+        assert m, f"{name} not declared in include/cellmap.h"
+        params = m.group(1).strip()
+        n_params = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(fn.argtypes) == n_params, f"{name}: {len(fn.argtypes)} argtypes for {n_params} declared parameters"
+    assert set(declared_symbols()) == set(_native.EXPORTS), "EXPORTS must list exactly what the header declares"
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU every compute entry point must fail loudly (RuntimeError + build hint)."""
     from cellmapper_amd import _native
