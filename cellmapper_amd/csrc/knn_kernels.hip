@@ -1473,7 +1473,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
     // sample-seeded thresholds of the plain full scan (see run_stage)
     char *seed_img = nullptr;
-    int *seed_map = nullptr, *seed_cand = nullptr;
+    int *seed_map = nullptr;
     float *seed_thr = nullptr;
     bool last_seeded = false;   // the last stage ran from seeded thresholds: a failure may hold fewer than k candidates
     // level 0 state: the grid over the reference rows is built on first use
@@ -1486,8 +1486,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     unsigned long long *d_ctr = nullptr;
     if (dbg & 4) {
         static unsigned long long *s_ctr = nullptr;
-        if (!s_ctr) (void)hipMalloc((void **)&s_ctr, 128);
-        (void)hipMemsetAsync(s_ctr, 0, 128, st);
+        if (!s_ctr) (void)hipMalloc((void **)&s_ctr, 256);
+        (void)hipMemsetAsync(s_ctr, 0, 256, st);
         d_ctr = s_ctr;
         g_dbg_ctr = s_ctr;
     }
@@ -1719,35 +1719,38 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                               !forced && !(flags & CM_KNN_FORCE_FALLBACK) &&   // (pinned levels do not escalate: a seed failure would have nowhere to go)
                               !getenv("CELLMAP_NO_SEED");
             if (seed) {
-                const int R = 64;
-                const int head = 64;   // real rows in the first tile of the sample image (see sample_map)
-                const int64_t n_s = (n_ref + R - 1) / R, n_simg = n_s + (cmk2::BR - head);
-                const int n_s_tiles = (int)((n_simg + cmk2::BR - 1) / cmk2::BR);
-                // K_s: the seed is the K_s-th smallest value of a 1/R sample; the number of sample rows among the query's k
-                // nearest is ~Poisson(k/R), and the seed is too tight (fewer than k rows below it) iff that number
-                // reaches K_s: K_s = smallest value with P(Poisson(k/R) >= K_s) < 1e-8 -- a retry stage is then a rarity
-                int Ks = 1;
-                {
+                // Seed = a value with at least m = 8 rows of a 1/R row sample at or below it (knn_cand_f16 in seeding mode:
+                // two lanes per query, each keeping its 4 smallest sub-tile minima in registers -- no lists, no merges).
+                // The number of sample rows among the query's k nearest is ~Binomial(k, 1/R) ~ Poisson(k/R); the seed is
+                // too tight (fewer than k rows below it) only if that number reaches m.  R = the smallest power of two
+                // from 16 on with P(Poisson(k/R) >= m) < 1e-7 (k = 30: R = 64, seed at rank ~ 8*64 of the full set): a
+                // retry stage is then a rarity, and the result never depends on it (certificate + escalation).
+                const int m = 8, L = 4;
+                int R = 16;
+                for (; R < 4096; R *= 2) {
                     const double x = (double)k / R;
-                    double p = exp(-x), cum = p;
-                    while (1.0 - cum > 1e-8 && Ks < 64) { p *= x / Ks; cum += p; ++Ks; }
+                    double pterm = exp(-x), cum = pterm;
+                    for (int j = 1; j < m; ++j) { pterm *= x / j; cum += pterm; }
+                    if (1.0 - cum < 1e-7) break;
                 }
+                const int64_t n_s = (n_ref + R - 1) / R;
+                const int n_s_tiles = (int)((n_s + cmk2::BR - 1) / cmk2::BR);
                 const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
                 if (!seed_img) {
                     seed_img = (char *)cm_ws_alloc(h, (size_t)n_s_tiles * tb1);
-                    seed_map = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_simg);
-                    seed_cand = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)p2.nq_pad * Ks);
+                    seed_map = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_s);
                     seed_thr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)p2.nq_pad);
-                    if (!seed_img || !seed_map || !seed_cand || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                    if (!seed_img || !seed_map || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
                 }
-                hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_simg + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, head, seed_map);
-                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_simg, d,
+                hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, cmk2::BR, seed_map);
+                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_s, d,
                                    p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
                                    (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr);
                 cmk2::P1Args sa = a;
-                sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1; sa.Kc = Ks;
-                sa.cand = seed_cand; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
-                sa.no_sched = 2;   // (its cost is appends and merges, not rows: one refresh after the short first tile)
+                sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1;
+                sa.cand = nullptr; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
+                sa.seed_len = L;
+                if (d_ctr) sa.ctr = d_ctr + 16;   // (diagnostics: the sample scan counts separately)
                 const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
                 CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, lds_s, sa));
                 a.thr0 = seed_thr;
@@ -1884,11 +1887,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         level = next;
     }
     if (g_dbg_ctr) {
-        unsigned long long hc[16] = {0};
+        unsigned long long hc2[32] = {0};
         (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(hc, g_dbg_ctr, 128, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[cellmap dbg] branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu event_cycles=%llu barrier_cycles=%llu dma_wait_cycles=%llu mfma_cluster_cycles=%llu\n",
-                hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9]);
+        (void)hipMemcpy(hc2, g_dbg_ctr, 256, hipMemcpyDeviceToHost);
+        for (int part = 0; part < 2; ++part) {
+            const unsigned long long *hc = hc2 + 16 * part;
+            if (part && !hc[5]) continue;
+            fprintf(stderr, "[cellmap dbg] %s branches=%llu appended=%llu prunes=%llu prune_cycles=%llu wave_cycles=%llu waves=%llu event_cycles=%llu barrier_cycles=%llu dma_wait_cycles=%llu mfma_cluster_cycles=%llu prologue_cycles=%llu loop_cycles=%llu final_cycles=%llu\n",
+                    part ? "sample-scan" : "filter", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], hc[9], hc[10], hc[11], hc[12]);
+        }
     }
     if (dbg & 3) return CM_OK;
 
@@ -2013,8 +2020,8 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
-        b += cm_align((size_t)(n_ref / 64 + 512) * 264) + cm_align(4 * (size_t)(n_ref / 64 + 256)) +
-             cm_align(4 * (size_t)nq_pad * 64) + cm_align(4 * (size_t)nq_pad) + 4096;   // threshold seeds
+        b += cm_align((size_t)(n_ref / 16 + 512) * 136) + cm_align(4 * (size_t)(n_ref / 16 + 256)) +
+             cm_align(4 * (size_t)nq_pad) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
         b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
         if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)

@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CM2_NW
 #define CM2_NW 8
 #endif
+#ifndef CM2_BT
+#define CM2_BT 2   // tiles per workgroup barrier in knn_cand_f16 (8-deep rings)
+#endif
 #ifndef CM2_EXP
 #define CM2_EXP 0  // timing experiments only (scripts/ablate_skeleton.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
 #endif
@@ -49,7 +52,10 @@ constexpr int QB = NW * 64;  // queries per workgroup pass
 constexpr int CL = 128;      // lane-private append buffer capacity (entries)
 // LDS tile buffers of knn_cand_f16 (tile t+1 has landed while tile t is computed, see the kernel): 4 full 32-KB tiles
 // at level 3, 8 hi-only 16-KB tiles at levels 1/2
-__host__ __device__ constexpr int ring_depth(bool hi_only, int KSTEPS = 4) { return (hi_only && KSTEPS < 8) ? 8 : 4; }
+#ifndef CM2_RING
+#define CM2_RING 8
+#endif
+__host__ __device__ constexpr int ring_depth(bool hi_only, int KSTEPS = 4) { return (hi_only && KSTEPS < 8) ? CM2_RING : 4; }
 
 __host__ __device__ constexpr int row_bytes(int KSTEPS) { return KSTEPS * 16 * 2 * 2; }  // hi + lo halves
 __host__ __device__ constexpr int tile_bytes(int KSTEPS) { return BR * row_bytes(KSTEPS); }
@@ -101,6 +107,7 @@ struct P1Args {
     // rows below the running threshold are ever appended, so "every non-candidate has a filter value >= the final
     // threshold" holds whatever it started from).  no_sched: no scheduled threshold refreshes, merges only when a log fills.
     const float *thr0 = nullptr;
+    int seed_len = 0;      // > 0: threshold-seeding mode of knn_cand_f16 (SEEDL = seed_len; only cthr[] is written)
     int no_sched = 0;      // 1: as described; 2: one scheduled refresh after the first tile, none afterwards (sample scan)
     int *wctr = nullptr;   // work-list mode: items beyond the first gridDim.x are handed out through this counter (zeroed
                            // by the caller): runs differ in length by orders of magnitude, a static assignment does not balance
@@ -338,6 +345,49 @@ __device__ __forceinline__ int wave_merge_prune(uint2 * /*unused*/, const uint2 
             if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                     \
         }                                                                                                      \
     }
+// Event path of knn_cand_f16 (round 2).  Typically ONE value in ONE lane passes.  The partial minima of the min tree
+// (MM[0..4]: registers 3g..3g+2 of P0, MM[5..9]: of P1; register 15 stands alone) are still live when the filter runs, so
+// the search descends through them: 6 compares find the group, 3 more the register -- no 16-mask SGPR array (which
+// spilled), and the append address is a uniform base + a 32-bit lane offset (saddr form: no 64-bit VALU arithmetic).
+#define CM2_APPEND_B(V, E, RB, LOFF)                                                                           \
+    if ((V) < tj_) {                                                                                           \
+        *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(wlbuf) + (size_t)((LOFF) + 8u * (unsigned)cj_)) =  \
+            make_uint2(__float_as_uint(V), (unsigned)((RB) + ((E) & 3) + 8 * ((E) >> 2)));                     \
+        ++cj_;                                                                                                 \
+    }
+#define CM2_GROUP_B(ACC, MMG, G, RB, LOFF)                                                                     \
+    if (__ballot((MMG) < tj_) != 0ull) {                                                                       \
+        CM2_APPEND_B((ACC)[3 * (G)], 3 * (G), RB, LOFF)                                                        \
+        CM2_APPEND_B((ACC)[3 * (G) + 1], 3 * (G) + 1, RB, LOFF)                                                \
+        CM2_APPEND_B((ACC)[3 * (G) + 2], 3 * (G) + 2, RB, LOFF)                                                \
+    }
+#define CM2_FILTER_B(P0, P1, MM, RB)                                                                           \
+    {                                                                                                          \
+        const bool pass0_ = (MM)[14] < thr[0], pass1_ = (MM)[15] < thr[1];                                     \
+        if (__ballot(pass0_ || pass1_) != 0ull) {                                                              \
+            unsigned long long te0_ = 0;                                                                       \
+            if (a.dbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                    \
+            if (__ballot(pass0_) != 0ull) {                                                                    \
+                const float tj_ = thr[0];                                                                      \
+                int cj_ = cnt[0];                                                                              \
+                CM2_GROUP_B(P0, (MM)[0], 0, RB, lboff0) CM2_GROUP_B(P0, (MM)[1], 1, RB, lboff0)                \
+                CM2_GROUP_B(P0, (MM)[2], 2, RB, lboff0) CM2_GROUP_B(P0, (MM)[3], 3, RB, lboff0)                \
+                CM2_GROUP_B(P0, (MM)[4], 4, RB, lboff0)                                                        \
+                if (__ballot((P0)[15] < tj_) != 0ull) CM2_APPEND_B((P0)[15], 15, RB, lboff0)                   \
+                cnt[0] = cj_;                                                                                  \
+            }                                                                                                  \
+            if (__ballot(pass1_) != 0ull) {                                                                    \
+                const float tj_ = thr[1];                                                                      \
+                int cj_ = cnt[1];                                                                              \
+                CM2_GROUP_B(P1, (MM)[5], 0, RB, lboff1) CM2_GROUP_B(P1, (MM)[6], 1, RB, lboff1)                \
+                CM2_GROUP_B(P1, (MM)[7], 2, RB, lboff1) CM2_GROUP_B(P1, (MM)[8], 3, RB, lboff1)                \
+                CM2_GROUP_B(P1, (MM)[9], 4, RB, lboff1)                                                        \
+                if (__ballot((P1)[15] < tj_) != 0ull) CM2_APPEND_B((P1)[15], 15, RB, lboff1)                   \
+                cnt[1] = cj_;                                                                                  \
+            }                                                                                                  \
+            if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                     \
+        }                                                                                                      \
+    }
 // Merge the logs of every query whose lanes hold more than LIM_ entries (runtime loop over the accumulators: one copy
 // of the merge code).
 #define CM2_MERGE_PASS(LIM_)                                                                                   \
@@ -451,7 +501,13 @@ __device__ __forceinline__ void min_step(int I, const f32x16 &P0, const f32x16 &
 // computed in float64 beforehand (knn_kernels.hip: cen_side) and copied per tile next to the rows like the |y|^2 side
 // block of K = 128: it initialises the accumulators.  Every error term of the filter then scales with the radius of the
 // bucket instead of the distance of the query from the global mean.
-template <int KSTEPS, int NP, bool CEN = false>
+// SEEDL > 0: threshold-seeding mode (hi*hi level over a 1/R row sample; no candidate lists at all).  Every lane keeps the
+// SEEDL smallest SUB-TILE MINIMA of each of its two queries in registers (sorted insertion of the min tree's result: 2
+// VALU per list entry and sub-tile, no branch, no log, no merge).  A sub-tile minimum is the value of one row and
+// different sub-tiles hold different rows, so at least SEEDL rows of the lane's half of the sample lie at or below its
+// SEEDL-th entry; the two lanes of a query own disjoint halves, hence at least 2*SEEDL sample rows lie at or below the
+// larger of their SEEDL-th entries -- that value is written to cthr[] as the query's seed (see knn_run_staged).
+template <int KSTEPS, int NP, bool CEN = false, int SEEDL = 0>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr bool LO3 = NP == 3;
     constexpr int K = KSTEPS * 16;
@@ -464,7 +520,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     constexpr int TILEB = GTILEB + (CEN ? 1024 : 0);          // stride of the LDS ring (CEN: + the side block)
     constexpr int ROWS_B = BR * ROWB;      // bytes of the rows of a tile; SIDE: followed by BR floats sc^2|y|^2
     constexpr int RING = ring_depth(!LO3, KSTEPS);
-    constexpr int AHEAD = RING - 1;   // the DMA pieces of tile t + AHEAD are issued during tile t
+    // Workgroup barrier every BT tiles (8-deep ring: BT = CM2_BT, default 2): between barriers the waves drift freely, so
+    // the time a wave loses to append events / merges is averaged over BT tiles before the slowest wave is waited for.
+    // The barrier at tile t (t - t0 a multiple of BT) makes tiles t+1 .. t+BT complete for everyone and tells that
+    // everyone is done with tiles < t; the buffer of tile t - BT is therefore free during tile t.
+    constexpr int BT = RING >= 8 ? CM2_BT : 1;
+    constexpr int AHEAD = RING - BT;   // the DMA pieces of tile t + AHEAD are issued during tile t
+    static_assert(AHEAD - 1 - BT >= 0, "ring too shallow for this barrier interval");
     constexpr int NCHUNK = ROWS_B / 1024;  // 1-KiB pieces of the rows = one LDS-DMA wave-instruction each (+1 side piece)
     constexpr int NST = BR / 32;           // 32-row sub-tiles per tile
     constexpr int NJ_ = 2;                 // 32-query accumulators per wave
@@ -512,6 +574,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 #define CM2_PT(t_) (a.perm_mul > 1u ? (int)(((unsigned long long)(unsigned)(t_) * a.perm_mul) % (unsigned)a.n_tiles) : (int)(t_))
 
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0, c_clus = 0;
+    unsigned long long c_procyc = 0, c_loopcyc = 0, c_fincyc = 0;
     const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
     const int n_work = a.wlist ? (a.n_wlist_dev ? *a.n_wlist_dev : a.n_wlist) : a.nqb * a.S;
     auto next_work = [&](int w) -> int {
@@ -534,6 +597,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
         }
         const int64_t qbase = (int64_t)qb * QB + wave * 64;
+        const unsigned long long tw0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
         // CEN: side values of this work item's bucket, one float per row of the (padded) reference image
         const float *side_row = CEN ? a.side + (size_t)a.blk_bucket[qb] * (size_t)a.side_stride : nullptr;
         (void)side_row;
@@ -568,6 +632,12 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         }
         int cnt[2] = {0, 0};     // entries in this lane's append buffer for query j*32+c
         int keptn[2] = {0, 0};   // entries in the query's kept list (same value in both hh lanes)
+        float sl0[SEEDL > 0 ? SEEDL : 1], sl1[SEEDL > 0 ? SEEDL : 1];   // SEEDL: smallest sub-tile minima, ascending
+#pragma unroll
+        for (int i = 0; i < (SEEDL > 0 ? SEEDL : 1); ++i) { sl0[i] = INFINITY; sl1[i] = INFINITY; }
+        (void)sl0; (void)sl1;
+        // byte offsets of this lane's two append logs from the wave's (uniform) log base
+        const unsigned lboff0 = (unsigned)((c * 2 + hh) * CL * 8), lboff1 = (unsigned)(((32 + c) * 2 + hh) * CL * 8);
 
         // Ring protocol (tile t lives in buffer t % RING).  At the top of tile t every wave waits for its own DMA pieces
         // of tile t+1, then the workgroup barrier makes tile t+1 complete for everyone and tells that everyone is done
@@ -624,14 +694,16 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         }
         int ptile = CM2_PT(t0), ptile_a = CM2_PT(t0 + AHEAD);
         const int pstep = a.perm_mul > 1u ? (int)(a.perm_mul % (unsigned)a.n_tiles) : 1;
+        const unsigned long long tw1_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (t > t0) {   // (the first tile synchronised above)
-                // own pieces of tile t+1 have landed; NP < 3: those of younger tiles may be in
-                // flight -- loads complete in order, stores in between only make the wait more conservative
+            if (t > t0 && (BT == 1 || (t - t0) % BT == 0)) {   // (the first tile synchronised above)
+                // own pieces of tiles t+1 .. t+BT have landed (in flight before this point: tiles t+1 .. t+AHEAD-1; those
+                // of the AHEAD-1-BT youngest may stay in flight -- loads complete in order, stores in between only make
+                // the wait more conservative)
                 if (t + AHEAD - 1 >= t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (conservative in the tail of a work item)
-                else if (SIDE && wave0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * (NPIECE + 1)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 2) * NPIECE) : "memory");
+                else if (SIDE && wave0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * (NPIECE + 1)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * NPIECE) : "memory");
                 if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
                 if (!(CM2_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
@@ -715,12 +787,23 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                float mp0 = mm[14], mp1 = mm[15];
-                if (!(a.dbg & 2)) CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
+                if constexpr (SEEDL > 0) {
+                    float v0_ = mm[14], v1_ = mm[15];
+#pragma unroll
+                    for (int i = 0; i < SEEDL; ++i) {   // sorted insertion (ascending lists)
+                        const float l0_ = fminf(sl0[i], v0_), l1_ = fminf(sl1[i], v1_);
+                        v0_ = fmaxf(sl0[i], v0_); v1_ = fmaxf(sl1[i], v1_);
+                        sl0[i] = l0_; sl1[i] = l1_;
+                    }
+                } else if (CM2_EXP & 8) {
+                    float mp0 = mm[14], mp1 = mm[15];
+                    if (!(a.dbg & 2)) CM2_FILTER_A(p0, p1, mp0, mp1, prbase);
+                } else if (!(a.dbg & 2)) CM2_FILTER_B(p0, p1, mm, prbase);
                 p0 = acc0;
                 p1 = acc1;
                 prbase = ptile * BR + st * 32 + 4 * hh;
             }
+            if constexpr (SEEDL == 0) {
             if (a.no_sched) {
                 // Seeded scan: no refresh schedule, and merges that each wave starts on its own leave the other waves
                 // waiting at the next tile barrier.  So a wave with a log more than 48 entries long announces it (tile index in an
@@ -737,10 +820,27 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
             }
             CM2_REFRESH_T(t, t0, CL - 16 * NST);
             if (a.no_sched) next_refresh = 0x7fffffff;
+            }
             ptile += pstep; if (ptile >= a.n_tiles) ptile -= a.n_tiles;
             ptile_a += pstep; if (ptile_a >= a.n_tiles) ptile_a -= a.n_tiles;
         }
-        if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
+        if constexpr (SEEDL > 0) {   // last sub-tile, then the seed of both queries of the lane
+            float v0_, v1_;
+            CM2_MIN16(p0, v0_);
+            CM2_MIN16(p1, v1_);
+#pragma unroll
+            for (int i = 0; i < SEEDL; ++i) {
+                const float l0_ = fminf(sl0[i], v0_), l1_ = fminf(sl1[i], v1_);
+                v0_ = fmaxf(sl0[i], v0_); v1_ = fmaxf(sl1[i], v1_);
+                sl0[i] = l0_; sl1[i] = l1_;
+            }
+            const float s0_ = fmaxf(sl0[SEEDL - 1], __shfl_xor(sl0[SEEDL - 1], 32));
+            const float s1_ = fmaxf(sl1[SEEDL - 1], __shfl_xor(sl1[SEEDL - 1], 32));
+            if (hh == 0) {
+                a.cthr[(qbase + c) * a.S + split] = s0_;
+                a.cthr[(qbase + 32 + c) * a.S + split] = s1_;
+            }
+        } else if (!(a.dbg & 2)) {  // drain the pipeline: filter the last sub-tile
             float mp0, mp1;
             CM2_MIN16(p0, mp0);
             CM2_MIN16(p1, mp1);
@@ -750,7 +850,12 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 #undef CM2_LOAD_AH
 #undef CM2_LOAD_SIDE
 
-        CM2_FINAL();
+        const unsigned long long tw2_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if constexpr (SEEDL == 0) CM2_FINAL();
+        if (a.dbg & 4) {
+            const unsigned long long tw3_ = __builtin_amdgcn_s_memtime();
+            c_procyc += tw1_ - tw0_; c_loopcyc += tw2_ - tw1_; c_fincyc += tw3_ - tw2_;
+        }
     }
 #undef CM2_DMA_TILE
 #undef CM2_DMA_PIECE
@@ -767,6 +872,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         atomicAdd(&a.ctr[7], c_barcyc);
         atomicAdd(&a.ctr[8], c_dmacyc);
         atomicAdd(&a.ctr[9], c_clus);
+        atomicAdd(&a.ctr[10], c_procyc);
+        atomicAdd(&a.ctr[11], c_loopcyc);
+        atomicAdd(&a.ctr[12], c_fincyc);
     }
 }
 

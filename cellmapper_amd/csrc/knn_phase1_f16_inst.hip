@@ -2,9 +2,9 @@
 #include "cm_internal.h"
 #include "knn_phase1_f16.h"
 
-template <int KSTEPS, int NP, bool CEN = false>
+template <int KSTEPS, int NP, bool CEN = false, int SEEDL = 0>
 static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    auto kern = cmk2::knn_cand_f16<KSTEPS, NP, CEN>;
+    auto kern = cmk2::knn_cand_f16<KSTEPS, NP, CEN, SEEDL>;
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
     CM_HIP(h, hipGetLastError());
@@ -16,6 +16,12 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
         if (a.nprod == 1 && KSTEPS == 2) return launch_f16<2, 1, true>(h, grid, lds, a);
         if (a.nprod == 1 && KSTEPS == 4) return launch_f16<4, 1, true>(h, grid, lds, a);
         CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: centred mode exists for the hi*hi level at K <= 64 only");
+    }
+    if (a.seed_len > 0) {   // threshold-seeding scan (register-resident lists of sub-tile minima)
+        if (a.seed_len == 4 && a.nprod == 1 && KSTEPS == 2) return launch_f16<2, 1, false, 4>(h, grid, lds, a);
+        if (a.seed_len == 4 && a.nprod == 1 && KSTEPS == 4) return launch_f16<4, 1, false, 4>(h, grid, lds, a);
+        if (a.seed_len == 4 && a.nprod == 1 && KSTEPS == 8) return launch_f16<8, 1, false, 4>(h, grid, lds, a);
+        CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: the seeding mode exists for the hi*hi level with 4-entry lists");
     }
     switch (KSTEPS) {
 #define CM_F16_CASE(ks_)                                                                \

@@ -1,11 +1,25 @@
 #!/bin/bash
-# Rehearsal of the N > 1 bench path on a ONE-GPU box: N ranks share cuda:0, torch.distributed over gloo (all-gather
-# exchange; gloo has no device all-to-all), every rank checks its slice of the sharded result against the single-GPU map
-# of all queries onto the full reference (identical labels, confidences to 1e-5).  Exercises HipOps, the 2-D layout,
-# the exact merge, the all-reduced bandwidth and bench.py's own N > 1 logic; only the RCCL calls themselves are not run.
+# Rehearsal of the N > 1 bench path on a ONE-GPU box, log kept under gpurun_out/ (copy to profiles/ to commit):
+#  (a) RCCL smoke: one rank under torch.distributed.run with --force-dist -- init_process_group("nccl"), the packed
+#      all_to_all_single / all_gather_into_tensor on the library's stream, barrier, all_reduce -- then the rank compares its
+#      sharded result with the single-GPU pipeline;
+#  (b) N = 2 and N = 4 ranks SHARING cuda:0 over gloo (RCCL refuses two ranks on one device; gloo has no device
+#      all-to-all, so the all-gather exchange), started by bench.py's OWN launcher (`python bench.py --gpus N`): every rank
+#      checks its slice against the single-GPU map of all queries onto the full reference (identical labels,
+#      confidences to 1e-5).  Exercises HipOps, the 2-D layout, the packed exchange buffer, the strided exact merge and the
+#      all-reduced bandwidth.
 set -o pipefail
-for n in 2 4; do
-  timeout -k 10 250 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2953$n \
-    bench.py --gpus $n --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather --nq 300000 --nref 400000 \
-    --cpu-sample 0 --check 0 2>&1 | grep -E "rehearsal|Error" | cut -c1-200 || exit 1
+LOG=${1:-gpurun_out/r02_rehearsal.log}
+: > $LOG
+for ex in alltoall allgather; do
+  timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+    bench.py --gpus 1 --steps 1 --warmup 1 --force-dist --exchange $ex --nq 300000 --nref 400000 --cpu-sample 0 --check 0 \
+    >> $LOG 2>&1 || { echo "RCCL smoke ($ex) FAILED" >> $LOG; exit 1; }
 done
+for n in 2 4; do
+  timeout -k 10 250 python bench.py --gpus $n --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather \
+    --nq 300000 --nref 400000 --cpu-sample 0 --check 0 --master-port 2953$n >> $LOG 2>&1 || { echo "rehearsal N=$n FAILED" >> $LOG; exit 1; }
+done
+timeout -k 10 250 python bench.py --gpus 2 --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather --metric cosine \
+    --nq 200000 --nref 300000 --cpu-sample 0 --check 0 --master-port 29537 >> $LOG 2>&1 || { echo "rehearsal cosine FAILED" >> $LOG; exit 1; }
+grep -E "rehearsal|n_gpus" $LOG | cut -c1-220
