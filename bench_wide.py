@@ -1,0 +1,248 @@
+"""bench.py --config 3 / 5: the aggregation-heavy single-GPU workloads.
+
+config 3: 1.5 M x 1.5 M, d=50, k=30 search, then obsm transfer (d_out = 2) and the dense layer transfer over reference.X
+          with 20 000 genes (A1 + A2).  X (120 GB float32) is resident in HBM; the product (another 120 GB) is produced in
+          query tiles -- resident as a whole when it fits next to X, otherwise through a two-tile ring that a consumer
+          (D2H copy, on-device evaluation) would drain.
+config 5: self-mapping of 4 M spatial cells (d=2, k=90; uniform-grid search) and expression imputation from a sparse
+          reference.X (30 000 genes, 3 % density, CSR): `M @ X` as CSR (scipy csr_matmat semantics), produced in query tiles
+          of fixed capacity -- the whole product (~0.9 TB) is never resident.
+
+The roofline object describes the dominant kernel of each workload, an HBM-bound gather: ALGORITHMIC bytes per query row
+(A2 `k*8 + k*G*4 + G*4`; A3 `k*8 + sum(neighbour nnz)*8 + out_nnz*8`) x rows / kernel time (HIP events on the
+library's stream), against 8 TB/s.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PEAK_HBM_GBS = 8000.0
+
+
+def _randn_rows(torch, g, n, d, dev, chunk=250_000):
+    out = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        out[c0:c1] = torch.randn((c1 - c0, d), generator=g, dtype=torch.float32, device=dev)
+    return out
+
+
+def _graph(pipe, ref, qry, k, kernel):
+    """k-NN -> kernel weights -> row-normalised mapping matrix as device CSR (regular rows: indptr = arange * k)."""
+    dist, idx = pipe.knn(ref, qry, k)
+    m = pipe.moments(dist, idx)
+    param = pipe.kernel_param(m, kernel) if kernel in ("gaussian", "scarches") else None
+    cols, vals, cnt = pipe.weights(dist, idx, ref.shape[0], kernel, param)
+    indptr, oc, ov = pipe.to_csr(cols, vals, cnt)
+    return dist, idx, indptr, oc, ov
+
+
+def run(a, pipe, torch):
+    return run_config3(a, pipe, torch) if a.config == 3 else run_config5(a, pipe, torch)
+
+
+# --------------------------------------------------------------------------------------------- config 3 ----------
+def run_config3(a, pipe, torch):
+    dev = pipe.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    G = a.genes
+    ref = _randn_rows(torch, g, a.nref, a.d, dev)
+    qry = _randn_rows(torch, g, a.nq, a.d, dev)
+    umap = torch.randn((a.nref, 2), generator=g, dtype=torch.float32, device=dev)
+    X = torch.empty((a.nref, G), dtype=torch.float32, device=dev)       # reference.X, dense float32
+    rows = max(1, (1 << 31) // max(G * 4, 1))
+    for r0 in range(0, a.nref, rows):
+        r1 = min(a.nref, r0 + rows)
+        X[r0:r1] = torch.rand((r1 - r0, G), generator=g, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    out_bytes = a.nq * G * 4
+    resident = out_bytes + (6 << 30) < free_b     # the whole product stays in HBM (plus the search's workspace)
+    tile = a.tile or (a.nq if resident else max(1024, min(a.nq, (free_b // 4) // (G * 4 * 2))))
+    out = torch.empty((a.nq if resident else 2 * tile, G), dtype=torch.float32, device=dev)
+    torch.cuda.set_stream(pipe.stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    spmm_ms = []
+
+    def step():
+        _, _, indptr, oc, ov = _graph(pipe, ref, qry, a.k, a.kernel)
+        obsm = pipe.spmm_dense(indptr, oc, ov, umap)                      # A1
+        e0.record(pipe.stream)
+        for i, q0 in enumerate(range(0, a.nq, tile)):                     # A2, query tiles
+            q1 = min(a.nq, q0 + tile)
+            dst = out[q0:q1] if resident else out[(i & 1) * tile:(i & 1) * tile + (q1 - q0)]
+            pipe.spmm_dense(indptr[q0:q1 + 1], oc, ov, X, out=dst)
+        e1.record(pipe.stream)
+        return indptr, oc, ov, obsm
+
+    for _ in range(a.warmup):
+        res = step()
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+        pipe.synchronize()
+        spmm_ms.append(e0.elapsed_time(e1))
+    elapsed = time.perf_counter() - t0
+    stages = pipe.h.stage_times()
+    ms = float(np.mean(spmm_ms))
+    bytes_per_q = a.k * 8 + a.k * G * 4 + G * 4
+    achieved = bytes_per_q * a.nq / (ms * 1e-3) / 1e9
+    result = {
+        "metric": "query cells/s end-to-end (k-NN+kernel+transfer)", "value": a.nq * a.steps / elapsed, "unit": "query cells/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "timed_region": "device-resident",
+        "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.kernel} kernel, obsm (d_out=2) + dense "
+                               f"layer X ({G} genes, float32) transfer (BASELINE configs[2]); output "
+                               f"{'resident in HBM' if resident else f'in a ring of two {tile}-row tiles'}",
+                   "baseline_config": 3, "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "genes": G, "query_tile": tile,
+                   "output_resident": bool(resident)},
+        "roofline": {"bound": "hbm", "kernel": "spmm_wide<float,4> (k-sparse x dense gather-accumulate, A2)", "achieved": achieved,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel_ms": ms,
+                     "bytes_per_query": bytes_per_q, "kernel_ms_covers": "all query tiles of the dense layer product in one step"},
+        "stage_ms_last_step": dict(stages, layer_spmm=ms),
+    }
+    # parity on a bounded sample: the HIP product rows against the CPU oracle's csr_matvecs restatement
+    if a.check > 0:
+        from oracle import oracle as orc
+
+        orc.build()
+        indptr, oc, ov, obsm = res
+        ns = min(128, a.nq)
+        sel = torch.arange(0, a.nq, max(1, a.nq // ns), device=dev)[:ns]
+        ipt = indptr.cpu().numpy()
+        sel_np = sel.cpu().numpy()
+        rows_c = np.concatenate([np.arange(ipt[i], ipt[i + 1]) for i in sel_np])
+        c_np = oc[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
+        v_np = ov[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
+        uniq, inv = np.unique(c_np, return_inverse=True)
+        Xs = X[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()      # only the gathered reference rows travel
+        lens = np.array([ipt[i + 1] - ipt[i] for i in sel_np])
+        ip2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        # (the oracle accumulates in stored order; remapped columns keep the order of the original ascending columns)
+        want = orc.spmm_dense(ip2, inv.astype(np.int32), v_np, Xs)
+        if resident:
+            got = out[sel.long()].cpu().numpy()
+        else:
+            got = torch.stack([pipe.spmm_dense(indptr[i:i + 2], oc, ov, X)[0] for i in sel_np.tolist()]).cpu().numpy()
+        ok = bool(np.array_equal(got, want))
+        um = umap[torch.from_numpy(uniq).to(dev).long()].cpu().numpy()
+        ok2 = bool(np.array_equal(obsm[sel.long()].cpu().numpy(), orc.spmm_dense(ip2, inv.astype(np.int32), v_np, um)))
+        result["parity_check"] = {"rows": int(ns), "layer_rows_bit_exact": ok, "obsm_rows_bit_exact": ok2, "ok": ok and ok2}
+    return result
+
+
+# --------------------------------------------------------------------------------------------- config 5 ----------
+def sparse_payload(torch, g, n, G, density, dev, chunk=500_000):
+    """CSR float32 [n, G] with round(density * G) entries per row: one column per stratum of width G // per_row (ascending,
+    distinct), values exp(N(0,1)) -- SURVEY.md 8d's sparse X."""
+    per = max(1, int(round(density * G)))
+    width = G // per
+    cols = torch.empty((n, per), dtype=torch.int32, device=dev)
+    vals = torch.empty((n, per), dtype=torch.float32, device=dev)
+    base = (torch.arange(per, device=dev, dtype=torch.int32) * width)[None, :]
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        cols[r0:r1] = base + torch.randint(0, width, (r1 - r0, per), generator=g, device=dev, dtype=torch.int32)
+        vals[r0:r1] = torch.exp(torch.randn((r1 - r0, per), generator=g, device=dev, dtype=torch.float32))
+    indptr = torch.arange(n + 1, device=dev, dtype=torch.int64) * per
+    return indptr, cols.view(-1), vals.view(-1), per
+
+
+def run_config5(a, pipe, torch):
+    dev = pipe.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    G = a.genes
+    n = a.nq                                  # self-mapping: query = reference
+    xy = torch.rand((n, a.d), generator=g, dtype=torch.float32, device=dev) * 2000.0
+    b_indptr, b_cols, b_vals, per = sparse_payload(torch, g, n, G, a.density, dev)
+    torch.cuda.synchronize()
+    # output tile: worst case min(G, k * per) entries per row; two tiles alternate (the consumer drains one while the next
+    # is produced)
+    row_cap = min(G, a.k * per)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    tile = a.tile or max(256, min(n, 16384, (free_b // 4) // (row_cap * 8 * 2)))
+    t_cols = [torch.empty(tile * row_cap, dtype=torch.int32, device=dev) for _ in range(2)]
+    t_vals = [torch.empty(tile * row_cap, dtype=torch.float32, device=dev) for _ in range(2)]
+    t_ptr = [torch.empty(tile + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    out_nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.set_stream(pipe.stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a3_ms = []
+
+    def step():
+        _, _, indptr, oc, ov = _graph(pipe, xy, xy, a.k, a.kernel)
+        out_nnz.zero_()
+        e0.record(pipe.stream)
+        for i, q0 in enumerate(range(0, n, tile)):
+            q1 = min(n, q0 + tile)
+            b = i & 1
+            pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, q0, q1, out=(t_ptr[b], t_cols[b], t_vals[b]))
+            out_nnz.add_(t_ptr[b][q1 - q0])
+        e1.record(pipe.stream)
+        return indptr, oc, ov
+
+    for _ in range(a.warmup):
+        res = step()
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+        pipe.synchronize()
+        a3_ms.append(e0.elapsed_time(e1))
+    elapsed = time.perf_counter() - t0
+    stages = pipe.h.stage_times()
+    ms = float(np.mean(a3_ms))
+    nnz_out = int(out_nnz.item())
+    alg_bytes = n * a.k * 8 + n * a.k * per * 8 + nnz_out * 8
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    result = {
+        "metric": "query cells/s end-to-end (k-NN+kernel+transfer)", "value": n * a.steps / elapsed, "unit": "query cells/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "timed_region": "device-resident",
+        "config": {"workload": f"self-mapping of {n} spatial cells, d={a.d}, k={a.k}, {a.kernel} kernel, expression imputation from a "
+                               f"sparse reference.X ({G} genes, {per} non-zeros per cell, CSR) (BASELINE configs[4]); CSR product "
+                               f"produced in {tile}-row tiles, {nnz_out} non-zeros in total",
+                   "baseline_config": 5, "nq": n, "n_ref": n, "d": a.d, "k": a.k, "genes": G, "nnz_per_cell": per,
+                   "query_tile": tile, "output_nnz": nnz_out},
+        "roofline": {"bound": "hbm", "kernel": "spgemm_rows<0> + spgemm_rows<1> (count + fill passes of the CSR x CSR product, A3)",
+                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+                     "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
+                     "kernel_ms_covers": "both passes over all query tiles in one step (the gather is done twice: count, fill)"},
+        "stage_ms_last_step": dict(stages, layer_spgemm=ms),
+    }
+    if a.check > 0:
+        from oracle import oracle as orc
+        import scipy.sparse as sp
+
+        orc.build()
+        indptr, oc, ov = res
+        ns = min(64, n)
+        sel_np = np.arange(0, n, max(1, n // ns))[:ns]
+        ipt = indptr.cpu().numpy()
+        rows_c = np.concatenate([np.arange(ipt[i], ipt[i + 1]) for i in sel_np])
+        c_np = oc[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
+        v_np = ov[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
+        uniq, inv = np.unique(c_np, return_inverse=True)
+        sel_rows = torch.from_numpy(uniq).to(dev).long()
+        bc = b_cols.view(n, per)[sel_rows].cpu().numpy().ravel()
+        bv = b_vals.view(n, per)[sel_rows].cpu().numpy().ravel()
+        Bs = sp.csr_matrix((bv, bc, np.arange(len(uniq) + 1, dtype=np.int64) * per), shape=(len(uniq), G))
+        lens = np.array([ipt[i + 1] - ipt[i] for i in sel_np])
+        ip2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        dense = orc.spmm_csr(ip2, inv.astype(np.int32), v_np, Bs)   # [ns, G] float32; csr_matmat drops exact zeros
+        ok = True
+        for r, i in enumerate(sel_np.tolist()):
+            optr, gc, gv = pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, i, i + 1)
+            gc, gv = gc.cpu().numpy(), gv.cpu().numpy()
+            wc = np.flatnonzero(dense[r])
+            ok = ok and np.array_equal(gc, wc) and np.array_equal(gv, dense[r][wc])
+        result["parity_check"] = {"rows": int(ns), "csr_rows_bit_exact": bool(ok), "ok": bool(ok)}
+    return result

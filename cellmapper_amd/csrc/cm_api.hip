@@ -11,6 +11,7 @@
 namespace {
 std::mutex g_err_mu;
 std::string g_create_err;
+void a3_session_drop(cm_handle_t h);
 
 struct DevBuf {  // RAII device allocation used by the host tier
     void *p = nullptr;
@@ -48,6 +49,32 @@ cm_status check_fallback_overflow(cm_handle_t h) {
     h->knn_stats[0] = h->d_nflag_pinned[0];
     if (h->d_nflag_pinned[1]) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN exact fallback overflow: more than 2048 reference rows tie within a query's k-th distance");
     return CM_OK;
+}
+
+// Host tier of A3: what cm_spmm_csr_nnz uploaded (mapping matrix, payload) and computed (output indptr) stays on the
+// device until the matching cm_spmm_csr call, so the count + fill pair uploads everything once.
+struct A3Session {
+    const void *key[6] = {};
+    int64_t nq = 0, n_ref = 0, n_out = 0;
+    DevBuf dp, dc, dv, bp, bc, bv, op;
+};
+void a3_session_drop(cm_handle_t h) {
+    if (h->a3_session) { delete static_cast<A3Session *>(h->a3_session); h->a3_session = nullptr; }
+}
+// second stream + two events for the tiled host-tier transfers (created on first use)
+cm_status tile_streams(cm_handle_t h) {
+    if (!h->copy_stream) CM_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i)
+        if (!h->tile_ev[i]) CM_HIP(h, hipEventCreateWithFlags(&h->tile_ev[i], hipEventDisableTiming));
+    return CM_OK;
+}
+size_t device_budget(cm_handle_t h, const char *env_mb) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    size_t budget = free_b / 2;
+    if (const char *e = getenv(env_mb)) budget = (size_t)atoll(e) << 20;   // testing: force tiling
+    (void)h;
+    return budget;
 }
 
 // param for the graph kernel from the distances (device), honouring the reference's global statistics
@@ -131,6 +158,9 @@ cm_status cm_destroy(cm_handle_t h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
+    a3_session_drop(h);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    for (int i = 0; i < 2; ++i) if (h->tile_ev[i]) (void)hipEventDestroy(h->tile_ev[i]);
     if (h->d_nflag_pinned) (void)hipHostFree(h->d_nflag_pinned);
     for (int i = 0; i < CM_N_STAGE_EVENTS; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -244,6 +274,25 @@ cm_status cm_spmm_dense_dev(cm_handle_t h, const int64_t *d_indptr, const int32_
                             int64_t nq, const void *d_B, int64_t /*n_ref*/, int64_t n_out, int32_t b_dtype, void *d_out) {
     CM_TRY(begin_call(h, 0));
     return cm_spmm_dense_run(h, d_indptr, d_cols, d_vals, nq, d_B, n_out, b_dtype, d_out);
+}
+
+cm_status cm_spmm_csr_nnz_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                              const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
+                              int64_t n_out, int64_t *d_out_indptr) {
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + cm_align(4 * (size_t)std::max<int64_t>(nq, 1)) + 4096));
+    if (nq < 0 || !d_out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    int32_t *rn = (int32_t *)cm_ws_alloc(h, 4 * (size_t)std::max<int64_t>(nq, 1));
+    if (!rn) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: device workspace exhausted");
+    CM_TRY(cm_spmm_csr_count_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, rn));
+    return cm_exclusive_scan_i32_to_i64(h, rn, nq, d_out_indptr);
+}
+
+cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                          const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
+                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
+    CM_TRY(begin_call(h, 0));
+    return cm_spmm_csr_fill_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, d_out_indptr, 0, d_out_cols,
+                                d_out_vals);
 }
 
 cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
@@ -421,72 +470,132 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
     if (b_dtype != CM_F32 && b_dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm: payload has no columns");
     CM_TRY(begin_call(h, 0));
+    CM_TRY(tile_streams(h));
     const size_t es = b_dtype == CM_F64 ? 8 : 4;
-    DevBuf dp, dc, dv, dB, dO;
-    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));
-    // column slabs keep payload + output within a fixed HBM budget (wide .X payloads exceed it)
-    size_t free_b = 0, total_b = 0;
-    CM_HIP(h, hipMemGetInfo(&free_b, &total_b));
-    size_t budget = free_b / 2;
-    if (const char *e = getenv("CELLMAP_SPMM_BUDGET_MB")) budget = (size_t)atoll(e) << 20;  // testing: force column slabs
+    DevBuf dp, dc, dv, dB, dO[2];
+    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));   // the mapping matrix goes up once
+    // Streaming ("wide aggregation outputs"): the payload is cut into column slabs that fit HBM next
+    // to two output tiles, the output into query tiles; tile i is copied to the caller's buffer on a second stream while
+    // tile i+1 is computed.  Nothing of size nq x n_out is ever resident.
+    const size_t budget = device_budget(h, "CELLMAP_SPMM_BUDGET_MB");
     int64_t cw = n_out;
-    size_t per_col = es * ((size_t)n_ref + (size_t)nq);
-    if (per_col * (size_t)n_out > budget) {
-        cw = (int64_t)(budget / per_col);
+    int64_t qt = std::max<int64_t>(1, std::min<int64_t>(nq, 1 << 16));           // query rows per output tile
+    auto need = [&](int64_t w, int64_t t) { return es * ((size_t)n_ref * w + 2 * (size_t)t * w); };
+    while (need(cw, qt) > budget && qt > 1024) qt /= 2;
+    if (need(cw, qt) > budget) {
+        cw = (int64_t)(budget / (es * ((size_t)n_ref + 2 * (size_t)qt)));
         cw = cw / 64 * 64;
         if (cw < 64) CM_FAIL(h, CM_E_NOMEM, "spmm: not enough device memory for a 64-column slab");
     }
     CM_TRY(dB.alloc(h, es * (size_t)n_ref * cw));
-    CM_TRY(dO.alloc(h, es * (size_t)nq * cw));
+    CM_TRY(dO[0].alloc(h, es * (size_t)qt * cw));
+    CM_TRY(dO[1].alloc(h, es * (size_t)qt * cw));
     for (int64_t c0 = 0; c0 < n_out; c0 += cw) {
-        int64_t w = std::min<int64_t>(cw, n_out - c0);
+        const int64_t w = std::min<int64_t>(cw, n_out - c0);
         CM_HIP(h, hipMemcpy2DAsync(dB.p, es * w, (const char *)B + es * c0, es * n_out, es * w, (size_t)n_ref, hipMemcpyHostToDevice, h->stream));
-        CM_TRY(cm_spmm_dense_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, dB.p, w, b_dtype, dO.p));
-        if (nq) CM_HIP(h, hipMemcpy2DAsync((char *)out + es * c0, es * n_out, dO.p, es * w, es * w, (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+        int it = 0;
+        for (int64_t q0 = 0; q0 < nq; q0 += qt, ++it) {
+            const int64_t nt = std::min<int64_t>(qt, nq - q0);
+            const int b = it & 1;
+            if (it >= 2) CM_HIP(h, hipStreamWaitEvent(h->stream, h->tile_ev[b], 0));   // the copy of tile it-2 has left this buffer
+            CM_TRY(cm_spmm_dense_run(h, dp.as<int64_t>() + q0, dc.as<int32_t>(), dv.as<float>(), nt, dB.p, w, b_dtype, dO[b].p));
+            CM_HIP(h, hipEventRecord(h->tile_ev[b], h->stream));
+            CM_HIP(h, hipStreamWaitEvent(h->copy_stream, h->tile_ev[b], 0));
+            CM_HIP(h, hipMemcpy2DAsync((char *)out + es * ((size_t)q0 * n_out + c0), es * n_out, dO[b].p, es * w, es * w, (size_t)nt,
+                                       hipMemcpyDeviceToHost, h->copy_stream));
+            CM_HIP(h, hipEventRecord(h->tile_ev[b], h->copy_stream));
+        }
+        CM_HIP(h, hipStreamSynchronize(h->copy_stream));
         CM_TRY(sync(h));
     }
     return CM_OK;
-}
-
-static cm_status spmm_csr_common(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
-                                 const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
-                                 int64_t n_out, int64_t *out_indptr_w, const int64_t *out_indptr_r, int32_t *out_cols,
-                                 float *out_vals) {
-    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + 4096));
-    DevBuf dp, dc, dv, bp, bc, bv, rn, op, oc, ov;
-    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));
-    CM_TRY(upload_csr(h, b_indptr, b_cols, b_vals, n_ref, bp, bc, bv));
-    CM_TRY(op.alloc(h, 8 * ((size_t)nq + 1)));
-    if (out_indptr_w) {
-        CM_TRY(rn.alloc(h, 4 * (size_t)nq));
-        CM_TRY(cm_spmm_csr_count_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, bp.as<int64_t>(), bc.as<int32_t>(),
-                                     bv.as<float>(), n_out, rn.as<int32_t>()));
-        CM_TRY(cm_exclusive_scan_i32_to_i64(h, rn.as<int32_t>(), nq, op.as<int64_t>()));
-        CM_TRY(d2h(h, out_indptr_w, op.p, 8 * ((size_t)nq + 1)));
-        return sync(h);
-    }
-    int64_t nnz = out_indptr_r[nq];
-    CM_TRY(oc.alloc(h, 4 * (size_t)nnz)); CM_TRY(ov.alloc(h, 4 * (size_t)nnz));
-    CM_TRY(h2d(h, op.p, out_indptr_r, 8 * ((size_t)nq + 1)));
-    CM_TRY(cm_spmm_csr_fill_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, bp.as<int64_t>(), bc.as<int32_t>(),
-                                bv.as<float>(), n_out, op.as<int64_t>(), oc.as<int32_t>(), ov.as<float>()));
-    CM_TRY(d2h(h, out_cols, oc.p, 4 * (size_t)nnz));
-    CM_TRY(d2h(h, out_vals, ov.p, 4 * (size_t)nnz));
-    return sync(h);
 }
 
 cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
                           const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                           int64_t n_out, int64_t *out_indptr) {
     if (!h) return CM_E_INVALID;
-    return spmm_csr_common(h, indptr, cols, vals, nq, b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr, nullptr, nullptr, nullptr);
+    if (nq < 0 || n_ref < 0 || !indptr || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + 4096));
+    a3_session_drop(h);
+    A3Session *ss = new (std::nothrow) A3Session();
+    if (!ss) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: out of host memory");
+    h->a3_session = ss;
+    const void *key[6] = {indptr, cols, vals, b_indptr, b_cols, b_vals};
+    memcpy(ss->key, key, sizeof(key));
+    ss->nq = nq; ss->n_ref = n_ref; ss->n_out = n_out;
+    DevBuf rn;
+    cm_status rc = upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv);
+    if (rc == CM_OK) rc = upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv);
+    if (rc == CM_OK) rc = ss->op.alloc(h, 8 * ((size_t)nq + 1));
+    if (rc == CM_OK) rc = rn.alloc(h, 4 * (size_t)nq);
+    if (rc == CM_OK)
+        rc = cm_spmm_csr_count_run(h, ss->dp.as<int64_t>(), ss->dc.as<int32_t>(), ss->dv.as<float>(), nq, ss->bp.as<int64_t>(),
+                                   ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out, rn.as<int32_t>());
+    if (rc == CM_OK) rc = cm_exclusive_scan_i32_to_i64(h, rn.as<int32_t>(), nq, ss->op.as<int64_t>());
+    if (rc == CM_OK) rc = d2h(h, out_indptr, ss->op.p, 8 * ((size_t)nq + 1));
+    if (rc == CM_OK) rc = sync(h);
+    if (rc != CM_OK) a3_session_drop(h);
+    return rc;
 }
 
 cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
                       const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                       int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
     if (!h) return CM_E_INVALID;
-    return spmm_csr_common(h, indptr, cols, vals, nq, b_indptr, b_cols, b_vals, n_ref, n_out, nullptr, out_indptr, out_cols, out_vals);
+    if (nq < 0 || n_ref < 0 || !indptr || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    CM_TRY(begin_call(h, 4096));
+    CM_TRY(tile_streams(h));
+    const void *key[6] = {indptr, cols, vals, b_indptr, b_cols, b_vals};
+    A3Session *ss = static_cast<A3Session *>(h->a3_session);
+    A3Session local;
+    if (!(ss && !memcmp(ss->key, key, sizeof(key)) && ss->nq == nq && ss->n_ref == n_ref && ss->n_out == n_out)) {
+        // no matching cm_spmm_csr_nnz call on this handle: upload here
+        a3_session_drop(h);
+        ss = &local;
+        CM_TRY(upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv));
+        CM_TRY(upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv));
+        CM_TRY(ss->op.alloc(h, 8 * ((size_t)nq + 1)));
+        CM_TRY(h2d(h, ss->op.p, out_indptr, 8 * ((size_t)nq + 1)));
+    }
+    // Query tiles: the output (which approaches nq x n_out for dense neighbourhoods) is produced in tiles of at most `cap`
+    // entries, copied to the caller's arrays on a second stream while the next tile is computed.
+    const size_t budget = device_budget(h, "CELLMAP_SPGEMM_BUDGET_MB");
+    const int64_t nnz = out_indptr[nq];
+    int64_t cap = std::max<int64_t>((int64_t)(budget / 16), 1);   // two buffers of (int32 column + float32 value) per entry
+    int64_t longest = 0;
+    for (int64_t i = 0; i < nq; ++i) longest = std::max<int64_t>(longest, out_indptr[i + 1] - out_indptr[i]);
+    if (cap < longest) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: not enough device memory for one output row (%lld entries)", (long long)longest);
+    cap = std::min<int64_t>(cap, std::max<int64_t>(nnz, 1));
+    DevBuf oc[2], ov[2];
+    for (int b = 0; b < 2; ++b) { CM_TRY(oc[b].alloc(h, 4 * (size_t)cap)); CM_TRY(ov[b].alloc(h, 4 * (size_t)cap)); }
+    cm_status rc = CM_OK;
+    int it = 0;
+    for (int64_t q0 = 0; q0 < nq && rc == CM_OK; ++it) {
+        // rows [q0, q1): as many as fit `cap` entries (binary search on the host copy of the output indptr)
+        const int64_t base = out_indptr[q0];
+        int64_t q1 = std::upper_bound(out_indptr + q0, out_indptr + nq + 1, base + cap) - out_indptr - 1;
+        if (q1 <= q0) q1 = q0 + 1;
+        const int64_t tn = out_indptr[q1] - base;
+        const int b = it & 1;
+        if (it >= 2) rc = hipStreamWaitEvent(h->stream, h->tile_ev[b], 0) == hipSuccess ? CM_OK : CM_E_HIP;
+        if (rc == CM_OK)
+            rc = cm_spmm_csr_fill_run(h, ss->dp.as<int64_t>() + q0, ss->dc.as<int32_t>(), ss->dv.as<float>(), q1 - q0, ss->bp.as<int64_t>(),
+                                      ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out, ss->op.as<int64_t>() + q0, base, oc[b].as<int32_t>(),
+                                      ov[b].as<float>());
+        if (rc == CM_OK && tn > 0) {
+            CM_HIP(h, hipEventRecord(h->tile_ev[b], h->stream));
+            CM_HIP(h, hipStreamWaitEvent(h->copy_stream, h->tile_ev[b], 0));
+            CM_HIP(h, hipMemcpyAsync(out_cols + base, oc[b].p, 4 * (size_t)tn, hipMemcpyDeviceToHost, h->copy_stream));
+            CM_HIP(h, hipMemcpyAsync(out_vals + base, ov[b].p, 4 * (size_t)tn, hipMemcpyDeviceToHost, h->copy_stream));
+            CM_HIP(h, hipEventRecord(h->tile_ev[b], h->copy_stream));
+        }
+        q0 = q1;
+    }
+    if (rc == CM_OK) { CM_HIP(h, hipStreamSynchronize(h->copy_stream)); rc = sync(h); }
+    else { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
+    a3_session_drop(h);
+    return rc;
 }
 
 }  // extern "C"

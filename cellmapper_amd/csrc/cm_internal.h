@@ -25,6 +25,11 @@ struct cm_handle_s {
     int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay ...
     int64_t staged_ivf_nref = 0, staged_ivf_nq = 0;   // ... on a problem of these sizes
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
+    // host tier of A3: device copies of the mapping matrix / payload / output indptr kept between cm_spmm_csr_nnz and the
+    // matching cm_spmm_csr call (opaque: owned by cm_api.hip, freed by cm_destroy)
+    void *a3_session = nullptr;
+    hipStream_t copy_stream = nullptr;   // D2H of finished output tiles while the next tile is computed (host tier)
+    hipEvent_t tile_ev[2] = {nullptr, nullptr};
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;
     hipEvent_t ev[CM_N_STAGE_EVENTS] = {};
@@ -102,5 +107,5 @@ cm_status cm_spmm_csr_count_run(cm_handle_t h, const int64_t *d_indptr, const in
                                 int64_t n_out, int32_t *d_row_nnz);
 cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
-                               int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals);
+                               int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals);
 cm_status cm_exclusive_scan_i32_to_i64(cm_handle_t h, const int32_t *d_in, int64_t n, int64_t *d_out /* n+1 */);

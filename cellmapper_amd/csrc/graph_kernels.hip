@@ -8,6 +8,9 @@
 //   cellmapper.py:338,373,628  mapping_matrix @ dense          cellmapper.py:373  mapping_matrix @ sparse
 #include "cm_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #include <math.h>
 
 namespace {
@@ -370,56 +373,166 @@ __global__ __launch_bounds__(256) void spmm_narrow(const int64_t *__restrict__ i
 }
 
 // ------------------------------------------------------------------ A3: CSR x CSR --------------------
-// One workgroup per output row with a dense float32 accumulator in LDS (n_out <= 36864 columns) plus a
-// "touched" bitmap.  Neighbour rows are applied one after the other (ascending column order of the mapping
-// matrix) so every output element sees the same sequence of float32 adds as scipy's csr_matmat.
-// MODE 0: count non-zeros per row.  MODE 1: emit (column, value) pairs in ascending column order.
+// One workgroup per output row with a dense float32 accumulator in LDS for `ct` output columns at a time (one pass when
+// n_out <= ct = 32 768 columns; wider payloads are processed in column passes and the row's output is emitted pass by
+// pass, so columns stay ascending).  Every output element must see the same sequence of float32 adds as scipy's
+// csr_matmat: neighbour rows in ascending column order of the mapping matrix -- a workgroup barrier separates the adds of
+// consecutive neighbours (entries of one payload row have distinct columns and need none).  The gather itself is software
+// pipelined: neighbours are taken in batches of SPG_NB; every thread keeps the first 1 024 entries' (column, value) pairs
+// of the NEXT batch's payload rows in registers, so ~SPG_NB x 8 KB per workgroup are in flight while the current batch is
+// added -- the barrier per neighbour no longer exposes the load latency.  The per-neighbour metadata
+// (weight, payload row bounds) sits in LDS; the next row's is prefetched into registers.  Exact zeros are dropped like
+// csr_matmat does.   MODE 0: count non-zeros per row.  MODE 1: emit (column, value) pairs in ascending column order.
+constexpr int SPG_NB = 8;     // neighbours per batch (two batches of (column, value) x 2 chunks live in registers)
+constexpr int SPG_MK = 512;   // neighbours per metadata chunk (one per thread)
 template <int MODE>
 __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                     const float *__restrict__ vals, int64_t nq,
                                                     const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
-                                                    const float *__restrict__ bvals, int n_out, int32_t *__restrict__ row_nnz,
-                                                    const int64_t *__restrict__ out_indptr, int32_t *__restrict__ ocols,
-                                                    float *__restrict__ ovals) {
+                                                    const float *__restrict__ bvals, int n_out, int ct,
+                                                    int32_t *__restrict__ row_nnz, const int64_t *__restrict__ out_indptr,
+                                                    int64_t out_base, int32_t *__restrict__ ocols, float *__restrict__ ovals,
+                                                    int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *acc = reinterpret_cast<float *>(smem);  // [n_out]
-    int *scan = reinterpret_cast<int *>(acc + ((n_out + 3) & ~3));  // [blockDim.x]
-    const int nt = blockDim.x, tid = threadIdx.x;
+    float *acc = reinterpret_cast<float *>(smem);                       // [ct] (ct is a multiple of 4)
+    int64_t *m_b0 = reinterpret_cast<int64_t *>(acc + ct);              // [SPG_MK] first entry of the neighbour's payload row
+    int *m_len = reinterpret_cast<int *>(m_b0 + SPG_MK);                // [SPG_MK] its length
+    float *m_a = reinterpret_cast<float *>(m_len + SPG_MK);             // [SPG_MK] the neighbour's weight
+    int *wsum = reinterpret_cast<int *>(m_a + SPG_MK);                  // [2][8] wave totals (by pass parity)
+    const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    int parity = 0;
+    auto fetch_meta = [&](int64_t row, int64_t off, float &ma, int64_t &mb0, int &mlen) {
+        ma = 0.f; mb0 = 0; mlen = 0;
+        if (row < nq) {
+            const int64_t p = indptr[row] + off + tid;
+            if (p < indptr[row + 1]) {
+                const int64_t j = cols[p];
+                ma = vals[p];
+                mb0 = bptr[j];
+                mlen = (int)(bptr[j + 1] - mb0);
+            }
+        }
+    };
+    float pre_a; int64_t pre_b0; int pre_len;      // first metadata chunk of the next row (in flight during this row)
+    int64_t pre_deg = 0, pre_out = 0;              // ... its degree and (MODE 1) the start of its output
+    auto fetch_row = [&](int64_t row) {
+        fetch_meta(row, 0, pre_a, pre_b0, pre_len);
+        pre_deg = row < nq ? indptr[row + 1] - indptr[row] : 0;
+        pre_out = (MODE == 1 && row < nq) ? out_indptr[row] : 0;
+    };
+    fetch_row(blockIdx.x);
     for (int64_t row = blockIdx.x; row < nq; row += gridDim.x) {
-        for (int c = tid; c < n_out; c += nt) acc[c] = 0.f;
-        __syncthreads();
-        for (int64_t p = indptr[row]; p < indptr[row + 1]; ++p) {
-            const float a = vals[p];
-            const int64_t j = cols[p];
-            for (int64_t t = bptr[j] + tid; t < bptr[j + 1]; t += nt) {
-                int c = bcols[t];
-                acc[c] = __fadd_rn(acc[c], __fmul_rn(a, bvals[t]));
+        const int64_t deg = pre_deg, row_out = pre_out;
+        (void)row_out;
+        const float f_a = pre_a; const int64_t f_b0 = pre_b0; const int f_len = pre_len;
+        fetch_row(row + gridDim.x);
+        int total = 0;   // non-zeros of this row emitted by earlier column passes
+        for (int c0 = 0; c0 < n_out; c0 += ct) {
+            const int cw = (n_out - c0 < ct) ? n_out - c0 : ct;
+            for (int c = tid; c < cw; c += nt) acc[c] = 0.f;
+            for (int64_t off = 0; off < deg || off == 0; off += SPG_MK) {
+                float ma; int64_t mb0; int mlen;
+                if (off == 0) { ma = f_a; mb0 = f_b0; mlen = f_len; }
+                else fetch_meta(row, off, ma, mb0, mlen);
+                __syncthreads();   // previous chunk's items are done with the metadata (and: acc is zeroed)
+                m_a[tid] = ma; m_b0[tid] = mb0; m_len[tid] = mlen;
+                __syncthreads();
+                const int nchunk = (int)(deg - off < SPG_MK ? deg - off : SPG_MK);
+                // ---- batches of SPG_NB neighbours, two register sets: the loads of batch i+1 are in flight while batch i
+                // is added (straight-line code, so the compiler counts the outstanding loads instead of draining them)
+                int ca[SPG_NB][2] = {}, cbv[SPG_NB][2] = {};
+                float va[SPG_NB][2] = {}, vb[SPG_NB][2] = {};
+                auto uni = [&](int u, int64_t &b0, int &len, float &wa) {   // metadata of neighbour u (scalar registers)
+                    len = 0; b0 = 0; wa = 0.f;
+                    if (u < nchunk) {
+                        len = __builtin_amdgcn_readfirstlane(m_len[u]);
+                        const int64_t b = m_b0[u];
+                        b0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+                        wa = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_a[u])));
+                    }
+                };
+                auto load_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], int ub) {
+                    // unconditional loads from clamped (always valid) addresses inside a UNIFORM branch, raw values kept:
+                    // nothing here needs a loaded value, so the compiler issues all of them back to back
+#pragma unroll
+                    for (int n = 0; n < SPG_NB; ++n) {
+                        int64_t b0; int len; float wa;
+                        uni(ub + n, b0, len, wa);
+                        if (len > 0 && !(dbg & 4)) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int t = j * 512 + tid;
+                                const int64_t src = b0 + (t < len ? t : len - 1);
+                                cc[n][j] = bcols[src];
+                                vv[n][j] = bvals[src];
+                            }
+                        }
+                    }
+                };
+                auto apply_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], int ub) {
+#pragma unroll
+                    for (int n = 0; n < SPG_NB; ++n) {
+                        int64_t b0; int len; float wa;
+                        uni(ub + n, b0, len, wa);
+                        if (len > 0) {   // (uniform)
+                            // the previous neighbour's adds are done.  (Not __syncthreads(): its fence would also wait
+                            // for the prefetched loads of the next batch -- only LDS traffic has to be ordered here.)
+                            if (!(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int c = cc[n][j] - c0;
+                                if (!(dbg & 6) && j * 512 + tid < len && (unsigned)c < (unsigned)cw)
+                                    acc[c] = __fadd_rn(acc[c], __fmul_rn(wa, vv[n][j]));
+                            }
+                            for (int64_t t = 1024 + tid; t < len; t += 512) {   // payload rows longer than 1 024 entries
+                                const int c = bcols[b0 + t] - c0;
+                                if ((unsigned)c < (unsigned)cw) acc[c] = __fadd_rn(acc[c], __fmul_rn(wa, bvals[b0 + t]));
+                            }
+                        }
+                    }
+                };
+                load_batch(ca, va, 0);
+                for (int ub = 0; ub < nchunk; ub += 2 * SPG_NB) {
+                    load_batch(cbv, vb, ub + SPG_NB);
+                    apply_batch(ca, va, ub);
+                    load_batch(ca, va, ub + 2 * SPG_NB);
+                    apply_batch(cbv, vb, ub + SPG_NB);
+                }
             }
-            __syncthreads();
-        }
-        // ordered compaction: each thread owns a contiguous column range
-        const int per = (n_out + nt - 1) / nt;
-        const int cb = tid * per, ce = (cb + per < n_out) ? cb + per : n_out;
-        int mine = 0;
-        for (int c = cb; c < ce; ++c) mine += (acc[c] != 0.f) ? 1 : 0;
-        scan[tid] = mine;
-        __syncthreads();
-        for (int o = 1; o < nt; o <<= 1) {
-            int add = tid >= o ? scan[tid - o] : 0;
-            __syncthreads();
-            scan[tid] += add;
-            __syncthreads();
-        }
-        if (MODE == 0) {
-            if (tid == nt - 1) row_nnz[row] = scan[tid];
-        } else {
-            int64_t o = out_indptr[row] + scan[tid] - mine;
-            for (int c = cb; c < ce; ++c) {
-                float v = acc[c];
-                if (v != 0.f) { ocols[o] = c; ovals[o] = v; ++o; }
+            __syncthreads();   // all adds of the pass are done
+            // ordered compaction: every wave owns a contiguous slice of the pass's columns and walks it 64 columns at a
+            // time (ballot + prefix popcount): consecutive lanes write consecutive output entries
+            const int cwr = (((cw + nw - 1) / nw) + 63) & ~63;
+            const int lo = wave * cwr, hi = (lo + cwr < cw) ? lo + cwr : cw;
+            int wcount = 0;
+            for (int c = lo; c < hi; c += 64) {
+                const bool nz = (c + lane < hi) && acc[c + lane] != 0.f;
+                wcount += __popcll(__ballot(nz));
             }
+            if (lane == 0) wsum[parity * 8 + wave] = wcount;
+            __syncthreads();
+            int before = 0, all = 0;
+            for (int w = 0; w < nw; ++w) { const int s_ = wsum[parity * 8 + w]; all += s_; if (w < wave) before += s_; }
+            parity ^= 1;
+            if (MODE == 1 && !(dbg & 8)) {
+                int64_t o = row_out - out_base + total + before;
+                for (int c = lo; c < hi; c += 64) {
+                    const float v = (c + lane < hi) ? acc[c + lane] : 0.f;
+                    const bool nz = v != 0.f;
+                    const unsigned long long m = __ballot(nz);
+                    if (nz) {
+                        const int64_t q = o + __popcll(m & ((1ull << lane) - 1ull));
+                        ocols[q] = c0 + c + lane;
+                        ovals[q] = v;
+                    }
+                    o += __popcll(m);
+                }
+            }
+            total += all;
+            __syncthreads();   // the accumulator is free for the next pass / row
         }
-        __syncthreads();
+        if (MODE == 0 && tid == 0) row_nnz[row] = total;
     }
 }
 
@@ -553,24 +666,38 @@ cm_status cm_spmm_dense_run(cm_handle_t h, const int64_t *d_indptr, const int32_
     CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
 }
 
+constexpr int SPG_CT = 32768;   // output columns per pass of the A3 accumulator (128 KB of LDS)
+
 static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_out,
-                               int32_t *d_row_nnz, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
+                               int32_t *d_row_nnz, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols,
+                               float *d_out_vals) {
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm_csr: payload has no columns");
-    if (n_out > 36864) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: %lld output columns exceed the on-chip accumulator (36864); split the columns", (long long)n_out);
+    if (n_out > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: more than 2^31 output columns");
     if (nq == 0) return CM_OK;
-    size_t lds = (((size_t)n_out + 3) & ~size_t(3)) * 4 + 512 * 4;
-    unsigned grid = (unsigned)(nq < 2048 ? nq : 2048);
+    int ct = SPG_CT;
+    if (const char *e = getenv("CELLMAP_SPGEMM_CT")) { int v = atoi(e); if (v >= 4 && v <= SPG_CT) ct = v & ~3; }   // testing: force column passes
+    if (n_out < ct) ct = (int)((n_out + 3) & ~3LL);
+    const int dbg = getenv("CELLMAP_SPGEMM_DBG") ? atoi(getenv("CELLMAP_SPGEMM_DBG")) : 0;   // timing experiments only (wrong results)
+    size_t lds = (size_t)ct * 4 + (size_t)SPG_MK * 16 + 128;
+    if (h->n_cu <= 0) {
+        hipDeviceProp_t pr;
+        CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
+        h->n_cu = pr.multiProcessorCount;
+    }
+    // resident workgroups: the accumulator decides how many fit a CU's 160 KB of LDS
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 1024)));
+    unsigned grid = (unsigned)std::min<int64_t>(nq, (int64_t)h->n_cu * per_cu);
     if (mode == 0) {
         auto kern = spgemm_rows<0>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, d_row_nnz, d_out_indptr, d_out_cols, d_out_vals);
+                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg);
     } else {
         auto kern = spgemm_rows<1>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, d_row_nnz, d_out_indptr, d_out_cols, d_out_vals);
+                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg);
     }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
@@ -579,12 +706,14 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
 cm_status cm_spmm_csr_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
                                 int64_t n_out, int32_t *d_row_nnz) {
-    return spgemm_launch(h, 0, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, d_row_nnz, nullptr, nullptr, nullptr);
+    return spgemm_launch(h, 0, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, d_row_nnz, nullptr, 0, nullptr, nullptr);
 }
+// out_base: value subtracted from d_out_indptr[row] to address d_out_cols / d_out_vals (query tiles of a larger output:
+// the tile's buffers start at the tile's first entry)
 cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
-                               int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
-    return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, d_out_cols, d_out_vals);
+                               int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals) {
+    return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, out_base, d_out_cols, d_out_vals);
 }
 
 // ------------------------------------------------------------------ T1: precomputed-distance ingest --

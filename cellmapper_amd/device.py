@@ -130,13 +130,45 @@ class DevicePipeline:
                     _dp(code), _dp(conf))
         return code, conf
 
-    def spmm_dense(self, indptr, cols, vals, B):
+    def spmm_dense(self, indptr, cols, vals, B, out=None):
+        """``M @ B`` for a dense payload (A1 / A2).  Query tiles: pass ``indptr[q0:q1 + 1]`` (a view)."""
         t = self.torch
         nq = indptr.shape[0] - 1
-        out = t.empty((nq, B.shape[1]), dtype=B.dtype, device=self.device)
+        if out is None:
+            out = t.empty((nq, B.shape[1]), dtype=B.dtype, device=self.device)
+        elif tuple(out.shape) != (nq, B.shape[1]) or out.dtype != B.dtype or not out.is_contiguous():
+            raise ValueError("spmm_dense(out=...): need a contiguous [nq, n_out] tensor of the payload's dtype")
         self.h.call("cm_spmm_dense_dev", _dp(indptr), _dp(cols), _dp(vals), nq, _dp(B), B.shape[0], B.shape[1],
                     self._dtype_id(B), _dp(out))
         return out
+
+    def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None):
+        """Rows [q0, q1) of ``M @ B`` for a CSR payload (A3, device tier): ``(out_indptr, out_cols, out_vals)`` of the TILE
+        (``out_indptr`` starts at 0).  Count pass, exclusive scan, fill pass -- the structure of scipy's csr_matmat.
+        ``out=(ptr [>= nt+1] int64, cols int32, vals float32)``: caller-provided tile buffers with room for the worst case
+        (``nt * min(n_out, k * max payload row)`` entries) -- no host read between the passes; the tile's entry count is
+        ``ptr[nt]`` on the device."""
+        t = self.torch
+        nq_all = indptr.shape[0] - 1
+        q1 = nq_all if q1 is None else q1
+        nt = q1 - q0
+        n_ref = b_indptr.shape[0] - 1
+        ip = indptr[q0:q1 + 1]   # (a view: entries still index the full cols / vals)
+        optr = out[0] if out is not None else t.empty(nt + 1, dtype=t.int64, device=self.device)
+        self.h.call("cm_spmm_csr_nnz_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
+                    int(n_out), _dp(optr))
+        if out is not None:
+            oc, ov = out[1], out[2]
+            if optr.dtype != t.int64 or oc.dtype != t.int32 or ov.dtype != t.float32 or optr.shape[0] < nt + 1:
+                raise ValueError("spmm_csr(out=...): need (int64 [>= nt+1], int32, float32) device tensors")
+            nnz = None
+        else:
+            nnz = int(optr[-1].item())   # (one host read per tile: the tile's output has to be allocated)
+            oc = t.empty(max(nnz, 1), dtype=t.int32, device=self.device)
+            ov = t.empty(max(nnz, 1), dtype=t.float32, device=self.device)
+        self.h.call("cm_spmm_csr_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
+                    int(n_out), _dp(optr), _dp(oc), _dp(ov))
+        return (optr, oc, ov) if nnz is None else (optr, oc[:nnz], ov[:nnz])
 
     def map_labels(self, ref, qry, k, codes, n_cat, metric="euclidean", kernel="gaussian", epsilon=1e-8,
                    out_code=None, out_conf=None, want_graph=False):

@@ -189,6 +189,22 @@ cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *c
 cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
                       const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                       int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals);
+/* Host-tier streaming ("wide aggregation outputs"; cellmapper.py:372-373 materialises the whole
+ * product): cm_spmm_csr_nnz keeps its device copies of both matrices and of out_indptr on the handle until the matching
+ * cm_spmm_csr call (same pointers and sizes), so the pair uploads everything once; cm_spmm_csr and cm_spmm_dense produce
+ * the output in query tiles (cm_spmm_dense additionally in column slabs of the payload) sized to the free device memory and
+ * copy tile i to the caller's arrays on a second stream while tile i+1 is computed -- outputs larger than HBM are fine.
+ * Any number of output columns: the on-chip accumulator of the sparse product covers 32 768 columns per pass.
+ *
+ * Device tier of the same (asynchronous on the handle's stream).  cm_spmm_csr_nnz_dev writes d_out_indptr [nq+1] (exclusive
+ * scan of the per-row counts, starting at 0); cm_spmm_csr_dev fills d_out_cols / d_out_vals [d_out_indptr[nq]].  For a
+ * query TILE pass d_indptr + q0 (its entries index the full d_cols / d_vals) and the tile's row count as nq. */
+cm_status cm_spmm_csr_nnz_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                              const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
+                              int64_t n_out, int64_t *d_out_indptr);
+cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                          const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
+                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals);
 
 /* ------------------------------------- shared-neighbour counts: jaccard / hnoca mapping methods ------
  * Replaces `(yx @ xx.T) + (yy @ xy.T)` on the 0/1 adjacency matrices of the four k-NN graphs and the following

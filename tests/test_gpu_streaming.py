@@ -1,0 +1,115 @@
+"""GPU tests of the streaming aggregation tiers (SURVEY.md section 7 "wide aggregation outputs"; reference call sites
+cellmapper.py:338,372-373): column passes of the A3 accumulator, query-tiled host tiers of A2 / A3 (outputs that do not
+fit the device budget), the device-tier A3 entry points.  Everything is compared bit for bit with the CPU oracle's
+restatement of scipy's csr_matvecs / csr_matmat."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from cellmapper_amd import _native
+
+    return _native.default_handle()
+
+
+def mapping(rng, nq, n_ref, k, ragged=False):
+    cols = np.sort(rng.integers(0, n_ref, (nq, k)), axis=1).astype(np.int32)
+    vals = rng.random((nq, k), dtype=np.float32)
+    if not ragged:
+        return np.arange(nq + 1, dtype=np.int64) * k, cols.ravel(), vals.ravel()
+    lens = rng.integers(0, k + 1, nq)
+    lens[0] = 0
+    keep = np.arange(k)[None, :] < lens[:, None]
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), cols[keep], vals[keep]
+
+
+def csr_from_dense_rows(dense):
+    m = sp.csr_matrix(dense)   # drops exact zeros, ascending columns
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+
+@pytest.mark.parametrize("n_out,ct", [(500, None), (500, 64), (2000, 252), (40000, None)])
+def test_spgemm_column_passes_match_oracle(hip, oracle, monkeypatch, n_out, ct):
+    """n_out > 36 864 columns (two passes of the LDS accumulator), and forced narrow passes: same CSR as one pass."""
+    rng = np.random.default_rng(n_out)
+    n_ref, nq, k = 900, 260, 9
+    indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+    B = sp.random(n_ref, n_out, density=0.02, format="csr", dtype=np.float32, random_state=rng)
+    B.data[:5] = 0.0   # stored zeros in the payload: products that are exactly zero are dropped from the output
+    want = csr_from_dense_rows(oracle.spmm_csr(indptr, cols, vals, B))
+    if ct is not None:
+        monkeypatch.setenv("CELLMAP_SPGEMM_CT", str(ct))
+    got = hip.spmm_csr(indptr, cols, vals, B.indptr, B.indices, B.data, n_out)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_spgemm_host_tier_streams_query_tiles(hip, oracle, monkeypatch):
+    """Output larger than the device budget: query tiles, copied out while the next tile is computed."""
+    rng = np.random.default_rng(77)
+    n_ref, nq, k, n_out = 3000, 5000, 12, 3000
+    indptr, cols, vals = mapping(rng, nq, n_ref, k)
+    B = sp.random(n_ref, n_out, density=0.03, format="csr", dtype=np.float32, random_state=rng)
+    want = csr_from_dense_rows(oracle.spmm_csr(indptr, cols, vals, B))
+    monkeypatch.setenv("CELLMAP_SPGEMM_BUDGET_MB", "4")   # 4 MB -> tiles of 256 Ki entries: ~30 tiles
+    got = hip.spmm_csr(indptr, cols, vals, B.indptr, B.indices, B.data, n_out)
+    assert got[0][-1] > 4 * (4 << 20) // 16, "the test must need several tiles"
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_spmm_dense_host_tier_streams_query_tiles(hip, oracle, monkeypatch):
+    """Dense payload: column slabs x query tiles with a two-tile ring; same bits as one pass."""
+    rng = np.random.default_rng(78)
+    n_ref, nq, k, G = 2500, 9000, 10, 640
+    indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+    for dt in (np.float32, np.float64):
+        X = rng.random((n_ref, G)).astype(dt)
+        want = oracle.spmm_dense(indptr, cols, vals, X)
+        monkeypatch.setenv("CELLMAP_SPMM_BUDGET_MB", "8")   # forces 1024-row query tiles and several column slabs
+        np.testing.assert_array_equal(hip.spmm_dense(indptr, cols, vals, X), want)
+        monkeypatch.delenv("CELLMAP_SPMM_BUDGET_MB")
+        np.testing.assert_array_equal(hip.spmm_dense(indptr, cols, vals, X), want)
+
+
+def test_spgemm_device_tier_tiles_equal_the_whole(oracle):
+    """cm_spmm_csr_nnz_dev / cm_spmm_csr_dev on query tiles (views of the indptr), with and without caller-provided
+    worst-case buffers, against the oracle."""
+    import torch
+
+    from cellmapper_amd.device import DevicePipeline
+
+    pipe = DevicePipeline(0)
+    rng = np.random.default_rng(79)
+    n_ref, nq, k, n_out = 1500, 1000, 8, 700
+    indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+    B = sp.random(n_ref, n_out, density=0.05, format="csr", dtype=np.float32, random_state=rng)
+    want = csr_from_dense_rows(oracle.spmm_csr(indptr, cols, vals, B))
+    dev = pipe.device
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    d = dict(indptr=t(indptr, np.int64), cols=t(cols, np.int32), vals=t(vals, np.float32), bp=t(B.indptr, np.int64),
+             bc=t(B.indices, np.int32), bv=t(B.data, np.float32))
+    with torch.cuda.stream(pipe.stream):
+        tile = 300
+        cap = tile * n_out
+        buf = (torch.empty(tile + 1, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+               torch.empty(cap, dtype=torch.float32, device=dev))
+        for use_buf in (False, True):
+            ptrs, cs, vs = [np.zeros(1, np.int64)], [], []
+            for q0 in range(0, nq, tile):
+                q1 = min(nq, q0 + tile)
+                optr, oc, ov = pipe.spmm_csr(d["indptr"], d["cols"], d["vals"], d["bp"], d["bc"], d["bv"], n_out, q0, q1,
+                                             out=buf if use_buf else None)
+                pipe.synchronize()
+                op = optr[:q1 - q0 + 1].cpu().numpy()
+                ptrs.append(op[1:] + ptrs[-1][-1])
+                cs.append(oc[:op[-1]].cpu().numpy())
+                vs.append(ov[:op[-1]].cpu().numpy())
+            np.testing.assert_array_equal(np.concatenate(ptrs), want[0])
+            np.testing.assert_array_equal(np.concatenate(cs), want[1])
+            np.testing.assert_array_equal(np.concatenate(vs), want[2])
