@@ -1,0 +1,186 @@
+"""GPU tests at the FULL sizes of BASELINE.json's configs, through the device tier of the C ABI.
+
+What can be compared in full is (config 1 against the oracle; config 2's 1.5 M rows against an independent candidate
+route); the rest is checked through size-independent properties plus oracle samples, as SURVEY.md 8d prescribes.
+Reference call sites: knn.py:428-440 (search), cellmapper.py:338 (obsm), :372-373 (layers), :595-605 (labels)."""
+import argparse
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    import torch
+
+    from cellmapper_amd.device import DevicePipeline
+
+    p = DevicePipeline(0)
+    torch.cuda.set_stream(p.stream)
+    return p
+
+
+def test_config1_exact_size_against_the_oracle_in_full(oracle):
+    """BASELINE configs[0]: 10 k x 10 k, d=50, k=15, one label column -- every row against the oracle, through the
+    drop-in host tier (what the reference's own CPU run produces)."""
+    from cellmapper_amd import _native
+
+    hip = _native.default_handle()
+    rng = np.random.default_rng(0)
+    n, d, k, n_cat = 10_000, 50, 15, 20
+    ref = rng.standard_normal((n, d)).astype(np.float32)
+    qry = rng.standard_normal((n, d)).astype(np.float32)
+    codes = rng.integers(0, n_cat, n).astype(np.int32)
+    o = oracle.run_path(ref, qry, k, labels=codes, n_cat=n_cat)
+    dist, idx = hip.knn(ref, qry, k)
+    assert np.array_equal(idx, o["idx"]) and np.array_equal(dist, o["dist"])
+    indptr, cols, vals, _, sigma = hip.mapping_matrix(dist, idx, n, "gaussian")
+    np.testing.assert_allclose(sigma, o["param"], rtol=1e-12)
+    assert np.array_equal(cols, o["cols"])
+    np.testing.assert_allclose(vals, o["vals"], rtol=1e-5)
+    code, conf = hip.label_vote(indptr, cols, vals, codes, n_cat)
+    agree = code == o["pred_code"]
+    if not agree.all():   # labels may differ only where the two best classes are within float32 rounding of each other
+        bad = np.flatnonzero(~agree)
+        assert len(bad) <= 2 and np.all(np.abs(conf[bad] - o["conf"][bad]) < 1e-6)
+    np.testing.assert_allclose(conf, o["conf"], rtol=1e-5)
+
+
+def test_config2_all_rows_by_an_independent_route(pipe, oracle, monkeypatch):
+    """BASELINE configs[1], ALL 1.5 M queries: the default route (split-fp16 MFMA filter, seeded thresholds) against the
+    direct-difference fp32 VALU filter (different kernel, different arithmetic, different error bound) -- both certified,
+    so indices and float64 distances must be bit-identical on every row; 4 096 rows against the oracle."""
+    import torch
+
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(0)
+    n, d, k = 1_500_000, 50, 30
+    ref = torch.randn((n, d), generator=g, device=pipe.device)
+    qry = torch.randn((n, d), generator=g, device=pipe.device)
+    dist, idx = pipe.knn(ref, qry, k)
+    pipe.synchronize()
+    st = pipe.h.knn_stats()
+    assert st["lowd_path"] == 2 and st["filter_products"] == 1 and st["fallback_queries"] <= 64, st
+    monkeypatch.setenv("CELLMAP_FILTER_PRODUCTS", "4")
+    dist4, idx4 = pipe.knn(ref, qry, k)
+    pipe.synchronize()
+    st4 = pipe.h.knn_stats()
+    monkeypatch.delenv("CELLMAP_FILTER_PRODUCTS")
+    assert st4["filter_products"] == 4, st4
+    assert torch.equal(idx, idx4) and torch.equal(dist, dist4)
+    del dist4, idx4
+    rng = np.random.default_rng(1)
+    sel = torch.as_tensor(np.sort(rng.choice(n, 4096, replace=False)), device=pipe.device)
+    od, oi = oracle.knn_euclidean(ref.cpu().numpy(), qry[sel].cpu().numpy(), k)
+    assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
+
+
+def _args(**kw):
+    a = argparse.Namespace(config=2, nq=0, nref=0, d=50, k=30, genes=0, density=0.03, tile=0, ncat=20, kernel="gaussian",
+                           metric="euclidean", steps=1, warmup=0, check=1, cpu_sample=0)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_config3_full_size_dense_layer_transfer(pipe):
+    """BASELINE configs[2]: 1.5 M x 1.5 M search, obsm (d_out = 2) and the dense layer over 20 000 genes (120 GB payload,
+    120 GB product) through the device tier -- sampled product rows bit-equal to the oracle's csr_matvecs restatement
+    (inside bench_wide.run_config3), the A2 kernel above half of the HBM roofline."""
+    import torch
+
+    import bench_wide
+
+    free_b, total_b = torch.cuda.mem_get_info(pipe.device)
+    n, G = 1_500_000, 20_000
+    if free_b < n * G * 4 + (24 << 30):
+        pytest.skip(f"needs the 120 GB payload resident: {free_b >> 30} GiB free")
+    r = bench_wide.run_config3(_args(config=3, nq=n, nref=n, genes=G), pipe, torch)
+    assert r["parity_check"]["ok"], r["parity_check"]
+    assert r["roofline"]["frac"] > 0.5, r["roofline"]
+    torch.cuda.empty_cache()
+
+
+def test_config3_properties_constant_payload_and_row_sums(pipe):
+    """Rows of the mapping matrix sum to 1: a constant payload column comes back constant (1e-5), a wide random payload's
+    product lies between the payload's column minima and maxima."""
+    import torch
+
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(3)
+    n_ref, nq, k, G = 400_000, 300_000, 30, 4096
+    ref = torch.randn((n_ref, 50), generator=g, device=pipe.device)
+    qry = torch.randn((nq, 50), generator=g, device=pipe.device)
+    dist, idx = pipe.knn(ref, qry, k)
+    m = pipe.moments(dist, idx)
+    cols, vals, cnt = pipe.weights(dist, idx, n_ref, "gaussian", pipe.kernel_param(m, "gaussian"))
+    indptr, oc, ov = pipe.to_csr(cols, vals, cnt)
+    X = torch.rand((n_ref, G), generator=g, device=pipe.device)
+    X[:, 7] = 2.5
+    out = pipe.spmm_dense(indptr, oc, ov, X)
+    pipe.synchronize()
+    assert bool(((out[:, 7] - 2.5).abs() < 2.5e-5).all())
+    # convex combinations of values in [0, 1) (rows sum to 1 within float32 rounding)
+    assert float(out[:, :7].max()) <= 1.0 + 1e-5 and float(out[:, :7].min()) >= 0.0
+    assert float(out[:, 8:].max()) <= 1.0 + 1e-5 and float(out[:, 8:].min()) >= 0.0
+
+
+def test_config4_d128_large_reference_shard_merge(pipe, oracle):
+    """BASELINE configs[3]'s shapes on one GPU: d=128, k=30 against a 12 M-row reference, searched whole and as 8 shards
+    merged by cm_knn_merge -- identical; oracle sample."""
+    import torch
+
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(4)
+    n_ref, nq, d, k, shards = 12_000_000, 200_000, 128, 30, 8
+    ref = torch.empty((n_ref, d), device=pipe.device)
+    for r0 in range(0, n_ref, 1_000_000):
+        ref[r0:r0 + 1_000_000] = torch.randn((1_000_000, d), generator=g, device=pipe.device)
+    qry = torch.randn((nq, d), generator=g, device=pipe.device)
+    dist, idx = pipe.knn(ref, qry, k)
+    pipe.synchronize()
+    st = pipe.h.knn_stats()
+    assert st["lowd_path"] == 4 and st["fallback_queries"] <= 64, st
+    per = n_ref // shards
+    buf = torch.empty((shards, 2, nq, k), dtype=torch.int64, device=pipe.device)
+    for s_ in range(shards):
+        pipe.knn(ref[s_ * per:(s_ + 1) * per], qry, k, idx_offset=s_ * per, squared=True,
+                 out=(buf[s_, 0].view(torch.float64), buf[s_, 1]))
+    md, mi = pipe.merge_strided(buf.view(-1), shards, 2 * nq * k, 0, nq * k, nq, k, sqrt_out=True)
+    pipe.synchronize()
+    assert torch.equal(mi, idx) and torch.equal(md, dist)
+    sel = torch.arange(0, nq, nq // 96, device=pipe.device)[:96]
+    od, oi = oracle.knn_euclidean(ref.cpu().numpy(), qry[sel].cpu().numpy(), k)
+    assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
+
+
+def test_config5_full_size_spatial_self_mapping_and_sparse_imputation(pipe, oracle):
+    """BASELINE configs[4]: 4 M spatial cells (d=2, k=90).  Search: every cell is its own nearest neighbour at distance 0,
+    rows sorted, neighbours distinct and in range, oracle sample.  Expression imputation from the sparse payload
+    (30 000 genes, 3 %) on the first 200 k query rows in 16 k-row tiles: sampled CSR rows bit-equal to the oracle's
+    csr_matmat restatement (inside bench_wide.run_config5)."""
+    import torch
+
+    import bench_wide
+
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(5)
+    n, k = 4_000_000, 90
+    xy = torch.rand((n, 2), generator=g, device=pipe.device) * 2000.0
+    dist, idx = pipe.knn(xy, xy, k)
+    pipe.synchronize()
+    st = pipe.h.knn_stats()
+    assert st["fallback_queries"] <= 64, st
+    assert bool((idx[:, 0] == torch.arange(n, device=pipe.device)).all()) and bool((dist[:, 0] == 0).all())
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and bool(((idx >= 0) & (idx < n)).all())
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    sel = torch.arange(0, n, n // 256, device=pipe.device)[:256]
+    od, oi = oracle.knn_euclidean(xy.cpu().numpy(), xy[sel].cpu().numpy(), k)
+    assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
+    del dist, idx, srt
+    torch.cuda.empty_cache()
+    r = bench_wide.run_config5(_args(config=5, nq=200_000, nref=200_000, d=2, k=k, genes=30_000), pipe, torch)
+    assert r["parity_check"]["ok"], r["parity_check"]
+    assert r["config"]["output_nnz"] > 200_000 * 20_000   # near-dense product rows (the union of 90 neighbours' supports)
