@@ -148,22 +148,27 @@ def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
 
 
 def host_inclusive_leg(a, ref_np, qry_np, codes_np):
-    """Host arrays in -> host results out through the drop-in host tier (what `CellMapper.map` calls): PCIe copies and
-    numpy materialisation included.  SURVEY.md 8d's definition of the metric; reported next to `value`, never as it."""
+    """Host arrays in -> host results out through the graph tier of the C ABI -- exactly what `CellMapper.map(obs_keys=...)`
+    calls: both embeddings uploaded (cm_rep_create), search and mapping matrix kept on the device (cm_graph_knn,
+    cm_graph_mapping), label codes up, labels and confidences down (cm_graph_label_vote).  PCIe copies included.
+    SURVEY.md 8d's definition of the metric; reported next to `value`, never as it."""
     from cellmapper_amd import _native
 
     h = _native.default_handle()
     best = None
     for _ in range(2):
         t0 = time.perf_counter()
-        dist, idx = h.knn(ref_np, qry_np, a.k, metric=a.metric)
-        indptr, cols, vals, _, _ = h.mapping_matrix(dist, idx, ref_np.shape[0], kernel=a.kernel)
-        code, conf = h.label_vote(indptr, cols, vals, codes_np, a.ncat)
+        xr, yr = _native.DeviceRep(h, ref_np), _native.DeviceRep(h, qry_np)
+        g = _native.DeviceGraph(h, xr, yr, a.k, a.metric)
+        xr.close(); yr.close()
+        g.mapping(a.kernel)
+        code, conf = g.label_vote(codes_np, a.ncat)
         dt = time.perf_counter() - t0
+        g.close()
         best = dt if best is None else min(best, dt)
     return {"seconds": best, "value": qry_np.shape[0] / best, "unit": "query cells/s",
-            "what": "numpy in -> numpy out through the host-tier C ABI (cm_knn, cm_mapping_matrix, cm_label_vote), "
-                    "H2D/D2H included, best of 2"}
+            "what": "numpy in -> numpy out through the graph tier of the C ABI (cm_rep_create x2, cm_graph_knn, "
+                    "cm_graph_mapping, cm_graph_label_vote), H2D/D2H included, best of 2"}
 
 
 def git_rev(path):

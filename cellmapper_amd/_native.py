@@ -38,6 +38,9 @@ EXPORTS = [
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
+    "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
+    "cm_graph_mapping", "cm_graph_mapping_fetch", "cm_graph_label_vote", "cm_graph_spmm_dense", "cm_graph_spmm_csr_nnz",
+    "cm_graph_spmm_csr",
 ]
 
 
@@ -90,6 +93,18 @@ def load_library():
         lib.cm_expression_metrics.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
         lib.cm_expression_metrics_dev.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
         lib.cm_debug_mfma_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+        lib.cm_rep_create.argtypes = [vp, vp, i64, i32, i32, C.POINTER(vp)]
+        lib.cm_rep_destroy.argtypes = [vp, vp]
+        lib.cm_graph_knn.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
+        lib.cm_graph_destroy.argtypes = [vp, vp]
+        lib.cm_graph_info.argtypes = [vp, vp, vp]
+        lib.cm_graph_knn_fetch.argtypes = [vp, vp, vp, vp]
+        lib.cm_graph_mapping.argtypes = [vp, vp, i32, dbl, vp, vp]
+        lib.cm_graph_mapping_fetch.argtypes = [vp, vp, vp, vp, vp]
+        lib.cm_graph_label_vote.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+        lib.cm_graph_spmm_dense.argtypes = [vp, vp, vp, i64, i64, i32, vp]
+        lib.cm_graph_spmm_csr_nnz.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
+        lib.cm_graph_spmm_csr.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.cm_version.argtypes = []
         lib.cm_device_count.argtypes = []
         for name in EXPORTS:
@@ -323,6 +338,127 @@ class Handle:
         out_vals = np.empty(nnz, np.float32)
         self.call("cm_spmm_csr", _ptr(indptr), _ptr(cols), _ptr(vals), nq, _ptr(bi), _ptr(bc), _ptr(bv), n_ref,
                   int(n_out), _ptr(out_indptr), _ptr(out_cols), _ptr(out_vals))
+        return out_indptr, out_cols, out_vals
+
+
+class DeviceRep:
+    """An embedding matrix uploaded once (``cm_rep_create``): ``xrep`` / ``yrep`` of ``Neighbors``."""
+
+    def __init__(self, handle: Handle, X: np.ndarray):
+        X = np.ascontiguousarray(X)
+        if X.ndim != 2:
+            raise ValueError(f"Representation must be 2-D (got shape {X.shape}).")
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        if not np.isfinite(X).all():
+            raise ValueError("Input contains NaN or infinity.")
+        self.h, self.shape, self.dtype = handle, X.shape, X.dtype
+        r = C.c_void_p()
+        handle.call("cm_rep_create", _ptr(X), X.shape[0], X.shape[1], CM_F64 if X.dtype == np.float64 else CM_F32, C.byref(r))
+        self._r = r
+
+    def close(self):
+        if getattr(self, "_r", None) and getattr(self.h, "_h", None):
+            self.h.lib.cm_rep_destroy(self.h._h, self._r)
+        self._r = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceGraph:
+    """One k-NN graph kept in HBM (``cm_graph_*``), and after :meth:`mapping` its row-normalised mapping matrix: what the
+    drop-in classes hold between ``compute_neighbors`` -> ``compute_mapping_matrix`` -> ``map_obs`` / ``map_obsm`` /
+    ``map_layers``.  Host arrays are produced only by the ``fetch_*`` methods."""
+
+    def __init__(self, handle: Handle, ref: DeviceRep, qry: DeviceRep, k: int, metric: str = "euclidean", form: str = "auto"):
+        if metric not in METRICS:
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
+        if ref.shape[1] != qry.shape[1]:
+            raise ValueError(f"Incompatible representation shapes {ref.shape} and {qry.shape}.")
+        self.h = handle
+        g = C.c_void_p()
+        handle.call("cm_graph_knn", ref._r, qry._r, int(k), METRICS[metric], FORMS[form], C.byref(g))
+        self._g = g
+        self.nq, self.n_ref, self.k = qry.shape[0], ref.shape[0], int(k)
+        self.dist_dtype = np.float32 if (METRICS[metric] == 1 and ref.dtype == np.float32) else np.float64
+        self.nnz = None
+        self.param = None
+
+    def close(self):
+        if getattr(self, "_g", None) and getattr(self.h, "_h", None):
+            self.h.lib.cm_graph_destroy(self.h._h, self._g)
+        self._g = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fetch_knn(self):
+        dist = np.empty((self.nq, self.k), self.dist_dtype)
+        idx = np.empty((self.nq, self.k), np.int64)
+        self.h.call("cm_graph_knn_fetch", self._g, _ptr(dist), _ptr(idx))
+        return dist, idx
+
+    def mapping(self, kernel: str = "gaussian", epsilon: float = 1e-8):
+        if kernel not in KERNELS:
+            raise ValueError(
+                f"Unknown kernel: {kernel}. Supported kernels are: 'gaussian', 'scarches', 'random', "
+                "'inverse_distance', 'equal'.")
+        nnz, param = C.c_int64(0), C.c_double(0.0)
+        self.nnz = None
+        self.h.call("cm_graph_mapping", self._g, KERNELS[kernel], float(epsilon), C.byref(nnz), C.byref(param))
+        self.nnz, self.param = nnz.value, param.value
+        return self.nnz, self.param
+
+    @property
+    def has_mapping(self) -> bool:
+        return self.nnz is not None
+
+    def fetch_mapping(self):
+        indptr = np.empty(self.nq + 1, np.int64)
+        cols = np.empty(self.nnz, np.int32)
+        vals = np.empty(self.nnz, np.float32)
+        self.h.call("cm_graph_mapping_fetch", self._g, _ptr(indptr), _ptr(cols), _ptr(vals))
+        return indptr, cols, vals
+
+    def label_vote(self, codes, n_cat: int):
+        codes = np.ascontiguousarray(codes, np.int32)
+        out_code = np.empty(self.nq, np.int32)
+        out_conf = np.empty(self.nq, np.float32)
+        self.h.call("cm_graph_label_vote", self._g, _ptr(codes), len(codes), int(n_cat), _ptr(out_code), _ptr(out_conf))
+        return out_code, out_conf
+
+    def spmm_dense(self, B):
+        B = np.asarray(B)
+        squeeze = B.ndim == 1
+        if squeeze:
+            B = B.reshape(-1, 1)
+        if B.dtype != np.float32:
+            B = B.astype(np.float64, copy=False)  # scipy upcast(float32, other) -> float64 for ints / float64
+        B = np.ascontiguousarray(B)
+        out = np.empty((self.nq, B.shape[1]), B.dtype)
+        self.h.call("cm_graph_spmm_dense", self._g, _ptr(B), B.shape[0], B.shape[1], CM_F64 if B.dtype == np.float64 else CM_F32,
+                    _ptr(out))
+        return out[:, 0] if squeeze else out
+
+    def spmm_csr(self, B_indptr, B_cols, B_vals, n_out: int):
+        bi = np.ascontiguousarray(B_indptr, np.int64)
+        bc = np.ascontiguousarray(B_cols, np.int32)
+        bv = np.ascontiguousarray(B_vals, np.float32)
+        n_ref = len(bi) - 1
+        out_indptr = np.empty(self.nq + 1, np.int64)
+        self.h.call("cm_graph_spmm_csr_nnz", self._g, _ptr(bi), _ptr(bc), _ptr(bv), n_ref, int(n_out), _ptr(out_indptr))
+        nnz = int(out_indptr[self.nq])
+        out_cols = np.empty(nnz, np.int32)
+        out_vals = np.empty(nnz, np.float32)
+        self.h.call("cm_graph_spmm_csr", self._g, _ptr(bi), _ptr(bc), _ptr(bv), n_ref, int(n_out), _ptr(out_indptr), _ptr(out_cols),
+                    _ptr(out_vals))
         return out_indptr, out_cols, out_vals
 
 

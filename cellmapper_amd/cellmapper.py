@@ -8,7 +8,6 @@ Out of scope here: the ``use_rep=None`` PCA / CCA fallback
 """
 from __future__ import annotations
 
-import gc
 from typing import Any, Literal
 
 import numpy as np
@@ -38,6 +37,7 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
                         self.reference.n_obs)
         self.knn: Neighbors | None = None
         self._mapping_matrix: csr_matrix | None = None
+        self._mapping_graph = None   # device-resident mapping matrix (a DeviceGraph); scipy CSR is built on first read
         self.label_transfer_metrics: dict[str, Any] | None = None
         self.label_transfer_report: pd.DataFrame | None = None
         self.prediction_postfix: str | None = None
@@ -56,12 +56,23 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
     # ------------------------------------------------------------------ mapping matrix (K3) ----------
     @property
     def mapping_matrix(self):
-        """Row-normalised mapping matrix, scipy CSR float32 of shape ``(n_query, n_reference)``."""
+        """Row-normalised mapping matrix, scipy CSR float32 of shape ``(n_query, n_reference)``.  After
+        ``compute_mapping_matrix`` with a kernel method it lives on the device; the scipy object is built when read."""
+        if self._mapping_matrix is None and self._mapping_graph is not None:
+            indptr, cols, vals = self._mapping_graph.fetch_mapping()
+            m = csr_matrix((vals, cols, indptr), shape=(self.query.n_obs, self.reference.n_obs))
+            m.has_sorted_indices = True
+            m.has_canonical_format = True
+            self._mapping_matrix = m
         return self._mapping_matrix
 
     @mapping_matrix.setter
     def mapping_matrix(self, value):
+        self._mapping_graph = None   # a caller-supplied matrix replaces the resident one
         self._mapping_matrix = None if value is None else self._validate_and_normalize_mapping_matrix(value)
+
+    def _has_mapping(self) -> bool:
+        return self._mapping_matrix is not None or self._mapping_graph is not None
 
     def _validate_and_normalize_mapping_matrix(self, mapping_matrix) -> csr_matrix:
         """Shape check, float64 row normalisation on the GPU, CSR float32 (reference cellmapper.py:99-137)."""
@@ -143,42 +154,58 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
             if yx.shape != expected:
                 raise ValueError(f"Mapping matrix shape mismatch: expected ({expected[0]}, {expected[1]}), "
                                  f"but got {yx.shape}.")
-            self._mapping_matrix = yx.normalized_mapping_matrix(kernel=method)
+            if getattr(yx, "_graph_dev", None) is not None:   # resident graph: K1-K3 on the device, nothing moves
+                yx._graph_dev.mapping(method)
+                self._mapping_graph, self._mapping_matrix = yx._graph_dev, None
+            else:
+                self._mapping_graph = None
+                self._mapping_matrix = yx.normalized_mapping_matrix(kernel=method)
         else:
             raise NotImplementedError(f"Method '{method}' is not implemented.")
 
     # ------------------------------------------------------------------ A1 / A2 / A3 -----------------
     def _require_mapping(self):
-        if self.mapping_matrix is None:
+        if not self._has_mapping():
             raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
-        m = self._mapping_matrix
+        m = self.mapping_matrix
         return m.indptr.astype(np.int64, copy=False), m.indices, m.data
+
+    def _backend(self):
+        """(label_vote, spmm_dense, spmm_csr) bound to the resident mapping matrix when there is one, else to host arrays."""
+        if not self._has_mapping():
+            raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
+        g = self._mapping_graph
+        if g is not None:
+            return g.label_vote, g.spmm_dense, g.spmm_csr
+        indptr, cols, vals = self._require_mapping()
+        h = _native.default_handle()
+        return (lambda codes, n_cat: h.label_vote(indptr, cols, vals, codes, n_cat),
+                lambda B: h.spmm_dense(indptr, cols, vals, B),
+                lambda bi, bc, bv, n_out: h.spmm_csr(indptr, cols, vals, bi, bc, bv, n_out))
 
     def map_obsm(self, key: str, prediction_postfix: str = "pred") -> None:
         """``query.obsm[f"{key}_{postfix}"] = M @ reference.obsm[key]`` (reference cellmapper.py:307-344)."""
-        indptr, cols, vals = self._require_mapping()
+        _, spmm_dense, _ = self._backend()
         logger.info("Mapping embeddings for key '%s'.", key)
         emb = np.asarray(self.reference.obsm[key])
         out_key = f"{key}_{prediction_postfix}"
-        self.query.obsm[out_key] = _native.default_handle().spmm_dense(indptr, cols, vals, emb)
+        self.query.obsm[out_key] = spmm_dense(emb)
         logger.info("Embeddings mapped and stored in query.obsm['%s'].", out_key)
 
     def map_layers(self, key: str) -> None:
         """``query_imputed = M @ (reference.X | reference.layers[key])`` (reference cellmapper.py:346-383)."""
-        indptr, cols, vals = self._require_mapping()
+        _, spmm_dense, spmm_csr = self._backend()
         logger.info("Mapping layer for key '%s'.", key)
         layer = self.reference.X if key == "X" else self.reference.layers[key]
-        h = _native.default_handle()
         if issparse(layer):
             B = csr_matrix(layer)
             if not B.has_canonical_format:
                 B = B.copy()
                 B.sum_duplicates()
-            oi, oc, ov = h.spmm_csr(indptr, cols, vals, B.indptr, B.indices, B.data.astype(np.float32, copy=False),
-                                    B.shape[1])
-            res = csr_matrix((ov, oc, oi), shape=(len(indptr) - 1, B.shape[1]))
+            oi, oc, ov = spmm_csr(B.indptr, B.indices, B.data.astype(np.float32, copy=False), B.shape[1])
+            res = csr_matrix((ov, oc, oi), shape=(len(oi) - 1, B.shape[1]))
         else:
-            res = h.spmm_dense(indptr, cols, vals, np.asarray(layer))
+            res = spmm_dense(np.asarray(layer))
         self.query_imputed = res
         msg = f"Expression for layer '{key}' mapped and stored in query_imputed.X."
         if not self._is_self_mapping:
@@ -244,7 +271,7 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
     def map_obs(self, key: str, prediction_postfix: str = "pred", confidence_postfix: str = "conf") -> None:
         """Transfer ``reference.obs[key]``: weighted vote for categorical data, weighted mean for numeric
         (reference cellmapper.py:534-637)."""
-        if self.mapping_matrix is None:
+        if not self._has_mapping():
             raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
         if key not in self.reference.obs.columns:
             raise KeyError(f"Key '{key}' not found in reference.obs")
@@ -261,21 +288,26 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
             self._map_obs_numerical(key, prediction_postfix)
 
     def _map_obs_categorical(self, key: str, prediction_postfix: str, confidence_postfix: str) -> None:
-        indptr, cols, vals = self._require_mapping()
+        label_vote, _, _ = self._backend()
         col = self.reference.obs[key]
         # sorted unique OBSERVED values: the category order sklearn's OneHotEncoder would produce
         if isinstance(col.dtype, pd.CategoricalDtype) and not col.isna().any():
             raw = col.cat.codes.to_numpy()
             cats = np.asarray(col.cat.categories)
-            present = np.unique(raw)
+            present = np.flatnonzero(np.bincount(raw, minlength=len(cats)))   # observed categories (no NaN here: codes >= 0)
             order = present[np.argsort(cats[present], kind="stable")]
-            remap = np.full(len(cats), -1, dtype=np.int64)
+            remap = np.full(len(cats), -1, dtype=np.int32)
             remap[order] = np.arange(len(order))
             codes, categories = remap[raw], cats[order]
+            cat_order = order
         else:
             categories, codes = np.unique(np.asarray(col), return_inverse=True)
-        code, conf = _native.default_handle().label_vote(indptr, cols, vals, codes.astype(np.int32), len(categories))
-        pred = pd.Series(data=categories[code], index=self.query.obs_names, dtype=col.dtype)
+            cat_order = None
+        code, conf = label_vote(codes.astype(np.int32), len(categories))
+        if cat_order is not None:   # categorical column: straight from codes (no factorisation of n_query strings)
+            pred = pd.Series(pd.Categorical.from_codes(cat_order[code], dtype=col.dtype), index=self.query.obs_names)
+        else:
+            pred = pd.Series(data=categories[code], index=self.query.obs_names, dtype=col.dtype)
         self.query.obs[f"{key}_{prediction_postfix}"] = pred
         self.query.obs[f"{key}_{confidence_postfix}"] = pd.Series(conf, index=self.query.obs_names)
         if f"{key}_colors" in self.reference.uns and isinstance(col.dtype, pd.CategoricalDtype):
@@ -283,11 +315,10 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
             self.query.uns[f"{key}_{prediction_postfix}_colors"] = [lookup.get(c, "#383838") for c in pred.cat.categories]
         logger.info("Categorical data mapped and stored in query.obs['%s'].", f"{key}_{prediction_postfix}")
         del codes, code, conf
-        gc.collect()
 
     def _map_obs_numerical(self, key: str, prediction_postfix: str) -> None:
-        indptr, cols, vals = self._require_mapping()
+        _, spmm_dense, _ = self._backend()
         values = np.array(self.reference.obs[key]).reshape(-1, 1)
-        mapped = _native.default_handle().spmm_dense(indptr, cols, vals, values)
+        mapped = spmm_dense(values)
         self.query.obs[f"{key}_{prediction_postfix}"] = pd.Series(data=mapped.ravel(), index=self.query.obs_names)
         logger.info("Numerical data mapped and stored in query.obs['%s'].", f"{key}_{prediction_postfix}")

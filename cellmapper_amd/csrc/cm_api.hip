@@ -13,13 +13,67 @@ std::mutex g_err_mu;
 std::string g_create_err;
 void a3_session_drop(cm_handle_t h);
 
-struct DevBuf {  // RAII device allocation used by the host tier
+// Device allocation pool of the host tier.  A released block is kept on the handle and handed to the next request it
+// fits (no more than twice the requested size); the pool is capped at a quarter of the device memory.
+void *pool_take(cm_handle_t h, size_t bytes, size_t *got) {
+    int best = -1;
+    for (int i = 0; i < (int)h->pool.size(); ++i)
+        if (h->pool[i].first >= bytes && h->pool[i].first <= 2 * bytes + 4096 && (best < 0 || h->pool[i].first < h->pool[best].first)) best = i;
+    if (best < 0) return nullptr;
+    void *p = h->pool[best].second;
+    *got = h->pool[best].first;
+    h->pool_bytes -= h->pool[best].first;
+    h->pool.erase(h->pool.begin() + best);
+    return p;
+}
+void pool_release(cm_handle_t h, void *p, size_t bytes) {
+    static size_t cap = 0;
+    if (!cap) {
+        size_t free_b = 0, total_b = 0;
+        cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? total_b / 4 : ((size_t)16 << 30);
+    }
+    if (!h || bytes > cap / 2) { (void)hipFree(p); return; }
+    h->pool.emplace_back(bytes, p);
+    h->pool_bytes += bytes;
+    while (h->pool_bytes > cap && !h->pool.empty()) {   // evict the oldest blocks
+        (void)hipFree(h->pool.front().second);
+        h->pool_bytes -= h->pool.front().first;
+        h->pool.erase(h->pool.begin());
+    }
+}
+void pool_drop(cm_handle_t h) {
+    for (auto &b : h->pool) (void)hipFree(b.second);
+    h->pool.clear();
+    h->pool_bytes = 0;
+}
+
+struct DevBuf {  // RAII device allocation used by the host tier (pooled per handle)
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    cm_handle_t owner = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) {
+            if (owner) pool_release(owner, p, cap); else (void)hipFree(p);
+            p = nullptr;
+        }
+    }
     cm_status alloc(cm_handle_t h, size_t bytes) {
+        release();
         if (bytes == 0) bytes = 16;
+        bytes = (bytes + 255) & ~size_t(255);
+        owner = h;
+        if ((p = pool_take(h, bytes, &cap)) != nullptr) return CM_OK;
         hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess && h && !h->pool.empty()) {   // give the pool back to the allocator and retry
+            pool_drop(h);
+            e = hipMalloc(&p, bytes);
+        }
         if (e != hipSuccess) { p = nullptr; CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
         return CM_OK;
     }
     template <typename T> T *as() { return reinterpret_cast<T *>(p); }
@@ -57,6 +111,10 @@ struct A3Session {
     const void *key[6] = {};
     int64_t nq = 0, n_ref = 0, n_out = 0;
     DevBuf dp, dc, dv, bp, bc, bv, op;
+    // the mapping matrix on the device: the session's own upload (dp / dc / dv) or a cm_graph's arrays
+    const int64_t *mp = nullptr;
+    const int32_t *mc = nullptr;
+    const float *mv = nullptr;
 };
 void a3_session_drop(cm_handle_t h) {
     if (h->a3_session) { delete static_cast<A3Session *>(h->a3_session); h->a3_session = nullptr; }
@@ -159,6 +217,7 @@ cm_status cm_destroy(cm_handle_t h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
     a3_session_drop(h);
+    pool_drop(h);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (int i = 0; i < 2; ++i) if (h->tile_ev[i]) (void)hipEventDestroy(h->tile_ev[i]);
     if (h->d_nflag_pinned) (void)hipHostFree(h->d_nflag_pinned);
@@ -464,16 +523,13 @@ cm_status cm_label_vote(cm_handle_t h, const int64_t *indptr, const int32_t *col
     return sync(h);
 }
 
-cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
-                        const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
-    if (!h) return CM_E_INVALID;
+static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                                   const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
     if (b_dtype != CM_F32 && b_dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm: payload has no columns");
-    CM_TRY(begin_call(h, 0));
     CM_TRY(tile_streams(h));
     const size_t es = b_dtype == CM_F64 ? 8 : 4;
-    DevBuf dp, dc, dv, dB, dO[2];
-    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));   // the mapping matrix goes up once
+    DevBuf dB, dO[2];
     // Streaming ("wide aggregation outputs"): the payload is cut into column slabs that fit HBM next
     // to two output tiles, the output into query tiles; tile i is copied to the caller's buffer on a second stream while
     // tile i+1 is computed.  Nothing of size nq x n_out is ever resident.
@@ -498,7 +554,7 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
             const int64_t nt = std::min<int64_t>(qt, nq - q0);
             const int b = it & 1;
             if (it >= 2) CM_HIP(h, hipStreamWaitEvent(h->stream, h->tile_ev[b], 0));   // the copy of tile it-2 has left this buffer
-            CM_TRY(cm_spmm_dense_run(h, dp.as<int64_t>() + q0, dc.as<int32_t>(), dv.as<float>(), nt, dB.p, w, b_dtype, dO[b].p));
+            CM_TRY(cm_spmm_dense_run(h, d_indptr + q0, d_cols, d_vals, nt, dB.p, w, b_dtype, dO[b].p));
             CM_HIP(h, hipEventRecord(h->tile_ev[b], h->stream));
             CM_HIP(h, hipStreamWaitEvent(h->copy_stream, h->tile_ev[b], 0));
             CM_HIP(h, hipMemcpy2DAsync((char *)out + es * ((size_t)q0 * n_out + c0), es * n_out, dO[b].p, es * w, es * w, (size_t)nt,
@@ -511,27 +567,43 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
     return CM_OK;
 }
 
-cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
-                          const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
-                          int64_t n_out, int64_t *out_indptr) {
+cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                        const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
     if (!h) return CM_E_INVALID;
-    if (nq < 0 || n_ref < 0 || !indptr || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    CM_TRY(begin_call(h, 0));
+    DevBuf dp, dc, dv;
+    CM_TRY(upload_csr(h, indptr, cols, vals, nq, dp, dc, dv));   // the mapping matrix goes up once
+    return spmm_dense_stream(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<float>(), nq, B, n_ref, n_out, b_dtype, out);
+}
+
+// shared by the host tier (mapping matrix in host arrays) and the graph tier (mapping matrix already on the device: d_m*)
+static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals,
+                                   const int64_t *d_mp, const int32_t *d_mc, const float *d_mv, int64_t nq,
+                                   const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                                   int64_t n_out, int64_t *out_indptr) {
+    if (nq < 0 || n_ref < 0 || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
     CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + 4096));
     a3_session_drop(h);
     A3Session *ss = new (std::nothrow) A3Session();
     if (!ss) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: out of host memory");
     h->a3_session = ss;
-    const void *key[6] = {indptr, cols, vals, b_indptr, b_cols, b_vals};
+    const void *key[6] = {d_mp ? (const void *)d_mp : (const void *)indptr, d_mp ? (const void *)d_mc : (const void *)cols,
+                          d_mp ? (const void *)d_mv : (const void *)vals, b_indptr, b_cols, b_vals};
     memcpy(ss->key, key, sizeof(key));
     ss->nq = nq; ss->n_ref = n_ref; ss->n_out = n_out;
     DevBuf rn;
-    cm_status rc = upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv);
+    cm_status rc = CM_OK;
+    if (d_mp) { ss->mp = d_mp; ss->mc = d_mc; ss->mv = d_mv; }
+    else {
+        rc = upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv);
+        ss->mp = ss->dp.as<int64_t>(); ss->mc = ss->dc.as<int32_t>(); ss->mv = ss->dv.as<float>();
+    }
     if (rc == CM_OK) rc = upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv);
     if (rc == CM_OK) rc = ss->op.alloc(h, 8 * ((size_t)nq + 1));
     if (rc == CM_OK) rc = rn.alloc(h, 4 * (size_t)nq);
     if (rc == CM_OK)
-        rc = cm_spmm_csr_count_run(h, ss->dp.as<int64_t>(), ss->dc.as<int32_t>(), ss->dv.as<float>(), nq, ss->bp.as<int64_t>(),
-                                   ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out, rn.as<int32_t>());
+        rc = cm_spmm_csr_count_run(h, ss->mp, ss->mc, ss->mv, nq, ss->bp.as<int64_t>(), ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out,
+                                   rn.as<int32_t>());
     if (rc == CM_OK) rc = cm_exclusive_scan_i32_to_i64(h, rn.as<int32_t>(), nq, ss->op.as<int64_t>());
     if (rc == CM_OK) rc = d2h(h, out_indptr, ss->op.p, 8 * ((size_t)nq + 1));
     if (rc == CM_OK) rc = sync(h);
@@ -539,21 +611,26 @@ cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *c
     return rc;
 }
 
-cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
-                      const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
-                      int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
-    if (!h) return CM_E_INVALID;
-    if (nq < 0 || n_ref < 0 || !indptr || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+static cm_status spmm_csr_fill_impl(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals,
+                                    const int64_t *d_mp, const int32_t *d_mc, const float *d_mv, int64_t nq,
+                                    const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                                    int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
+    if (nq < 0 || n_ref < 0 || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
     CM_TRY(begin_call(h, 4096));
     CM_TRY(tile_streams(h));
-    const void *key[6] = {indptr, cols, vals, b_indptr, b_cols, b_vals};
+    const void *key[6] = {d_mp ? (const void *)d_mp : (const void *)indptr, d_mp ? (const void *)d_mc : (const void *)cols,
+                          d_mp ? (const void *)d_mv : (const void *)vals, b_indptr, b_cols, b_vals};
     A3Session *ss = static_cast<A3Session *>(h->a3_session);
     A3Session local;
     if (!(ss && !memcmp(ss->key, key, sizeof(key)) && ss->nq == nq && ss->n_ref == n_ref && ss->n_out == n_out)) {
-        // no matching cm_spmm_csr_nnz call on this handle: upload here
+        // no matching count call on this handle: upload here
         a3_session_drop(h);
         ss = &local;
-        CM_TRY(upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv));
+        if (d_mp) { ss->mp = d_mp; ss->mc = d_mc; ss->mv = d_mv; }
+        else {
+            CM_TRY(upload_csr(h, indptr, cols, vals, nq, ss->dp, ss->dc, ss->dv));
+            ss->mp = ss->dp.as<int64_t>(); ss->mc = ss->dc.as<int32_t>(); ss->mv = ss->dv.as<float>();
+        }
         CM_TRY(upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv));
         CM_TRY(ss->op.alloc(h, 8 * ((size_t)nq + 1)));
         CM_TRY(h2d(h, ss->op.p, out_indptr, 8 * ((size_t)nq + 1)));
@@ -580,9 +657,8 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
         const int b = it & 1;
         if (it >= 2) rc = hipStreamWaitEvent(h->stream, h->tile_ev[b], 0) == hipSuccess ? CM_OK : CM_E_HIP;
         if (rc == CM_OK)
-            rc = cm_spmm_csr_fill_run(h, ss->dp.as<int64_t>() + q0, ss->dc.as<int32_t>(), ss->dv.as<float>(), q1 - q0, ss->bp.as<int64_t>(),
-                                      ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out, ss->op.as<int64_t>() + q0, base, oc[b].as<int32_t>(),
-                                      ov[b].as<float>());
+            rc = cm_spmm_csr_fill_run(h, ss->mp + q0, ss->mc, ss->mv, q1 - q0, ss->bp.as<int64_t>(), ss->bc.as<int32_t>(),
+                                      ss->bv.as<float>(), n_out, ss->op.as<int64_t>() + q0, base, oc[b].as<int32_t>(), ov[b].as<float>());
         if (rc == CM_OK && tn > 0) {
             CM_HIP(h, hipEventRecord(h->tile_ev[b], h->stream));
             CM_HIP(h, hipStreamWaitEvent(h->copy_stream, h->tile_ev[b], 0));
@@ -596,6 +672,222 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
     else { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
     a3_session_drop(h);
     return rc;
+}
+
+cm_status cm_spmm_csr_nnz(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                          const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                          int64_t n_out, int64_t *out_indptr) {
+    if (!h) return CM_E_INVALID;
+    if (!indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    return spmm_csr_nnz_impl(h, indptr, cols, vals, nullptr, nullptr, nullptr, nq, b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr);
+}
+
+cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t nq,
+                      const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
+                      int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
+    if (!h) return CM_E_INVALID;
+    if (!indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    return spmm_csr_fill_impl(h, indptr, cols, vals, nullptr, nullptr, nullptr, nq, b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr,
+                              out_cols, out_vals);
+}
+
+// ------------------------------------------------------------------ graph tier: device-resident staged flow ----
+// What the drop-in Python classes hold between compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm /
+// map_layers (one in-process flow upstream, cellmapper.py:465-484): the embeddings, the k-NN result and the mapping matrix
+// stay on the device; host arrays are produced only when the caller asks for them (the *_fetch calls).
+struct cm_rep_s {
+    DevBuf buf;
+    int64_t n = 0;
+    int32_t d = 0, dtype = 0;
+};
+struct cm_graph_s {
+    int64_t nq = 0, n_ref = 0;
+    int32_t k = 0, metric = 0, dist_is_f32 = 0;
+    DevBuf dist, idx;              // k-NN result as the reference returns it: float64 (float32: cosine on float32 input), int64
+    DevBuf indptr, cols, vals;     // row-normalised mapping matrix, canonical CSR on the device
+    bool has_map = false;
+    int64_t nnz = 0;
+};
+
+cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, cm_rep_t *out) {
+    if (!h) return CM_E_INVALID;
+    if (!out || !X || n < 1 || d < 1 || (dtype != CM_F32 && dtype != CM_F64)) CM_FAIL(h, CM_E_INVALID, "rep: bad arguments");
+    CM_TRY(begin_call(h, 0));
+    cm_rep_s *r = new (std::nothrow) cm_rep_s();
+    if (!r) CM_FAIL(h, CM_E_NOMEM, "rep: out of host memory");
+    r->n = n; r->d = d; r->dtype = dtype;
+    const size_t bytes = (size_t)n * d * (dtype == CM_F64 ? 8 : 4);
+    cm_status rc = r->buf.alloc(h, bytes);
+    if (rc == CM_OK) rc = h2d(h, r->buf.p, X, bytes);
+    if (rc == CM_OK) rc = sync(h);
+    if (rc != CM_OK) { delete r; return rc; }
+    *out = r;
+    return CM_OK;
+}
+
+cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r) {
+    if (!h) return CM_E_INVALID;
+    (void)hipSetDevice(h->device);
+    delete r;
+    return CM_OK;
+}
+
+cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int32_t metric, int32_t form, cm_graph_t *out) {
+    if (!h) return CM_E_INVALID;
+    if (!ref || !qry || !out) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
+    if (ref->d != qry->d || ref->dtype != qry->dtype) CM_FAIL(h, CM_E_INVALID, "graph: the two representations differ in width or dtype");
+    if (k < 1 || k > ref->n)
+        CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)ref->n);
+    cm_graph_s *g = new (std::nothrow) cm_graph_s();
+    if (!g) CM_FAIL(h, CM_E_NOMEM, "graph: out of host memory");
+    g->nq = qry->n; g->n_ref = ref->n; g->k = k; g->metric = metric;
+    g->dist_is_f32 = (metric == CM_METRIC_COSINE && ref->dtype == CM_F32) ? 1 : 0;
+    const size_t nk = (size_t)g->nq * k;
+    cm_status rc = g->dist.alloc(h, (g->dist_is_f32 ? 4 : 8) * nk);
+    if (rc == CM_OK) rc = g->idx.alloc(h, 8 * nk);
+    // queries in chunks of 2^21 rows like the host tier (bounds the workspace)
+    const int64_t QCH = 1 << 21;
+    const size_t es = ref->dtype == CM_F64 ? 8 : 4, des = g->dist_is_f32 ? 4 : 8;
+    int64_t nflag = 0;
+    for (int64_t q0 = 0; q0 < g->nq && rc == CM_OK; q0 += QCH) {
+        const int64_t nqc = std::min<int64_t>(QCH, g->nq - q0);
+        rc = begin_call(h, cm_knn_ws_bytes(ref->n, nqc, ref->d, k, ref->dtype));
+        if (rc == CM_OK)
+            rc = cm_knn_run(h, ref->buf.p, ref->n, (const char *)qry->buf.p + es * q0 * ref->d, nqc, ref->d, ref->dtype, k, metric, form, 0, 0,
+                            (char *)g->dist.p + des * q0 * k, g->idx.as<int64_t>() + q0 * k);
+        if (rc == CM_OK) rc = sync(h);
+        if (rc == CM_OK) rc = check_fallback_overflow(h);
+        nflag += h->knn_stats[0];
+    }
+    h->knn_stats[0] = nflag;
+    if (rc != CM_OK) { delete g; return rc; }
+    *out = g;
+    return CM_OK;
+}
+
+cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g) {
+    if (!h) return CM_E_INVALID;
+    (void)hipSetDevice(h->device);
+    if (g && h->a3_session && static_cast<A3Session *>(h->a3_session)->mp == g->indptr.as<int64_t>()) a3_session_drop(h);
+    delete g;
+    return CM_OK;
+}
+
+cm_status cm_graph_knn_fetch(cm_handle_t h, cm_graph_t g, void *out_dist, int64_t *out_idx) {
+    if (!h) return CM_E_INVALID;
+    if (!g || !out_dist || !out_idx) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
+    CM_TRY(begin_call(h, 0));
+    const size_t nk = (size_t)g->nq * g->k;
+    CM_TRY(d2h(h, out_dist, g->dist.p, (g->dist_is_f32 ? 4 : 8) * nk));
+    CM_TRY(d2h(h, out_idx, g->idx.p, 8 * nk));
+    return sync(h);
+}
+
+cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double epsilon, int64_t *out_nnz, double *out_param) {
+    if (!h) return CM_E_INVALID;
+    if (!g) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
+    if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
+    const size_t nk = (size_t)g->nq * g->k;
+    CM_TRY(begin_call(h, 64 * 1024 + cm_scan_ws_bytes(g->nq) + cm_align(8 * nk) + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)g->nq)));
+    g->has_map = false;
+    // float32 distances (cosine on float32 input) are widened on the device: the graph kernels read float64
+    const double *dd = g->dist.as<double>();
+    if (g->dist_is_f32) {
+        double *w = (double *)cm_ws_alloc(h, 8 * nk);
+        if (!w) CM_FAIL(h, CM_E_NOMEM, "graph: device workspace exhausted");
+        CM_TRY(cm_widen_f32_run(h, g->dist.as<float>(), (int64_t)nk, w));
+        dd = w;
+    }
+    int32_t *ecols = (int32_t *)cm_ws_alloc(h, 4 * nk);
+    float *evals = (float *)cm_ws_alloc(h, 4 * nk);
+    int32_t *cnt = (int32_t *)cm_ws_alloc(h, 4 * (size_t)g->nq);
+    double *m3 = (double *)cm_ws_alloc(h, 64);
+    if (!ecols || !evals || !cnt || !m3) CM_FAIL(h, CM_E_NOMEM, "graph: device workspace exhausted");
+    double *param = m3 + 5;
+    CM_HIP(h, hipMemsetAsync(m3, 0, 64, h->stream));
+    CM_TRY(cm_moments_run(h, dd, g->idx.as<int64_t>(), (int64_t)nk, nullptr, m3));
+    double hm[3] = {0, 0, 0};
+    CM_TRY(d2h(h, hm, m3, 24));
+    CM_TRY(sync(h));
+    if (!(hm[2] > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
+    CM_TRY(kernel_param_dev(h, dd, g->idx.as<int64_t>(), (int64_t)nk, kernel, m3, param));
+    CM_TRY(cm_weights_run(h, dd, g->idx.as<int64_t>(), g->nq, g->k, g->n_ref, kernel, param, epsilon, ecols, evals, cnt, nullptr));
+    CM_TRY(g->indptr.alloc(h, 8 * ((size_t)g->nq + 1)));
+    CM_TRY(g->cols.alloc(h, 4 * nk));
+    CM_TRY(g->vals.alloc(h, 4 * nk));
+    CM_TRY(cm_ell_to_csr_run(h, ecols, evals, nullptr, cnt, g->nq, g->k, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(),
+                             nullptr));
+    int64_t nnz = 0;
+    double hp = 0.0;
+    CM_TRY(d2h(h, &nnz, g->indptr.as<int64_t>() + g->nq, 8));
+    CM_TRY(d2h(h, &hp, param, 8));
+    CM_TRY(sync(h));
+    g->nnz = nnz;
+    g->has_map = true;
+    if (out_nnz) *out_nnz = nnz;
+    if (out_param) *out_param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? hp : 0.0;
+    return CM_OK;
+}
+
+#define CM_NEED_MAP(h, g)                                                                                         \
+    if (!g || !g->has_map) CM_FAIL(h, CM_E_INVALID, "graph: the mapping matrix has not been computed (cm_graph_mapping)")
+
+cm_status cm_graph_mapping_fetch(cm_handle_t h, cm_graph_t g, int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
+    if (!h) return CM_E_INVALID;
+    CM_NEED_MAP(h, g);
+    CM_TRY(begin_call(h, 0));
+    CM_TRY(d2h(h, out_indptr, g->indptr.p, 8 * ((size_t)g->nq + 1)));
+    CM_TRY(d2h(h, out_cols, g->cols.p, 4 * (size_t)g->nnz));
+    CM_TRY(d2h(h, out_vals, g->vals.p, 4 * (size_t)g->nnz));
+    return sync(h);
+}
+
+cm_status cm_graph_label_vote(cm_handle_t h, cm_graph_t g, const int32_t *codes, int64_t n_ref, int32_t n_cat, int32_t *out_code,
+                              float *out_conf) {
+    if (!h) return CM_E_INVALID;
+    CM_NEED_MAP(h, g);
+    if (n_ref != g->n_ref) CM_FAIL(h, CM_E_INVALID, "graph: %lld label codes for %lld reference cells", (long long)n_ref, (long long)g->n_ref);
+    CM_TRY(begin_call(h, 0));
+    DevBuf dcodes, ocode, oconf;
+    CM_TRY(dcodes.alloc(h, 4 * (size_t)n_ref)); CM_TRY(ocode.alloc(h, 4 * (size_t)g->nq)); CM_TRY(oconf.alloc(h, 4 * (size_t)g->nq));
+    CM_TRY(h2d(h, dcodes.p, codes, 4 * (size_t)n_ref));
+    CM_TRY(cm_vote_run(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, 0, nullptr, dcodes.as<int32_t>(), n_cat,
+                       ocode.as<int32_t>(), oconf.as<float>()));
+    CM_TRY(d2h(h, out_code, ocode.p, 4 * (size_t)g->nq));
+    CM_TRY(d2h(h, out_conf, oconf.p, 4 * (size_t)g->nq));
+    return sync(h);
+}
+
+cm_status cm_graph_spmm_dense(cm_handle_t h, cm_graph_t g, const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
+    if (!h) return CM_E_INVALID;
+    CM_NEED_MAP(h, g);
+    if (n_ref != g->n_ref) CM_FAIL(h, CM_E_INVALID, "graph: payload with %lld rows for %lld reference cells", (long long)n_ref, (long long)g->n_ref);
+    CM_TRY(begin_call(h, 0));
+    return spmm_dense_stream(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, B, n_ref, n_out, b_dtype, out);
+}
+
+cm_status cm_graph_spmm_csr_nnz(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
+                                int64_t n_ref, int64_t n_out, int64_t *out_indptr) {
+    if (!h) return CM_E_INVALID;
+    CM_NEED_MAP(h, g);
+    return spmm_csr_nnz_impl(h, nullptr, nullptr, nullptr, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq,
+                             b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr);
+}
+
+cm_status cm_graph_spmm_csr(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
+                            int64_t n_ref, int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
+    if (!h) return CM_E_INVALID;
+    CM_NEED_MAP(h, g);
+    return spmm_csr_fill_impl(h, nullptr, nullptr, nullptr, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq,
+                              b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr, out_cols, out_vals);
+}
+
+cm_status cm_graph_info(cm_handle_t h, cm_graph_t g, int64_t out[8]) {
+    if (!h) return CM_E_INVALID;
+    if (!g || !out) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
+    out[0] = g->nq; out[1] = g->n_ref; out[2] = g->k; out[3] = g->metric; out[4] = g->dist_is_f32; out[5] = g->has_map ? 1 : 0;
+    out[6] = g->nnz; out[7] = 0;
+    return CM_OK;
 }
 
 }  // extern "C"

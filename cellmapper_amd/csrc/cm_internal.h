@@ -28,6 +28,10 @@ struct cm_handle_s {
     // host tier of A3: device copies of the mapping matrix / payload / output indptr kept between cm_spmm_csr_nnz and the
     // matching cm_spmm_csr call (opaque: owned by cm_api.hip, freed by cm_destroy)
     void *a3_session = nullptr;
+    // device allocation pool of the host tier: blocks released by a call are reused by the next one instead of going
+    // through hipMalloc / hipFree every time (freed by cm_destroy; bounded, see pool_release in cm_api.hip)
+    std::vector<std::pair<size_t, void *>> pool;
+    size_t pool_bytes = 0;
     hipStream_t copy_stream = nullptr;   // D2H of finished output tiles while the next tile is computed (host tier)
     hipEvent_t tile_ev[2] = {nullptr, nullptr};
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
@@ -76,6 +80,7 @@ cm_status cm_knn_merge_run(cm_handle_t h, const double *d_dist, const int64_t *d
 cm_status cm_moments_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, const double *d_center,
                          double *d_out3);
 cm_status cm_param_run(cm_handle_t h, const double *d_m3, int32_t kernel, double *d_param);
+cm_status cm_widen_f32_run(cm_handle_t h, const float *d_in, int64_t n, double *d_out);   // float32 distances -> float64
 cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
                          int64_t n_ref, int32_t kernel, const double *d_param, double eps, int32_t *d_cols,
                          float *d_vals, int32_t *d_cnt, double *d_conn);

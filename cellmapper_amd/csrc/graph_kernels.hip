@@ -539,6 +539,18 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
 }  // namespace
 
 // ======================================================================= host-side launchers ==========
+namespace {
+__global__ void widen_f32(const float *__restrict__ in, int64_t n, double *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (double)in[i];
+}
+}  // namespace
+cm_status cm_widen_f32_run(cm_handle_t h, const float *d_in, int64_t n, double *d_out) {
+    if (n == 0) return CM_OK;
+    hipLaunchKernelGGL(widen_f32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, h->stream, d_in, n, d_out);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
 cm_status cm_moments_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, const double *d_center,
                          double *d_out3) {
     double *partial = (double *)cm_ws_alloc(h, sizeof(double) * 3 * RED_BLOCKS);

@@ -7,7 +7,6 @@ sklearn here, and there is no CPU fallback.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from functools import cached_property
 from typing import Literal
 
@@ -29,31 +28,60 @@ def _csr(indptr, cols, data, shape, dtype):
     return m
 
 
-@dataclass
 class NeighborsResults:
     """Nearest-neighbor results store (reference knn.py:14-66).
 
     ``distances`` / ``indices`` have shape ``(n_samples, n_neighbors)``; padded entries are ``inf`` / ``-1``.
     ``n_targets`` is the number of columns of the graph matrices (defaults to ``n_samples``).
+
+    Results of :meth:`Neighbors.compute_neighbors` are DEVICE-RESIDENT (``_graph``: a ``cm_graph`` of the C ABI): the two
+    arrays are copied to the host the first time ``distances`` / ``indices`` is read, so the staged flow
+    ``compute_neighbors -> compute_mapping_matrix -> map_*`` never moves them at all.
     """
 
-    distances: np.ndarray
-    indices: np.ndarray
-    n_targets: int | None = None
+    def __init__(self, distances: np.ndarray | None = None, indices: np.ndarray | None = None, n_targets: int | None = None,
+                 *, _graph=None):
+        self._graph_dev = _graph
+        self._distances, self._indices = distances, indices
+        if _graph is None:
+            if distances is None or indices is None:
+                raise TypeError("NeighborsResults needs `distances` and `indices`.")
+            if self._indices.shape != self._distances.shape:
+                raise ValueError("Indices and distances must have the same shape.")
+            self._shape2 = tuple(self._indices.shape)
+        else:
+            self._shape2 = (_graph.nq, _graph.k)
+        self.n_targets = self._shape2[0] if n_targets is None else n_targets
 
-    def __post_init__(self):
-        if self.indices.shape != self.distances.shape:
-            raise ValueError("Indices and distances must have the same shape.")
-        if self.n_targets is None:
-            self.n_targets = self.indices.shape[0]
+    def _materialize(self):
+        if self._distances is None or self._indices is None:
+            self._distances, self._indices = self._graph_dev.fetch_knn()
+
+    @property
+    def distances(self) -> np.ndarray:
+        self._materialize()
+        return self._distances
+
+    @property
+    def indices(self) -> np.ndarray:
+        self._materialize()
+        return self._indices
+
+    def __repr__(self):
+        where = "device" if (self._graph_dev is not None and self._distances is None) else "host"
+        return f"NeighborsResults(n_samples={self._shape2[0]}, n_neighbors={self._shape2[1]}, n_targets={self.n_targets}, data={where})"
+
+    def __eq__(self, other):
+        return (isinstance(other, NeighborsResults) and self.n_targets == other.n_targets
+                and np.array_equal(self.distances, other.distances) and np.array_equal(self.indices, other.indices))
 
     @property
     def n_samples(self) -> int:
-        return self.indices.shape[0]
+        return self._shape2[0]
 
     @property
     def n_neighbors(self) -> int:
-        return self.indices.shape[1]
+        return self._shape2[1]
 
     @property
     def shape(self) -> tuple[int, int]:
@@ -116,6 +144,10 @@ class NeighborsResults:
         """Kernel weights -> canonical CSR -> row-normalised float32 in ONE device pass (K1+K2+K3)."""
         if kernel == "random":
             return None
+        if self._graph_dev is not None:   # resident graph: nothing is uploaded
+            self._graph_dev.mapping(kernel, kwargs.get("epsilon", 1e-8))
+            indptr, cols, vals = self._graph_dev.fetch_mapping()
+            return _csr(indptr, cols, vals, self.shape, np.float32)
         h = _native.default_handle()
         indptr, cols, vals, _, _ = h.mapping_matrix(self.distances, self.indices, self.shape[1], kernel,
                                                    kwargs.get("epsilon", 1e-8))
@@ -166,13 +198,25 @@ class Neighbors:
         logger.info("Using %s to compute %d neighbors.", "hip" if method == "hip" else f"hip (requested: {method})",
                     n_neighbors)
         h = _native.default_handle()
+        if metric not in _native.METRICS:
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
         nx, ny = self.xrep.shape[0], self.yrep.shape[0]
-        self.yx = NeighborsResults(*h.knn(self.xrep, self.yrep, n_neighbors, metric), n_targets=nx)
-        if only_yx:
-            return
-        self.xx = NeighborsResults(*h.knn(self.xrep, self.xrep, n_neighbors, metric), n_targets=None)
-        self.yy = NeighborsResults(*h.knn(self.yrep, self.yrep, n_neighbors, metric), n_targets=None)
-        self.xy = NeighborsResults(*h.knn(self.yrep, self.xrep, n_neighbors, metric), n_targets=ny)
+        # both representations go to the device ONCE (same dtype rule as the host tier: float32 only if both are);
+        # the results stay there (NeighborsResults materialises numpy arrays on first access)
+        dt = np.float32 if (self.xrep.dtype == np.float32 and self.yrep.dtype == np.float32) else np.float64
+        xr = _native.DeviceRep(h, np.asarray(self.xrep).astype(dt, copy=False))
+        yr = xr if self.yrep is self.xrep else _native.DeviceRep(h, np.asarray(self.yrep).astype(dt, copy=False))
+        try:
+            self.yx = NeighborsResults(n_targets=nx, _graph=_native.DeviceGraph(h, xr, yr, n_neighbors, metric))
+            if only_yx:
+                return
+            self.xx = NeighborsResults(n_targets=None, _graph=_native.DeviceGraph(h, xr, xr, n_neighbors, metric))
+            self.yy = NeighborsResults(n_targets=None, _graph=_native.DeviceGraph(h, yr, yr, n_neighbors, metric))
+            self.xy = NeighborsResults(n_targets=ny, _graph=_native.DeviceGraph(h, yr, xr, n_neighbors, metric))
+        finally:
+            xr.close()
+            if yr is not xr:
+                yr.close()
 
     def get_adjacency_matrices(self):
         """Unweighted adjacency matrices ``(xx, yy, xy, yx)`` (reference knn.py:467-483)."""

@@ -206,6 +206,40 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
                           const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                           int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals);
 
+/* ---------------------------------------------------------------- graph tier: device-resident staged flow ----
+ * Upstream, compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm / map_layers is ONE in-process flow over
+ * objects that stay in memory (cellmapper.py:426-491; Neighbors / NeighborsResults knn.py:14-77,269-465).  These objects
+ * are its device-side counterpart: the representations, the k-NN result and the row-normalised mapping matrix stay in HBM
+ * between the staged calls of the drop-in classes; host arrays are produced only when the caller reads them
+ * (NeighborsResults.distances / .indices, CellMapper.mapping_matrix -> the *_fetch calls).  Host pointers in, host pointers
+ * out, synchronous, like the host tier; arithmetic and results are those of cm_knn / cm_mapping_matrix / cm_label_vote /
+ * cm_spmm_dense / cm_spmm_csr.
+ *   cm_rep_t   = an embedding matrix uploaded once (xrep / yrep of Neighbors; the four-graph mode searches each twice)
+ *   cm_graph_t = one k-NN graph (query rows x reference rows) and, after cm_graph_mapping, its mapping matrix */
+typedef struct cm_rep_s *cm_rep_t;
+typedef struct cm_graph_s *cm_graph_t;
+cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, cm_rep_t *out);
+cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r);
+/* K0 (knn.py:428-440): same arguments and errors as cm_knn */
+cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int32_t metric, int32_t form, cm_graph_t *out);
+cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g);
+/* out[0] = query rows, [1] = reference rows, [2] = k, [3] = metric, [4] = 1 if distances are float32 (cosine on float32
+ * input), [5] = 1 once the mapping matrix exists, [6] = its nnz, [7] = 0 */
+cm_status cm_graph_info(cm_handle_t h, cm_graph_t g, int64_t out[8]);
+/* distances float64 [nq,k] (float32 when info[4]), indices int64 [nq,k] */
+cm_status cm_graph_knn_fetch(cm_handle_t h, cm_graph_t g, void *out_dist, int64_t *out_idx);
+/* K1-K3 (knn.py:134-226,79-111; cellmapper.py:99-137) on the resident graph: same arithmetic as cm_mapping_matrix */
+cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double epsilon, int64_t *out_nnz, double *out_param);
+cm_status cm_graph_mapping_fetch(cm_handle_t h, cm_graph_t g, int64_t *out_indptr, int32_t *out_cols, float *out_vals);
+/* A0 / A0n / A1 / A2 / A3 with the resident mapping matrix (cellmapper.py:589-637, :338, :372-373) */
+cm_status cm_graph_label_vote(cm_handle_t h, cm_graph_t g, const int32_t *codes, int64_t n_ref, int32_t n_cat, int32_t *out_code,
+                              float *out_conf);
+cm_status cm_graph_spmm_dense(cm_handle_t h, cm_graph_t g, const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out);
+cm_status cm_graph_spmm_csr_nnz(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
+                                int64_t n_ref, int64_t n_out, int64_t *out_indptr);
+cm_status cm_graph_spmm_csr(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
+                            int64_t n_ref, int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals);
+
 /* ------------------------------------- shared-neighbour counts: jaccard / hnoca mapping methods ------
  * Replaces `(yx @ xx.T) + (yy @ xy.T)` on the 0/1 adjacency matrices of the four k-NN graphs and the following
  * transform (cellmapper.py:287-301; adjacencies: knn.py:228-266,467-483).  yx, yy: int64 [nq,k]; xx, xy: int64 [nr,k]

@@ -398,3 +398,58 @@ def test_evaluate_expression_transfer_side_effects():
     with pytest.raises(NotImplementedError):
         cm.evaluate_expression_transfer(method="kendall")
 
+
+
+def test_staged_flow_keeps_results_on_the_device(oracle):
+    """compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm / map_layers through the graph tier (cm_graph_*):
+    nothing is copied back until the caller reads it, and what is read equals the host-tier results and the oracle."""
+    import pandas as pd
+    import scipy.sparse as sp
+
+    from cellmapper_amd import CellMapper, MiniAnnData, _native
+
+    rng = np.random.default_rng(5)
+    n_ref, nq, d, k, G = 6000, 1500, 40, 20, 96
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    codes = rng.integers(0, 9, n_ref)
+    umap = rng.standard_normal((n_ref, 2)).astype(np.float32)
+    X = sp.random(n_ref, G, density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    Xd = rng.random((n_ref, G), dtype=np.float32)
+    reference = MiniAnnData(X=X, obs=pd.DataFrame({"label": pd.Categorical([f"c{c}" for c in codes]),
+                                                   "age": rng.random(n_ref)}),
+                            obsm={"X_emb": ref, "X_umap": umap}, layers={"dense": Xd})
+    query = MiniAnnData(X=np.zeros((nq, 3), np.float32), obsm={"X_emb": qry})
+    cm = CellMapper(query, reference)
+    cm.compute_neighbors(n_neighbors=k, use_rep="X_emb", only_yx=True)
+    yx = cm.knn.yx
+    assert yx._distances is None and yx.shape == (nq, n_ref) and yx.n_neighbors == k   # still on the device
+    cm.compute_mapping_matrix("gaussian")
+    cm.map_obs("label")
+    cm.map_obs("age")
+    cm.map_obsm("X_umap")
+    cm.map_layers("X")
+    sparse_imputed = cm.query_imputed.X
+    cm.map_layers("dense")
+    assert yx._distances is None and cm._mapping_matrix is None, "the staged flow must not have materialised host copies"
+    o = oracle.run_path(ref, qry, k, labels=np.unique([f"c{c}" for c in codes], return_inverse=True)[1].astype(np.int32), n_cat=9,
+                        numeric=np.asarray(reference.obs["age"]), obsm=umap, layer=Xd)
+    assert np.array_equal(yx.indices, o["idx"]) and np.array_equal(yx.distances, o["dist"])
+    m = cm.mapping_matrix
+    assert np.array_equal(m.indices, o["cols"]) and m.dtype == np.float32
+    np.testing.assert_allclose(m.data, o["vals"], rtol=1e-5)
+    h = _native.default_handle()
+    ip = m.indptr.astype(np.int64)
+    code, conf = h.label_vote(ip, m.indices, m.data, np.unique([f"c{c}" for c in codes], return_inverse=True)[1].astype(np.int32), 9)
+    np.testing.assert_array_equal(query.obs["label_conf"].to_numpy(), conf)           # graph tier == host tier, bit for bit
+    np.testing.assert_array_equal(query.obsm["X_umap_pred"], h.spmm_dense(ip, m.indices, m.data, umap))
+    np.testing.assert_array_equal(cm.query_imputed.X, h.spmm_dense(ip, m.indices, m.data, Xd))
+    np.testing.assert_array_equal(query.obs["age_pred"].to_numpy(), h.spmm_dense(ip, m.indices, m.data, np.asarray(reference.obs["age"])))
+    want = sp.csr_matrix(oracle.spmm_csr(ip, m.indices, m.data, X))
+    want.sort_indices()
+    assert np.array_equal(sparse_imputed.indices, want.indices) and np.array_equal(sparse_imputed.data, want.data)
+    # a caller-supplied mapping matrix replaces the resident one (host-tier path from then on)
+    cm.mapping_matrix = m
+    assert cm._mapping_graph is None
+    cm.map_obsm("X_umap")
+    np.testing.assert_array_equal(query.obsm["X_umap_pred"], h.spmm_dense(ip, m.indices, m.data, umap))
