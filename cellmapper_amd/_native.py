@@ -40,7 +40,7 @@ EXPORTS = [
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
     "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
     "cm_graph_mapping", "cm_graph_mapping_fetch", "cm_graph_label_vote", "cm_graph_spmm_dense", "cm_graph_spmm_csr_nnz",
-    "cm_graph_spmm_csr",
+    "cm_graph_spmm_csr", "cm_gram", "cm_project",
 ]
 
 
@@ -105,6 +105,8 @@ def load_library():
         lib.cm_graph_spmm_dense.argtypes = [vp, vp, vp, i64, i64, i32, vp]
         lib.cm_graph_spmm_csr_nnz.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp]
         lib.cm_graph_spmm_csr.argtypes = [vp, vp, vp, vp, vp, i64, i64, vp, vp, vp]
+        lib.cm_gram.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+        lib.cm_project.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]
         lib.cm_version.argtypes = []
         lib.cm_device_count.argtypes = []
         for name in EXPORTS:
@@ -291,6 +293,47 @@ class Handle:
         grp = None if group is None else np.ascontiguousarray(group, np.int32)
         out = np.empty((int(n_ref), int(n_groups) + 1), np.float64)
         self.call("cm_presence_scores", _ptr(dist), _ptr(idx), nq, k, int(n_ref), _ptr(grp), int(n_groups), _ptr(out))
+        return out
+
+    # ---- joint representations: float64 Gram matrix / projection of a cell x gene matrix
+    @staticmethod
+    def _tall(X):
+        """(dense, indptr, cols, vals, n, p, dtype_id) of a dense or scipy-sparse cell x gene matrix."""
+        import scipy.sparse as sp
+
+        if sp.issparse(X):
+            X = X.tocsr()
+            if not X.has_canonical_format:
+                X = X.copy()
+                X.sum_duplicates()
+            return (None, np.ascontiguousarray(X.indptr, np.int64), np.ascontiguousarray(X.indices, np.int32),
+                    np.ascontiguousarray(X.data, np.float32), X.shape[0], X.shape[1], CM_F32)
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        return X, None, None, None, X.shape[0], X.shape[1], CM_F64 if X.dtype == np.float64 else CM_F32
+
+    def gram(self, X, center_rows: bool = False):
+        """``A'^T A'`` [p, p] float64 (``A'`` = rows centred at their means if ``center_rows``)."""
+        D, ip, ic, iv, n, p, dt = self._tall(X)
+        out = np.empty((p, p), np.float64)
+        self.call("cm_gram", _ptr(D), _ptr(ip), _ptr(ic), _ptr(iv), n, p, dt, int(bool(center_rows)), _ptr(out))
+        return out
+
+    def project(self, X, P, center_rows: bool = False, col_shift=None):
+        """``A' P`` [n, nc] float64; ``A'`` = A, rows centred (``center_rows``) or shifted by ``col_shift`` [p]."""
+        D, ip, ic, iv, n, p, dt = self._tall(X)
+        P = np.ascontiguousarray(P, np.float64)
+        if P.ndim != 2 or P.shape[0] != p:
+            raise ValueError(f"Projection matrix must have shape ({p}, nc); got {P.shape}.")
+        mode = 1 if center_rows else (2 if col_shift is not None else 0)
+        sh = None if col_shift is None else np.ascontiguousarray(col_shift, np.float64)
+        out = np.empty((n, P.shape[1]), np.float64)
+        for c0 in range(0, P.shape[1], 64):   # the kernel projects onto at most 64 directions per pass
+            Pc = np.ascontiguousarray(P[:, c0:c0 + 64])
+            oc = np.empty((n, Pc.shape[1]), np.float64)
+            self.call("cm_project", _ptr(D), _ptr(ip), _ptr(ic), _ptr(iv), n, p, dt, mode, _ptr(sh), _ptr(Pc), Pc.shape[1], _ptr(oc))
+            out[:, c0:c0 + 64] = oc
         return out
 
     def label_vote(self, indptr, cols, vals, codes, n_cat: int):

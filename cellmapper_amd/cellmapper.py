@@ -4,7 +4,7 @@ Keeps the reference's user API (``cellmapper.py:20-637``): ``CellMapper(query, r
 ``compute_neighbors`` / ``compute_mapping_matrix`` / ``map_obs`` / ``map_obsm`` / ``map_layers``,
 ``mapping_matrix`` (scipy CSR float32, settable), ``query_imputed``, ``load_precomputed_distances``.
 All arithmetic (k-NN, graph kernel, normalisation, label vote, SpMM / SpGEMM) runs in the HIP backend.
-Out of scope here: the ``use_rep=None`` PCA / CCA fallbacks and the evaluation mixin.
+The ``use_rep=None`` fallbacks (fast CCA / joint PCA) live in ``embedding.py``; the label evaluation mixin is out of scope.
 """
 from __future__ import annotations
 
@@ -15,6 +15,7 @@ import pandas as pd
 from scipy.sparse import csr_matrix, issparse
 
 from . import _native
+from .embedding import EmbeddingMixin
 from .evaluate import ExpressionEvaluationMixin, PresenceMixin
 from .knn import Neighbors
 from .logging import logger
@@ -23,7 +24,7 @@ from .utils import create_imputed_anndata, get_n_comps
 _KERNEL_METHODS = ("gaussian", "scarches", "inverse_distance", "random", "equal")
 
 
-class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
+class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
     """Mapping of labels, embeddings, and expression values between reference and query datasets."""
 
     def __init__(self, query, reference=None) -> None:
@@ -104,14 +105,38 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin):
         """Nearest neighbors between reference and query in ``use_rep`` (reference cellmapper.py:139-251).
 
         ``use_rep="X"`` means ``.X`` (reserved, as upstream); otherwise ``.obsm[use_rep]``; the first
-        ``min(n_comps or 50, d)`` columns are used.  ``use_rep=None`` (automatic PCA / CCA representation) is
-        outside this backend's scope: compute a joint representation first and pass its key.
+        ``min(n_comps or 50, d)`` columns are used.  ``use_rep=None`` computes a joint representation first
+        (``fallback_representation``: fast CCA or joint PCA; plain PCA in self-mapping mode), see ``embedding.py``.
         """
+        if fallback_kwargs is None:
+            fallback_kwargs = {}
+        else:
+            fallback_kwargs = dict(fallback_kwargs)
         self.only_yx = only_yx
-        if use_rep is None:
-            raise NotImplementedError(
-                "use_rep=None (automatic joint PCA / fast-CCA representation) is not part of the MI355X backend. "
-                "Pre-compute a joint representation and pass its key via `use_rep`.")
+        if use_rep is None:   # joint representation computed on the fly (reference cellmapper.py:211-235)
+            if self._is_self_mapping:
+                logger.warning("No representation provided (`use_rep=None`) and self-mapping mode detected. Computing a "
+                               "joint representation automatically using PCA.")
+                key_added = fallback_kwargs.pop("key_added", "X_pca")
+                from .embedding import joint_pca_scores
+
+                X = self.query.X
+                self.query.obsm[key_added] = joint_pca_scores(X if issparse(X) else np.asarray(X),
+                                                              get_n_comps(n_comps, n_vars=X.shape[1]))
+            else:
+                logger.warning("No representation provided (`use_rep=None`). Computing a joint representation automatically "
+                               "using '%s'. For optimal results, consider pre-computing a representation and passing it to "
+                               "`use_rep`.", fallback_representation)
+                if fallback_representation == "fast_cca":
+                    key_added = fallback_kwargs.pop("key_added", "X_cca")
+                    self.compute_fast_cca(n_comps=n_comps, key_added=key_added, **fallback_kwargs)
+                elif fallback_representation == "joint_pca":
+                    key_added = fallback_kwargs.pop("key_added", "X_pca")
+                    self.compute_joint_pca(n_comps=n_comps, key_added=key_added, **fallback_kwargs)
+                else:
+                    raise ValueError(f"Unknown fallback_representation: {fallback_representation}. "
+                                     "Supported options are 'fast_cca' and 'joint_pca'.")
+            use_rep = key_added
         if use_rep == "X":
             xrep, yrep = self.reference.X, self.query.X
         else:

@@ -297,6 +297,21 @@ cm_status cm_expression_metrics(cm_handle_t h, const float *orig, const float *i
 cm_status cm_expression_metrics_dev(cm_handle_t h, const float *d_orig, const float *d_imputed, int64_t n, int64_t n_genes,
                                     const int32_t *d_group, int32_t n_groups, int32_t method, float *d_out);
 
+/* ------------------------------------------------- joint representations -----------
+ * The dense linear algebra behind `use_rep=None` (cellmapper.py:211-235): fast CCA = truncated SVD of the cross-covariance
+ * (X - rowmean)(Y - rowmean)^T / (G - 1) of query and reference expression (EmbeddingMixin.compute_fast_cca,
+ * embedding.py:50-185; truncated_svd_cross_covariance, utils.py:230-398) and joint PCA (embedding.py:14-48).  Two
+ * primitives over a tall cell x gene matrix A [n, p] -- dense row-major (dtype CM_F32 / CM_F64) or, with X = NULL,
+ * canonical CSR (int64 indptr, int32 cols, float32 vals) -- in float64 on the f64 matrix cores:
+ *   cm_gram    : out [p, p] = A'^T A'                 A' = A (center_rows = 0) or every row centred at its mean (1)
+ *   cm_project : out [n, nc] = A' P                   P [p, nc] float64, nc <= 64; center_mode 0 none, 1 row means,
+ *                                                      2 subtract col_shift [p] from every row (PCA's column means)
+ * The p x p eigen-problems and the small SVD that turn these into singular vectors are the host's (embedding.py). */
+cm_status cm_gram(cm_handle_t h, const void *X, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t n, int32_t p,
+                  int32_t dtype, int32_t center_rows, double *out);
+cm_status cm_project(cm_handle_t h, const void *X, const int64_t *indptr, const int32_t *cols, const float *vals, int64_t n, int32_t p,
+                     int32_t dtype, int32_t center_mode, const double *col_shift, const double *P, int32_t nc, double *out);
+
 /* ---------------------------------------------------------------- diagnostics -----------------------
  * n independent products D = A*B + C on one v_mfma_f32_32x32x16_f16 chain each (chain k-steps of 16): a fp16 bits
  * [n, chain, 32, 16] row-major, b fp16 bits [n, chain, 16, 32], c / d float32 [n, 32, 32].  Test aid: pins the

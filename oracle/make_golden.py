@@ -213,10 +213,41 @@ def expr_eval_case():
     return out
 
 
+def joint_embedding_case(utils_mod):
+    """The reference's own truncated_svd_cross_covariance (utils.py:230-398; ARPACK on the implicit operator) on a dense
+    float32 pair and on a CSR pair, and -- for joint PCA, which upstream delegates to scanpy (absent here) -- sklearn's
+    PCA(svd_solver="arpack"), the estimator scanpy.pp.pca runs by default, on the concatenated matrices."""
+    from sklearn.decomposition import PCA
+
+    rng = np.random.default_rng(2024)
+    nq, nr, G, nc = 300, 420, 96, 10
+    # low-rank structure + noise, non-negative like expression data
+    Z = rng.standard_normal((nq + nr, 12))
+    W = rng.standard_normal((12, G))
+    A = np.log1p(np.exp(Z @ W + 0.3 * rng.standard_normal((nq + nr, G)))).astype(np.float32)
+    Xq, Xr = A[:nq], A[nq:]
+    out = dict(Xq=Xq, Xr=Xr, n_comps=np.int64(nc), **VERSIONS)
+    U, s, Vt = utils_mod.truncated_svd_cross_covariance(Xq, Xr, n_comps=nc, zero_center=True, implicit=True, random_state=0)
+    out.update(dense_U=U, dense_s=s, dense_Vt=Vt)
+    U, s, Vt = utils_mod.truncated_svd_cross_covariance(Xq, Xr, n_comps=nc, zero_center=False, implicit=True, random_state=0)
+    out.update(nocenter_U=U, nocenter_s=s, nocenter_Vt=Vt)
+    S = A * (rng.random(A.shape) < 0.25)
+    Sq, Sr = sp.csr_matrix(S[:nq]), sp.csr_matrix(S[nq:])
+    U, s, Vt = utils_mod.truncated_svd_cross_covariance(Sq, Sr, n_comps=nc, zero_center=True, implicit=True, random_state=0)
+    out.update(**csr_parts("Sq", Sq), **csr_parts("Sr", Sr), sparse_U=U, sparse_s=s, sparse_Vt=Vt)
+    joint = np.concatenate([Xr, Xq], axis=0)   # reference first, as embedding.py:35 concatenates
+    out["pca_scores"] = PCA(n_components=nc, svd_solver="arpack", random_state=0).fit_transform(joint)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cm_mod, knn_mod, utils_mod = load_reference()
     saved = {}
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "joint_embedding":
+        np.savez_compressed(os.path.join(OUT, "joint_embedding.npz"), **joint_embedding_case(utils_mod))
+        print("joint_embedding.npz written")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "expr_eval":
         np.savez_compressed(os.path.join(OUT, "expr_eval.npz"), **expr_eval_case())
         print("expr_eval.npz written")
@@ -230,6 +261,8 @@ def main():
         path = os.path.join(OUT, f"{name}.npz")
         np.savez_compressed(path, **d)
         saved[name] = os.path.getsize(path)
+
+    save("joint_embedding", joint_embedding_case(utils_mod))
 
     # ---- 1. small_data fixture of the reference's tests (tests/conftest.py:23-28), k=3, full mode
     x = np.array([[0, 0], [1, 0], [0, 1], [1, 1], [2, 2]], dtype=np.float64)

@@ -453,3 +453,61 @@ def test_staged_flow_keeps_results_on_the_device(oracle):
     assert cm._mapping_graph is None
     cm.map_obsm("X_umap")
     np.testing.assert_array_equal(query.obsm["X_umap_pred"], h.spmm_dense(ip, m.indices, m.data, umap))
+
+
+def test_joint_representations_match_reference_and_oracle(oracle):
+    """fast CCA / joint PCA through cm_gram + cm_project (float64 matrix cores) against the
+    reference's own truncated_svd_cross_covariance outputs (golden) and the dense LAPACK oracle; then the `use_rep=None`
+    flow of CellMapper.map (cellmapper.py:211-235) end to end.  Tolerances: singular values 1e-7 relative, singular vectors
+    1e-6 up to their sign (the reference's ARPACK tolerance; the float32 inputs are centred in float64 here and in
+    float32 upstream), PCA scores 2e-5 of their range."""
+    import pandas as pd
+    import scipy.sparse as sp
+
+    from cellmapper_amd import CellMapper, MiniAnnData, _native
+    from cellmapper_amd.embedding import joint_pca_scores, truncated_svd_cross_covariance
+    from parity import load_golden
+
+    g = load_golden("joint_embedding")
+    nc = int(g["n_comps"])
+    h = _native.default_handle()
+    # primitives against numpy
+    Xq64 = g["Xq"].astype(np.float64)
+    rowc = Xq64 - Xq64.mean(axis=1)[:, None]
+    np.testing.assert_allclose(h.gram(g["Xq"], center_rows=True), rowc.T @ rowc, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(h.gram(g["Xq"]), Xq64.T @ Xq64, rtol=1e-12)
+    P = np.random.default_rng(0).standard_normal((g["Xq"].shape[1], 70))   # > 64 directions: two passes
+    np.testing.assert_allclose(h.project(g["Xq"], P, center_rows=True), rowc @ P, rtol=1e-11, atol=1e-10)
+    Sq = sp.csr_matrix((g["Sq_data"], g["Sq_indices"], g["Sq_indptr"]), shape=tuple(g["Sq_shape"]))
+    Sr = sp.csr_matrix((g["Sr_data"], g["Sr_indices"], g["Sr_indptr"]), shape=tuple(g["Sr_shape"]))
+    Sd = np.asarray(Sq.todense(), np.float64)
+    np.testing.assert_allclose(h.gram(Sq), Sd.T @ Sd, rtol=1e-12)
+    mu = Sd.mean(axis=0)
+    np.testing.assert_allclose(h.project(Sq, P[:, :5], col_shift=mu), (Sd - mu) @ P[:, :5], rtol=1e-11, atol=1e-10)
+    for tag, X, Y, zc in (("dense", g["Xq"], g["Xr"], True), ("nocenter", g["Xq"], g["Xr"], False), ("sparse", Sq, Sr, True)):
+        U, s, Vt = truncated_svd_cross_covariance(X, Y, n_comps=nc, zero_center=zc)
+        np.testing.assert_allclose(s, g[f"{tag}_s"], rtol=1e-7)
+        assert np.max(np.abs(np.abs(np.sum(U * g[f"{tag}_U"], axis=0)) - 1)) < 1e-6
+        assert np.max(np.abs(np.abs(np.sum(Vt * g[f"{tag}_Vt"], axis=1)) - 1)) < 1e-6
+        Uo, so, _ = oracle.cross_cov_svd(X, Y, nc, zero_center=zc)
+        np.testing.assert_allclose(s, so, rtol=1e-9)
+        assert oracle.subspace_error(U, Uo) < 1e-7
+    Z = joint_pca_scores(np.concatenate([g["Xr"], g["Xq"]]), nc)
+    np.testing.assert_allclose(Z, g["pca_scores"], atol=2e-5 * np.abs(Z).max())
+    np.testing.assert_allclose(Z, oracle.joint_pca(np.concatenate([g["Xr"], g["Xq"]]), nc), atol=1e-9 * np.abs(Z).max())
+    # the drop-in flow: use_rep=None -> fast CCA on shared genes -> neighbours -> label transfer
+    nq, nr = g["Xq"].shape[0], g["Xr"].shape[0]
+    genes_r = [f"g{i}" for i in range(g["Xr"].shape[1])]
+    genes_q = genes_r[::-1]                                              # same genes, different order: inner join by name
+    labels = pd.Categorical([f"t{i % 4}" for i in range(nr)])
+    reference = MiniAnnData(X=g["Xr"], obs=pd.DataFrame({"label": labels}), var=pd.DataFrame(index=genes_r))
+    query = MiniAnnData(X=np.ascontiguousarray(g["Xq"][:, ::-1]), var=pd.DataFrame(index=genes_q))
+    cm = CellMapper(query, reference).map(obs_keys="label", n_neighbors=8, only_yx=True)
+    assert query.obsm["X_cca"].shape == (nq, nc) or query.obsm["X_cca"].shape[1] == min(50, g["Xq"].shape[1])
+    assert reference.uns["X_cca_params"]["n_common_genes"] == g["Xq"].shape[1]
+    np.testing.assert_allclose(np.linalg.norm(query.obsm["X_cca"], axis=1), 1.0, rtol=1e-12)    # l2_scale
+    assert "label_pred" in query.obs and cm.knn.yx.n_neighbors == 8
+    cm2 = CellMapper(query, reference)
+    cm2.compute_joint_pca(n_comps=nc)
+    np.testing.assert_allclose(reference.obsm["X_pca"], g["pca_scores"][:nr], atol=2e-5 * np.abs(Z).max())
+    np.testing.assert_allclose(query.obsm["X_pca"], g["pca_scores"][nr:], atol=2e-5 * np.abs(Z).max())

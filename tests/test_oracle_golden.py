@@ -148,3 +148,22 @@ def test_oracle_expression_metrics_match_reference(oracle, method):
         r = oracle.expression_metrics(g["orig"], g["imputed"], method, g["labels"] == name)
         assert np.allclose(r, g[f"{method}_groups"][:, j], rtol=1e-5, atol=2e-6, equal_nan=True)
 
+
+
+def test_joint_embedding_oracle_matches_reference_golden(oracle):
+    """Fast CCA (utils.py:230-398, the reference's own ARPACK run) and joint PCA (sklearn's arpack PCA = scanpy.pp.pca's
+    default path) against the dense LAPACK restatement: singular values 1e-7, every singular vector up to its sign 1e-6."""
+    import scipy.sparse as sp
+
+    g = load_golden("joint_embedding")
+    nc = int(g["n_comps"])
+    Sq = sp.csr_matrix((g["Sq_data"], g["Sq_indices"], g["Sq_indptr"]), shape=tuple(g["Sq_shape"]))
+    Sr = sp.csr_matrix((g["Sr_data"], g["Sr_indices"], g["Sr_indptr"]), shape=tuple(g["Sr_shape"]))
+    for tag, X, Y, zc in (("dense", g["Xq"], g["Xr"], True), ("nocenter", g["Xq"], g["Xr"], False), ("sparse", Sq, Sr, True)):
+        U, s, Vt = oracle.cross_cov_svd(X, Y, nc, zero_center=zc)
+        np.testing.assert_allclose(s, g[f"{tag}_s"], rtol=1e-7)
+        assert np.max(np.abs(np.abs(np.sum(U * g[f"{tag}_U"], axis=0)) - 1)) < 1e-6
+        assert np.max(np.abs(np.abs(np.sum(Vt * g[f"{tag}_Vt"], axis=1)) - 1)) < 1e-6
+        assert oracle.subspace_error(U, g[f"{tag}_U"]) < 1e-5
+    P = oracle.joint_pca(np.concatenate([g["Xr"], g["Xq"]]), nc)
+    np.testing.assert_allclose(P, g["pca_scores"], atol=2e-5 * np.abs(P).max())
