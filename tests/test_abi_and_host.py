@@ -143,8 +143,8 @@ def test_cellmapper_prerequisite_errors():
     for fn, arg in ((cm.map_obsm, "X_emb"), (cm.map_layers, "X"), (cm.map_obs, "label")):
         with pytest.raises(ValueError, match="Mapping matrix has not been computed"):
             fn(arg)
-    with pytest.raises(NotImplementedError):
-        cm.compute_neighbors(use_rep=None)
+    with pytest.raises(ValueError, match="Unknown fallback_representation"):   # use_rep=None computes a joint representation
+        cm.compute_neighbors(use_rep=None, fallback_representation="nope")
     with pytest.raises(ValueError, match="only available in self-mapping"):
         cm.load_precomputed_distances()
     self_cm = CellMapper(qry)
