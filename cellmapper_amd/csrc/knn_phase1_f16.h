@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CM2_BT
 #define CM2_BT 2   // tiles per workgroup barrier in knn_cand_f16 (8-deep rings)
 #endif
+#ifndef CM2_SB8
+#define CM2_SB8 0   // K = 128 hi*hi kernel: 1 = single fragment set (see knn_cand_f16); measured 0.8 % slower, so off
+#endif
 #ifndef CM2_EXP
 #define CM2_EXP 0  // timing experiments only (scripts/ablate_skeleton.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
 #endif
@@ -682,9 +685,16 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
     }
         const int sched_lim = a.no_sched ? 8 : 0;   // logs shorter than this are left alone by a scheduled refresh
         int next_refresh = a.no_sched ? (a.no_sched == 2 ? t0 : 0x7fffffff) : t0 + 1;  // tile index at whose end every query's threshold is refreshed (doubling schedule)
-        half8 ah[KSTEPS], al[KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
+        // K = 128 (16-MFMA chains), CM2_SB8: ONE fragment set -- fragment s is last read by MFMA 2s+1 and reloaded right
+        // behind it for the next sub-tile, 14 MFMAs (~450 cycles) before its next use; saves the 32 VGPRs of the second set
+        // (scratch 44 -> 12 bytes per lane).  Measured at 1.5 M x 1.5 M x d=128 on one box, alternating: 520.3 ms with two
+        // sets, 524.0 ms with one -- the spilled values are not touched in the tile loop, so the default keeps two sets.
+        constexpr bool SB = !LO3 && KSTEPS >= 8 && CM2_SB8;
+        half8 ah[KSTEPS], al[SB ? 1 : KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) { ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0}; al[s] = ah[s]; }
+        for (int s = 0; s < KSTEPS; ++s) ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < (SB ? 1 : KSTEPS); ++s) al[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (t0 < t1) {   // first tile: nothing to overlap with
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both prologue tiles (simplest; once per work item)
             __builtin_amdgcn_s_barrier();
@@ -739,8 +749,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                     constexpr int NM1 = 2 * KSTEPS;            // MFMAs per split product
                     constexpr int NMT = NM1 * NP;              // MFMAs of the whole chain
                     constexpr int PER = (16 + (NMT < 16 ? NMT : 16) - 1) / (NMT < 16 ? NMT : 16);   // min-tree steps per gap
-                    half8(&cur)[KSTEPS] = (!LO3 && (st & 1)) ? al : ah;
-                    half8(&nxt)[KSTEPS] = (!LO3 && (st & 1)) ? ah : al;
+                    half8(&cur)[KSTEPS] = (!LO3 && !SB && (st & 1)) ? reinterpret_cast<half8(&)[KSTEPS]>(al) : ah;
+                    half8(&nxt)[KSTEPS] = (!LO3 && !SB && (st & 1)) ? ah : (SB ? ah : reinterpret_cast<half8(&)[KSTEPS]>(al));
                     wait_lds<0>(cur);
                     if constexpr (SIDE) {   // both accumulators start from the rows' sc^2|y|^2 (C operand of the first MFMAs)
                         asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));   // (ordered after the wait above)
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
                         const int pr = i / NM1, s = (i % NM1) >> 1, jq = i & 1;
-                        if (LO3 && i == 2 * NM1) wait_lds<0>(al);
+                        if constexpr (LO3) { if (i == 2 * NM1) wait_lds<0>(al); }
                         if (pr == 2) {
                             if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[1][s], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], qh[0][s], acc0, 0, 0, 0);
@@ -771,7 +781,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                                 if (i >= 2 * NM1 && i < 2 * NM1 + KSTEPS)
                                     CM2_DSR128X(ah[i - 2 * NM1], arow, 32 * (i - 2 * NM1), ntile, nst * 32 * ROWB);
                             } else {
-                                if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
+                                if (SB) { if (i & 1) CM2_DSR128X(ah[i >> 1], arow, 32 * (i >> 1), ntile, nst * 32 * ROWB); }
+                                else if (i < KSTEPS) CM2_DSR128X(nxt[i], arow, 32 * i, ntile, nst * 32 * ROWB);
                                 if (SIDE && i == KSTEPS) CM2_LOAD_SIDE(ntile, nst);   // (y0..y3 were consumed by MFMA 0 and 1)
                             }
                         }
