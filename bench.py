@@ -133,6 +133,9 @@ def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
     over the host cores) on a bounded sample: `n_sample` queries against the FULL reference; brute force is linear in the
     number of queries.  The one-off re-layout of the reference (float64 upcast into tiles) is set-up: measured, stated,
     and excluded from the rate -- at full size it is amortised over 1.5 M queries."""
+    # threads = the cores this process may actually use (cgroup CPU quota / affinity), not the host's core count: a GPU box
+    # gives a one-GPU job a share of its cores, and oversubscribing them only slows the scan down
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
     from oracle import oracle as orc
 
     orc.build()
@@ -145,6 +148,29 @@ def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
                 sample=f"{n_sample} queries x {ref_np.shape[0]} reference rows, d={ref_np.shape[1]}, k={k}, "
                        f"k-NN+kernel+label vote, {dt - setup:.2f} s of scan (+ {setup:.2f} s one-off reference re-layout, "
                        f"excluded)"), out
+
+
+def usable_cores() -> int:
+    """CPU cores available to this process: min(affinity mask, cgroup v2 / v1 CPU quota, os.cpu_count())."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:   # cgroup v2: "<quota|max> <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def host_inclusive_leg(a, ref_np, qry_np, codes_np):
