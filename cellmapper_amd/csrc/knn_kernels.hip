@@ -7,11 +7,13 @@
 #include "cm_internal.h"
 #include "knn_phase1.h"
 #include "knn_phase1_f16.h"
+#include "knn_phase1_q4.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
+cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 // grid_knn.hip: uniform-grid candidate search for d <= 3
@@ -1390,8 +1392,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // any tile image: <= 256 B per row (K <= 64) / 512 B per row + side block (K = 128)
     char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (wide ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
     char *Qp = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * (wide ? 512 : 256));
-    uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * Kc_max);
-    uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 64 * 2 * cmk2::CL);
+    // (x 128 queries per wave: the four-accumulator kernel; the two-accumulator kernels use half of it)
+    uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 128 * Kc_max);
+    uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 128 * 2 * cmk2::CL);
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * CMEAN_COLS);
     double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_COLS);
     if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
@@ -1536,6 +1539,18 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             const int kc2 = k + (k > 30 ? k : 30);
             if (kc2 <= Kc_max && kc2 + 2 * cmk2::CL <= 512) p2.Kc = kc2;   // (every candidate buffer is sized for Kc_max)
         }
+        // Four accumulators per wave (knn_phase1_q4.h) for large full-set scans of the hi*hi level at K = 64: 1 024-query
+        // blocks, so the padded query count is rounded up accordingly (every buffer carries that slack) and the 512-query
+        // kernels of the same stage (seed scan) see an even number of blocks.
+        // CELLMAP_Q4: 0 = never, 2 = whenever the kernel exists for the stage (tests), default = large sets only (a block is
+        // 1 024 queries: below two blocks per CU the 512-query kernel fills the chip better).
+        const int q4_env = getenv("CELLMAP_Q4") ? atoi(getenv("CELLMAP_Q4")) : 1;
+        const bool q4 = level == 1 && !cenl && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
+                        (q4_env == 2 || (p2.S == 1 && nsub >= (int64_t)2 * cmk2::QBQ * (h->n_cu > 0 ? h->n_cu : 256)));
+        if (q4) {
+            p2.nq_pad = (p2.nq_pad + cmk2::QBQ - 1) / cmk2::QBQ * cmk2::QBQ;
+            p2.nqb = (int)(p2.nq_pad / cmk2::QB);
+        }
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
         if (img != want) {
@@ -1599,6 +1614,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
             if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
             if (w3) return cm_p1f16w_launch(h, p2.grid, p2.lds, x);
+            if (q4 && !x.wlist && !x.seed_len) {
+                cmk2::P1Args y = x;
+                y.nqb = (int)(p2.nq_pad / cmk2::QBQ);
+                const int res = h->n_cu > 0 ? h->n_cu : 256;
+                const int64_t nw = (int64_t)y.nqb * y.S;
+                return cm_p1f16q_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
+            }
             return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);
         };
         // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
@@ -2015,13 +2037,13 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
         size_t tileb = (size_t)cmk2::tile_bytes(KSTEPS > 4 ? KSTEPS : 4) + 1024;   // any tile image of the staged search: <= 256 B per row
         b += cm_align((size_t)n_tiles * tileb + 65536) + cm_align((size_t)nq_pad * (KSTEPS > 4 ? cmk2::row_bytes(KSTEPS) : 256));
-        b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * Kc) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 64 * 2 * cmk2::CL);
+        b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * (Kc + 16)) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * 2 * cmk2::CL);
         // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
         b += cm_align((size_t)(n_ref / 16 + 512) * 136) + cm_align(4 * (size_t)(n_ref / 16 + 256)) +
-             cm_align(4 * (size_t)nq_pad) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds
+             cm_align(4 * (size_t)(nq_pad + 1024)) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
         b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
         if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)

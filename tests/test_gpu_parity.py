@@ -441,6 +441,32 @@ def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtyp
     assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
 
 
+@pytest.mark.parametrize("n_ref,nq,d,k,dtype", [
+    (140000, 9000, 50, 30, np.float32),     # seeded thresholds (>= 1 024 tiles), reference splits (few query blocks)
+    (20000, 5000, 61, 15, np.float64),      # refresh schedule from +inf thresholds, ragged last block
+    (150000, 3000, 20, 10, np.float32),     # K = 32 instantiation
+    (30000, 40000, 33, 50, np.float32),     # many blocks, wide lists (K' = 75)
+])
+def test_four_accumulator_filter_is_exact(hip, oracle, monkeypatch, n_ref, nq, d, k, dtype):
+    """knn_cand_f16q (128 queries per wave, accumulator-major chains, in-place filtering two accumulators behind the MFMAs;
+    the default for large full-set scans) forced on small problems: identical to the oracle and to the two-accumulator
+    kernel, bit for bit."""
+    rng = np.random.default_rng(n_ref + d)
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    monkeypatch.setenv("CELLMAP_Q4", "2")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["fallback_queries"] <= 64 and st["filter_products"] == 1, st
+    sel = rng.choice(nq, 600, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+    monkeypatch.setenv("CELLMAP_Q4", "0")
+    dist2, idx2 = hip.knn(ref, qry, k)
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+
+
 def test_bucket_pruning_large_k_on_the_last_level(hip, oracle, monkeypatch):
     """k = 100 on very tight float64 clusters: the direct-difference level is the main stage and prunes; with K' = 125 the
     re-rank can rank 8 lists per query, so the plan must not hand out more -- a query dropped for holding too many
