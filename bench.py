@@ -416,7 +416,9 @@ def main_rank(a):
             qry_np = qry.cpu().numpy()
             codes_np = codes.cpu().numpy()
         if (a.cpu_sample > 0 or a.check > 0) and a.metric == "euclidean":
-            ns = max(a.cpu_sample, a.check)
+            # bounded CPU leg: the sample shrinks with the cost of a query (n_ref x d) so that it stays ~5 s of scan
+            scale = min(1.0, (1_500_000 * 50) / float(a.nref * a.d))
+            ns = max(256, int(max(a.cpu_sample, a.check) * scale)) if max(a.cpu_sample, a.check) > 256 else max(a.cpu_sample, a.check)
             cb, o = cpu_baseline(ref_np, qry_np, codes_np, a.k, a.ncat, a.kernel, ns)
             if a.cpu_sample > 0:
                 result["cpu_baseline"] = cb

@@ -9,8 +9,8 @@ P = os.path.join(ROOT, "profiles")
 
 
 def one(name, pattern):
-    m = sorted(glob.glob(os.path.join(SRC, name, "**", pattern), recursive=True))
-    return m[0] if m else None
+    m = sorted(glob.glob(os.path.join(SRC, name, "**", pattern), recursive=True), key=os.path.getmtime)
+    return m[-1] if m else None   # (gpurun merges into gpurun_out/: files of an earlier collection may still be there)
 
 
 def short(name):
@@ -85,7 +85,8 @@ def mfma_block(f, tag, kernel, what):
         return
     t_ms = sum(kernel_ms(f"pmc_mfma_{tag}", kernel))
     gui = mf["GRBM_GUI_ACTIVE"] / 8.0
-    f.write(f"## {kernel} -- {what} ({n1} launches of the kernel in the pass, summed: warm-up step + timed step, each a seed scan + a main scan)\n\n")
+    f.write(f"## {kernel} -- {what} ({n1} launches of kernels of that family in the pass, summed: warm-up step + timed step, each a "
+            f"seed scan (`knn_cand_f16<.,1,false,4>`) + a main scan (`knn_cand_f16q` at K <= 64 / `knn_cand_f16<8,1>` at K = 128), plus the pilot)\n\n")
     f.write(f"Pass `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` (kernel time in the pass {t_ms:.1f} ms):\n\n")
     for k in sorted(mf):
         f.write(f"- {k} = {mf[k]:.6g}\n")
