@@ -121,8 +121,8 @@ def main():
         if t2:
             f.write(f"HBM-side traffic of the main scan (separate passes; largest dispatch): FETCH_SIZE = {t2[0]:.6g} KB, WRITE_SIZE = {t2[1]:.6g} KB.  With the "
                     f"gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at 64 B: x2) => **{t2[2] / 1e9:.0f} GB per launch**; algorithmic "
-                    "bytes are 0.8 GB (prepared rows once + candidate lists): the rest are re-reads of the 192 MB hi-only reference image by the 2 930 query "
-                    "blocks, mostly served by L2 / Infinity Cache (the counters sit on the fabric side of L2 and include Infinity-Cache hits).  The kernel is "
+                    "bytes are 0.8 GB (prepared rows once + candidate lists): the rest are re-reads of the 192 MB hi-only reference image by the 1 465 query "
+                    "blocks (1 024 queries each), mostly served by L2 / Infinity Cache (the counters sit on the fabric side of L2 and include Infinity-Cache hits).  The kernel is "
                     "not HBM-bound.\n\n")
             json.dump({"kernel": "cmk2::knn_cand_f16", "config": "1.5M x 1.5M, d=50, k=30 (main scan, one launch)", "FETCH_SIZE_KB": t2[0],
                        "WRITE_SIZE_KB": t2[1],
