@@ -150,6 +150,24 @@ def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
                        f"excluded)"), out
 
 
+def sklearn_baseline(ref_np, qry_np, k, n_sample):
+    """scikit-learn's own exact search (the third-party package the reference calls, knn.py:429-440) on the same sample, if
+    it is importable on this box: NearestNeighbors(algorithm as the reference leaves it: "auto" -> brute for d > 15)."""
+    try:
+        from sklearn.neighbors import NearestNeighbors
+        import sklearn
+    except Exception:
+        return None
+    q = qry_np[:n_sample]
+    nn = NearestNeighbors(n_neighbors=k, metric="euclidean").fit(ref_np)
+    t0 = time.perf_counter()
+    dist, idx = nn.kneighbors(q)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "query cells/s", "cores": usable_cores(), "kind": "sklearn",
+            "sample": f"sklearn {sklearn.__version__} NearestNeighbors.kneighbors, {n_sample} queries x {ref_np.shape[0]} reference rows, "
+                      f"d={ref_np.shape[1]}, k={k}, search only, {dt:.2f} s"}, idx
+
+
 def usable_cores() -> int:
     """CPU cores available to this process: min(affinity mask, cgroup v2 / v1 CPU quota, os.cpu_count())."""
     n = os.cpu_count() or 1
@@ -422,6 +440,11 @@ def main_rank(a):
             cb, o = cpu_baseline(ref_np, qry_np, codes_np, a.k, a.ncat, a.kernel, ns)
             if a.cpu_sample > 0:
                 result["cpu_baseline"] = cb
+                sk = sklearn_baseline(ref_np, qry_np, a.k, min(ns, 2048))
+                if sk is not None:
+                    result["cpu_baseline_sklearn"] = sk[0]
+                    # (not a parity gate: sklearn breaks exact ties by heap layout; on continuous synthetic data there are none)
+                    result["cpu_baseline_sklearn"]["indices_equal_oracle"] = bool(np.array_equal(sk[1], o["idx"][:sk[1].shape[0]]))
             if a.check > 0:
                 # an evenly strided sample of the whole query set would need the oracle on other rows; the first `ns`
                 # rows are as random as any (i.i.d. synthetic data).  The kernel bandwidth is a global statistic, so

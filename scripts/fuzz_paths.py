@@ -2,7 +2,7 @@
 """Randomised cross-check of the staged search's optional machinery (run on the GPU box): for random shapes around the
 size thresholds, metrics, dtypes and cluster structures, the default search (bucket pruning, seeded thresholds, hints)
 must return bit-identical neighbours and distances to the search with all of it switched off
-(CELLMAP_NO_IVF / CELLMAP_NO_SEED / CELLMAP_NO_HINT).  Prints one line per case; exits non-zero on the first mismatch."""
+(CELLMAP_NO_IVF / CELLMAP_NO_SEED / CELLMAP_NO_HINT / CELLMAP_Q4=0; even cases force the four-accumulator filter).  Prints one line per case; exits non-zero on the first mismatch."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -37,12 +37,14 @@ def main():
         ref, qry = mk(n_ref), mk(nq)
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ.pop(v, None)
+        os.environ["CELLMAP_Q4"] = "2" if case % 2 == 0 else "1"   # the four-accumulator filter wherever it exists / by its size rule
         t0 = time.perf_counter()
         d1, i1 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
         t1 = time.perf_counter()
         st1 = pipe.h.knn_stats()
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ[v] = "1"
+        os.environ["CELLMAP_Q4"] = "0"
         d2, i2 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
         t2 = time.perf_counter()
         st2 = pipe.h.knn_stats()
