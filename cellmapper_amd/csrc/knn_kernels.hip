@@ -1374,7 +1374,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const int Kc_max = pf.Kc + 16;   // (+16: the bucket-centred level uses k + max(30, k) candidates)
     const int64_t nq_pad = pf.nq_pad;
     // subsets may use more reference splits than the full set: rows of the candidate buffers
-    const int64_t cand_rows = std::max<int64_t>(nq_pad * pf.S, nq_pad + (int64_t)cmk2::QB * 512);
+    // (x up to 4 reference splits of the four-accumulator stage, see run_stage; bounded for very large query sets)
+    const int64_t cand_rows = std::max<int64_t>(std::max<int64_t>(nq_pad * pf.S, nq_pad + (int64_t)cmk2::QB * 512),
+                                                std::min<int64_t>(4 * (nq_pad + 1024), nq_pad + 1024 + 2000000));
     const int64_t pack_slack = (int64_t)LS_CMAX * cmk2::QB;   // bucket-aligned packing pads every bucket to whole blocks
     float *qnorm = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));
     float *qlo = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));   // |lo part| of every prepared query row
@@ -1545,11 +1547,35 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // CELLMAP_Q4: 0 = never, 2 = whenever the kernel exists for the stage (tests), default = large sets only (a block is
         // 1 024 queries: below two blocks per CU the 512-query kernel fills the chip better).
         const int q4_env = getenv("CELLMAP_Q4") ? atoi(getenv("CELLMAP_Q4")) : 1;
-        const bool q4 = level == 1 && !cenl && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
-                        (q4_env == 2 || (p2.S == 1 && nsub >= (int64_t)2 * cmk2::QBQ * (h->n_cu > 0 ? h->n_cu : 256)));
+        bool q4 = level == 1 && !cenl && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
+                  (q4_env == 2 || nsub >= 32768);
         if (q4) {
-            p2.nq_pad = (p2.nq_pad + cmk2::QBQ - 1) / cmk2::QBQ * cmk2::QBQ;
-            p2.nqb = (int)(p2.nq_pad / cmk2::QB);
+            // Work partitioning.  A stage is ceil(blocks x S / resident workgroups) rounds of work items, an item = one query
+            // block against 1/S of the reference.  An item's time does not fall like 1/S: about a quarter of a full scan is
+            // per-query candidate handling, and a split still appends ~K'(1 + ln(R0 / (S K'))) rows per query (R0 ~ 12 K':
+            // rank of the seed) -- measured: two half scans cost 1.15 x one full scan, four quarter scans 1.35 x.  Pick,
+            // between the 512-query kernel with the plan's split count and the 1 024-query kernel (13 % faster per pair,
+            // measured) with 1..8 splits, what this model says finishes first.  Forced mode (tests) keeps the plan's splits.
+            const int res = h->n_cu > 0 ? h->n_cu : 256;
+            const int64_t nb4 = (nsub + cmk2::QBQ - 1) / cmk2::QBQ;
+            auto item = [](int S) { return 0.75 / S + 0.25 * (1.0 + log(std::max(1.0, 12.0 / S))) / (1.0 + log(12.0)); };
+            auto rounds = [&](int64_t blocks, int S) { return (double)((blocks * S + res - 1) / res); };
+            int S4 = p2.S;
+            if (q4_env != 2) {
+                double best = 1e30;
+                for (int S = 1; S <= 8; ++S) {
+                    if (S > 1 && (S * p2.Kc > RR_NCMAX || p2.n_tiles / S < 256 || (nb4 * cmk2::QBQ) * S > cand_rows)) continue;
+                    const double r = rounds(nb4, S) * item(S);
+                    if (r < best - 1e-9) { best = r; S4 = S; }
+                }
+                if (best >= rounds(p2.nqb, p2.S) * 0.565 * item(p2.S)) q4 = false;
+            }
+            if (q4) {
+                p2.nq_pad = nb4 * cmk2::QBQ;
+                p2.nqb = (int)(p2.nq_pad / cmk2::QB);
+                p2.tps = (p2.n_tiles + S4 - 1) / S4;
+                p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps;
+            }
         }
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
@@ -2041,6 +2067,10 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
         b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
+        {   // candidate rows of a split four-accumulator stage (cand_rows in knn_run_staged)
+            const int64_t extra = std::min<int64_t>(3 * (nq_pad + 1024), 2000000 + 2048);
+            b += cm_align(sizeof(int) * (size_t)extra * (Kc + 16)) + cm_align(4 * (size_t)extra);
+        }
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
         b += cm_align((size_t)(n_ref / 16 + 512) * 136) + cm_align(4 * (size_t)(n_ref / 16 + 256)) +
              cm_align(4 * (size_t)(nq_pad + 1024)) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds

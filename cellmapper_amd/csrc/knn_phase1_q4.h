@@ -19,11 +19,15 @@
 namespace cmk2 {
 
 constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumulator kernel
+#ifndef CM2Q_PRIO
+#define CM2Q_PRIO 0   // wave priority while an append event is handled (s_setprio; 0 = leave it alone)
+#endif
 
 // One accumulator's event: the partial minima T0..T4 (registers 3g..3g+2) and the accumulator itself.
 #define CM2Q_EVENT(ACC, T0, T1, T2, T3, T4, J, RB)                                                             \
     {                                                                                                          \
         unsigned long long te0_ = 0;                                                                           \
+        if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(CM2Q_PRIO);   /* the event is on the path to the tile barrier */ \
         if (a.dbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                        \
         const float tj_ = thr[J];                                                                              \
         int cj_ = cnt[J];                                                                                      \
@@ -33,6 +37,7 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
         if (__ballot((ACC)[15] < tj_) != 0ull) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                          \
         cnt[J] = cj_;                                                                                          \
         if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                         \
+        if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(0);                                                          \
     }
 
 template <int KSTEPS>
