@@ -150,22 +150,47 @@ def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
                        f"excluded)"), out
 
 
+_SKLEARN_CHILD = r"""
+import json, sys, time
+import numpy as np
+d = np.load(sys.argv[1])
+ref, q, k = d["ref"], d["q"], int(d["k"])
+import sklearn
+from sklearn.neighbors import NearestNeighbors
+nn = NearestNeighbors(n_neighbors=k, metric="euclidean").fit(ref)
+t0 = time.perf_counter()
+dist, idx = nn.kneighbors(q)
+dt = time.perf_counter() - t0
+np.save(sys.argv[2], idx)
+print(json.dumps({"seconds": dt, "version": sklearn.__version__}))
+"""
+
+
 def sklearn_baseline(ref_np, qry_np, k, n_sample):
     """scikit-learn's own exact search (the third-party package the reference calls, knn.py:429-440) on the same sample, if
-    it is importable on this box: NearestNeighbors(algorithm as the reference leaves it: "auto" -> brute for d > 15)."""
+    it is importable on this box.  Runs in a CHILD process with a bounded thread count and a timeout: on many-core hosts
+    sklearn's OpenMP threads calling OpenBLAS can exhaust OpenBLAS's thread table and abort the interpreter -- that must not
+    take the benchmark down.  Returns (record, indices) or None."""
+    import tempfile
+
+    q = qry_np[:n_sample]
+    cores = min(usable_cores(), 64)
     try:
-        from sklearn.neighbors import NearestNeighbors
-        import sklearn
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            fin, fout = os.path.join(td, "in.npz"), os.path.join(td, "idx.npy")
+            np.savez(fin, ref=ref_np, q=q, k=np.int64(k))
+            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            r = subprocess.run([sys.executable, "-c", _SKLEARN_CHILD, fin, fout], env=env, capture_output=True, text=True, timeout=120)
+            if r.returncode != 0:
+                return None
+            info = json.loads(r.stdout.strip().splitlines()[-1])
+            idx = np.load(fout)
     except Exception:
         return None
-    q = qry_np[:n_sample]
-    nn = NearestNeighbors(n_neighbors=k, metric="euclidean").fit(ref_np)
-    t0 = time.perf_counter()
-    dist, idx = nn.kneighbors(q)
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "query cells/s", "cores": usable_cores(), "kind": "sklearn",
-            "sample": f"sklearn {sklearn.__version__} NearestNeighbors.kneighbors, {n_sample} queries x {ref_np.shape[0]} reference rows, "
-                      f"d={ref_np.shape[1]}, k={k}, search only, {dt:.2f} s"}, idx
+    dt = info["seconds"]
+    return {"value": n_sample / dt, "unit": "query cells/s", "cores": cores, "kind": "sklearn",
+            "sample": f"sklearn {info['version']} NearestNeighbors.kneighbors (child process, {cores} OpenMP threads), {n_sample} queries x "
+                      f"{ref_np.shape[0]} reference rows, d={ref_np.shape[1]}, k={k}, search only, {dt:.2f} s"}, idx
 
 
 def usable_cores() -> int:

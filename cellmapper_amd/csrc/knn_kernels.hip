@@ -163,6 +163,19 @@ __global__ void maxabs_rows(const T *__restrict__ X, int64_t n, int d, int metri
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(&gmax[4], __float_as_uint(m));
 }
+// Euclidean rows need no per-row scale: the same maximum over the flat array, coalesced (one element per thread and step)
+template <typename T>
+__global__ __launch_bounds__(256) void maxabs_flat(const T *__restrict__ X, int64_t total, int d, const double *__restrict__ mean,
+                                                    unsigned *__restrict__ gmax) {
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % d);
+        m = fmaxf(m, fabsf((float)((double)X[e] - (mean ? mean[c] : 0.0))));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&gmax[4], __float_as_uint(m));
+}
 // sc = 2^(top_exp - e) with maxabs = m * 2^e, m in [0.5, 1): scaled coordinates land in [2^(top_exp-1), 2^top_exp) at most
 // (top_exp = 12 for K <= 64, 11 for K = 128 so that sc^2 |y|^2 <= 2^30 still fits the first norm digit a1 = N * 2^-15)
 __global__ void f16_scale_kernel(const unsigned *__restrict__ gmax, float *__restrict__ scale3, int top_exp) {
@@ -188,7 +201,7 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
                               float *__restrict__ rownorm, unsigned *__restrict__ gmax, int yn_block, int hi_only,
                               const int *__restrict__ rowmap, float *__restrict__ rowlo,
                               const double *__restrict__ cen = nullptr, const int *__restrict__ blk_bucket = nullptr,
-                              float *__restrict__ rownorm_c = nullptr, float *__restrict__ rowcen = nullptr) {
+                              float *__restrict__ rownorm_c = nullptr, float *__restrict__ rowcen = nullptr, int stage_lds = 0) {
     // cen != nullptr (bucket-centred queries, knn_cand_f16<.,1,true>): the row is prepared as q' - cen[bucket of its
     // 512-query block]; rownorm stays |q'|, rownorm_c = |q' - c|, rowcen = |c|; rowmap entries < 0 are padding (zero row).
     // rowlo (queries): |lo part of the row| in input units -- the certificate of filter level 1 bounds the dropped
@@ -200,6 +213,26 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
     const int ROWB = (is_ref && hi_only) ? KSTEPS * 32 : cmk2::row_bytes(KSTEPS);
     const int TILEB = cmk2::BR * ROWB + (yn_block ? 1024 : 0);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Source rows staged through LDS (round 2): a thread per row reading its row straight from global memory touches 64
+    // cache lines per load instruction, twice (norm pass, conversion pass).  When the block's rows fit (the launcher passes
+    // `stage_lds` = bytes of dynamic LDS, else 0), each wave copies whole rows with coalesced loads first; the arithmetic
+    // below is unchanged.  Row stride d + 1 elements (odd for the usual even d: conflict-free thread-per-row reads).
+    extern __shared__ __align__(16) unsigned char prep_smem[];
+    T *sx = reinterpret_cast<T *>(prep_smem);
+    const bool staged = stage_lds > 0;
+    if (staged) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+        const int64_t b0 = (int64_t)blockIdx.x * blockDim.x;
+        for (int rr = wave; rr < (int)blockDim.x; rr += nwv) {
+            const int64_t ii = b0 + rr;
+            if (ii >= n_pad) break;
+            const bool lv = ii < n && !(rowmap && rowmap[ii] < 0);
+            if (!lv) continue;
+            const T *src = X + (rowmap ? (int64_t)rowmap[ii] : ii) * d;
+            for (int c = lane; c < d; c += 64) sx[(size_t)rr * (d + 1) + c] = src[c];
+        }
+        __syncthreads();
+    }
     float yn_f = 0.f, lo_ratio = 0.f;
     if (i < n_pad) {
         const float sc = scale3[0];
@@ -210,7 +243,8 @@ __global__ void prep_rows_f16(const T *__restrict__ X, int64_t n, int d, int KST
         double nscale = 1.0;
         // rowmap (queries only): prepare row i from source row rowmap[i] (query subsets of the staged search)
         const bool live = i < n && !(rowmap && rowmap[i] < 0);
-        const T *x = X + ((rowmap && live) ? (int64_t)rowmap[i] : (live ? i : 0)) * d;
+        const T *x = staged ? sx + (size_t)threadIdx.x * (d + 1)
+                            : X + ((rowmap && live) ? (int64_t)rowmap[i] : (live ? i : 0)) * d;
         const double *cj = (cen && blk_bucket) ? cen + (size_t)blk_bucket[i / cmk2::QB] * d : nullptr;
         double s2 = 0.0;  // squared norm of the centred (cosine: normalised, then centred) row
         double s2c = 0.0, c2 = 0.0;   // centred mode: |q' - c|^2, |c|^2
@@ -1357,6 +1391,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     hipStream_t st = h->stream;
     const int bs = 256;
     const int path = phase1_path(d, k);
+    // dynamic LDS of prep_rows_f16 when a block's source rows fit (64 KB without opting in): coalesced staging
+    const size_t prep_lds = (size_t)bs * (d + 1) * sizeof(T) <= 64 * 1024 ? (size_t)bs * (d + 1) * sizeof(T) : 0;
     const bool wide = path == 3;     // 62 <= d <= 128: K = 128 kernels, no direct level
     const bool lowp = path == 2;     // d <= 15 (or CELLMAP_PHASE1=direct): no MFMA levels, the direct kernel is the filter
     const int dl = lowd_dpad(d);     // row stride of the direct kernel
@@ -1411,8 +1447,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     hipLaunchKernelGGL(colmean_final, dim3(1), dim3(CMEAN_COLS), 0, st, cpart, n_ref, d, d_mean);
     // (the direct / grid filters work on the rows as given: their rounding bound needs max |coordinate| of the raw values)
     const double *mean_ma = lowp ? (const double *)nullptr : (const double *)d_mean;
-    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, mean_ma, words);
-    hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, mean_ma, words);
+    if (metric == CM_METRIC_EUCLIDEAN) {
+        hipLaunchKernelGGL(maxabs_flat<T>, dim3(2048), dim3(256), 0, st, d_ref, n_ref * (int64_t)d, d, mean_ma, words);
+        hipLaunchKernelGGL(maxabs_flat<T>, dim3(2048), dim3(256), 0, st, d_qry, nq * (int64_t)d, d, mean_ma, words);
+    } else {
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((n_ref + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d, metric, mean_ma, words);
+        hipLaunchKernelGGL(maxabs_rows<T>, dim3((unsigned)((nq + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nq, d, metric, mean_ma, words);
+    }
     hipLaunchKernelGGL(f16_scale_kernel, dim3(1), dim3(64), 0, st, words, scale3, 12);
     CM_HIP(h, hipGetLastError());
     // locality sort (see ls_assign): permutation of the reference rows for the tile images, of the queries for the order
@@ -1584,20 +1625,21 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
                                    nref_pad, 1, metric, reinterpret_cast<float *>(Rp), dl, (const int *)rperm);
             else
-                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_ref, d,
+                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((nref_pad + bs - 1) / bs)), dim3(bs), prep_lds, st, d_ref, n_ref, d,
                                    p2.KSTEPS, nref_pad, 1, metric, scale3, (const double *)d_mean, Rp, (float *)nullptr, words,
-                                   wide ? 1 : 0, want, (const int *)rperm, (float *)nullptr);
+                                   wide ? 1 : 0, want, (const int *)rperm, (float *)nullptr, (const double *)nullptr,
+                                   (const int *)nullptr, (float *)nullptr, (float *)nullptr, (int)prep_lds);
             img = want;
         }
         if (level == 4) {
             hipLaunchKernelGGL(prep_rows_lowd<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
                                p2.nq_pad, 0, metric, reinterpret_cast<float *>(Qp), dl, qmap);
         } else {
-            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), 0, st, d_qry, nsub, d,
+            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), prep_lds, st, d_qry, nsub, d,
                                p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qp, qnorm, (unsigned *)nullptr,
                                wide ? 1 : 0, 0, qmap, qlo, cenl ? (const double *)cen : (const double *)nullptr,
                                cenl ? (const int *)blk_bucket : (const int *)nullptr, cenl ? qnc : (float *)nullptr,
-                               cenl ? qcen : (float *)nullptr);
+                               cenl ? qcen : (float *)nullptr, (int)prep_lds);
             if (!w3) {   // (knn_cand_f16w keeps the plan of make_plan2: 2-deep ring of full tiles)
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
                 p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * (p2.tileb + (cenl ? 1024 : 0)) + 64;
@@ -1791,9 +1833,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                     if (!seed_img || !seed_map || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
                 }
                 hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, cmk2::BR, seed_map);
-                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), 0, st, d_ref, n_s, d,
+                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), prep_lds, st, d_ref, n_s, d,
                                    p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
-                                   (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr);
+                                   (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr, (const double *)nullptr,
+                                   (const int *)nullptr, (float *)nullptr, (float *)nullptr, (int)prep_lds);
                 cmk2::P1Args sa = a;
                 sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1;
                 sa.cand = nullptr; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
