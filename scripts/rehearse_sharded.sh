@@ -22,4 +22,7 @@ for n in 2 4; do
 done
 timeout -k 10 250 python bench.py --gpus 2 --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather --metric cosine \
     --nq 200000 --nref 300000 --cpu-sample 0 --check 0 --master-port 29537 >> $LOG 2>&1 || { echo "rehearsal cosine FAILED" >> $LOG; exit 1; }
+# config 4's shape (d=128, K = 128 kernel family, reference sharded over ALL ranks) at a reduced size, 4 shards
+timeout -k 10 250 python bench.py --gpus 4 --config 4 --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather \
+    --nq 120000 --nref 600000 --cpu-sample 0 --check 0 --master-port 29538 >> $LOG 2>&1 || { echo "rehearsal config 4 FAILED" >> $LOG; exit 1; }
 grep -E "rehearsal|n_gpus" $LOG | cut -c1-220
