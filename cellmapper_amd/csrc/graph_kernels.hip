@@ -814,6 +814,68 @@ __global__ __launch_bounds__(256) void ingest_fill(const int64_t *__restrict__ i
     }
     for (int s = m + lane; s < kmax; s += 64) { oi[s] = -1; od[s] = INFINITY; }
 }
+// Rows with 1 024 or more stored neighbours (no limit upstream, utils.py:129-219): one WORKGROUP per row, the row in
+// dynamic LDS (up to IG_LONG_MAX entries), wave 0 gathers (stable compaction as above), all 256 threads rank.
+constexpr int IG_LONG_MAX = 12288;
+__global__ __launch_bounds__(256) void ingest_fill_long(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                        const double *__restrict__ data, int64_t n, int include_self, int kmax,
+                                                        int cap, int64_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+    extern __shared__ __align__(16) unsigned char ig_smem[];
+    double *s_d = reinterpret_cast<double *>(ig_smem);
+    int *s_c = reinterpret_cast<int *>(s_d + cap);
+    __shared__ int s_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t lo = indptr[i], hi = indptr[i + 1];
+        if (tid < 64) {
+            int m = 0;
+            for (int64_t base = lo; base < hi; base += 64) {
+                const int64_t p = base + lane;
+                const bool in = p < hi;
+                const int c = in ? indices[p] : 0;
+                const bool keep = in && !(include_self == 0 && c == (int32_t)i);
+                const unsigned long long b = __ballot(keep);
+                if (keep) {
+                    const int pos = m + __popcll(b & ((1ull << lane) - 1ull));
+                    s_d[pos] = data[p];
+                    s_c[pos] = c;
+                }
+                m += __popcll(b);
+            }
+            if (include_self == 1) {
+                bool has = false;
+                for (int s_ = lane; s_ < m; s_ += 64) has = has || s_c[s_] == (int32_t)i;
+                if (__ballot(has) == 0ull) {
+                    if (lane == 0) { s_d[m] = 0.0; s_c[m] = (int)i; }
+                    ++m;
+                }
+            }
+            if (lane == 0) s_m = m;
+        }
+        __syncthreads();
+        const int m = s_m;
+        bool bad = false;
+        for (int s_ = tid; s_ + 1 < m; s_ += 256) bad = bad || !(s_d[s_ + 1] - s_d[s_] >= 0.0);
+        const bool sorted = __syncthreads_or(bad ? 1 : 0) == 0;
+        int64_t *oi = out_idx + i * (int64_t)kmax;
+        double *od = out_dist + i * (int64_t)kmax;
+        for (int s_ = tid; s_ < m; s_ += 256) {
+            const double v = s_d[s_];
+            int rk = s_;
+            if (!sorted) {
+                rk = 0;
+                for (int j = 0; j < m; ++j) {
+                    const double u = s_d[j];
+                    rk += (u < v || (u == v && j < s_)) ? 1 : 0;
+                }
+            }
+            oi[rk] = s_c[s_];
+            od[rk] = v;
+        }
+        for (int s_ = m + tid; s_ < kmax; s_ += 256) { oi[s_] = -1; od[s_] = INFINITY; }
+        __syncthreads();
+    }
+}
 }  // namespace
 
 cm_status cm_ingest_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, int64_t n, int include_self,
@@ -826,10 +888,19 @@ cm_status cm_ingest_count_run(cm_handle_t h, const int64_t *d_indptr, const int3
 
 cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
                              int include_self, int kmax, int64_t *d_out_idx, double *d_out_dist) {
-    if (kmax + 1 > IG_MAX) CM_FAIL(h, CM_E_UNSUPPORTED, "precomputed distances: a row has %d entries (maximum %d)", kmax, IG_MAX - 1);
-    if (n > 0 && kmax > 0)
+    if (kmax + 1 > IG_LONG_MAX)
+        CM_FAIL(h, CM_E_UNSUPPORTED, "precomputed distances: a row has %d entries (maximum %d)", kmax, IG_LONG_MAX - 1);
+    if (n > 0 && kmax > 0 && kmax + 1 <= IG_MAX)
         hipLaunchKernelGGL(ingest_fill, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_indices, d_data, n,
                            include_self, kmax, d_out_idx, d_out_dist);
+    else if (n > 0 && kmax > 0) {   // long rows: one workgroup per row, the row in dynamic LDS
+        const int cap = kmax + 1;
+        const size_t lds = (size_t)cap * 12 + 16;
+        auto kern = ingest_fill_long;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(n, 4096)), dim3(256), lds, h->stream, d_indptr, d_indices, d_data, n,
+                           include_self, kmax, cap, d_out_idx, d_out_dist);
+    }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }

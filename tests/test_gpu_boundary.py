@@ -317,7 +317,7 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
     rng = np.random.default_rng(41)
     n = 3000
     lens = rng.integers(0, 40, n)
-    lens[7] = 900                                   # a long row (limit: 1023 entries)
+    lens[7] = 900                                   # a long row for the wave-per-row kernel (up to 1 023 entries)
     lens[11] = 0
     rows = np.repeat(np.arange(n), lens)
     cols = np.concatenate([rng.choice(n, l, replace=False) for l in lens]) if lens.sum() else np.zeros(0, int)
@@ -336,7 +336,23 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
         assert np.array_equal(gi, oi) and np.array_equal(gd, od), inc
     gi, gd = extract_neighbors_from_distances(sp.csr_matrix((4, 4)))
     assert gi.shape == (4, 0) and gd.shape == (4, 0)
-    big = sp.csr_matrix((np.ones(1500), (np.zeros(1500, int), np.arange(1500))), shape=(1500, 1500))
+    # rows with 1 024+ stored neighbours: one workgroup per row (no limit upstream; here up to 12 287 entries)
+    n2 = 5000
+    lens2 = rng.integers(0, 30, n2)
+    lens2[3], lens2[4], lens2[77] = 1500, 4200, 1024
+    rows2 = np.repeat(np.arange(n2), lens2)
+    cols2 = np.concatenate([rng.choice(n2, l, replace=False) for l in lens2])
+    m2 = sp.csr_matrix((np.round(rng.random(len(rows2)) * 64) / 8, (rows2, cols2)), shape=(n2, n2))
+    m2.sort_indices()
+    lo, hi = m2.indptr[4], m2.indptr[5]           # one of the long rows stored sorted by distance
+    o = np.argsort(m2.data[lo:hi], kind="stable")
+    m2.data[lo:hi], m2.indices[lo:hi] = m2.data[lo:hi][o], m2.indices[lo:hi][o]
+    m2.has_sorted_indices = False
+    for inc in (None, True, False):
+        gi, gd = extract_neighbors_from_distances(m2, include_self=inc)
+        oi, od = oracle.extract_neighbors_from_distances(m2, include_self=inc)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), inc
+    big = sp.csr_matrix((np.ones(13000), (np.zeros(13000, int), np.arange(13000))), shape=(13000, 13000))
     with pytest.raises(NotImplementedError):
         extract_neighbors_from_distances(big)
 
