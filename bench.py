@@ -338,7 +338,7 @@ def main_rank(a):
     def check_overflow():
         ov = pipe.h.knn_stats().get("fallback_overflow", 0)
         if ov:
-            print(f"[bench] rank {rank}: exact-fallback overflow (more than 2048 rows within a query's bound): results "
+            print(f"[bench] rank {rank}: exact-fallback overflow (more than 4096 rows within a query's bound): results "
                   f"would be truncated", file=sys.stderr, flush=True)
             sys.exit(5)
 

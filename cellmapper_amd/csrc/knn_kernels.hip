@@ -40,7 +40,7 @@ constexpr int kSupportedKP[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 5
 constexpr int RR_NCMAX = 1024;  // max candidates per query handled by the re-rank / merge kernels
 constexpr int RR_DMAX = 260;
 constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
-constexpr int FB_CAP = 2048;    // fallback collection capacity per query
+constexpr int FB_CAP = 4096;    // fallback collection capacity per query
 constexpr int FB_BLOCKS = 1024;
 constexpr int FBS_SLICES = 512;  // sliced fallback: reference slices scanned in parallel per flagged query ...
 constexpr int FBS_NQ = 1024;     // ... for the first FBS_NQ flagged queries (the rest: one workgroup per query)

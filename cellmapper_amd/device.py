@@ -37,7 +37,7 @@ class DevicePipeline:
         exact-fallback list overflowed has a truncated neighbour list (cm_knn_stats out[4])."""
         self.torch.cuda.synchronize(self.device)
         if self.h.knn_stats()["fallback_overflow"]:
-            raise NotImplementedError("k-NN exact fallback overflow: more than 2048 reference rows tie within a query's "
+            raise NotImplementedError("k-NN exact fallback overflow: more than 4096 reference rows tie within a query's "
                                       "k-th distance")
 
     def _dtype_id(self, t):

@@ -197,6 +197,28 @@ def test_knn_forced_fallback_and_duplicates(hip, oracle):
     assert hip.knn_stats()["fallback_queries"] >= 1
 
 
+def test_mass_duplicates_within_the_kth_distance(hip, oracle):
+    """3 000 identical reference rows: every query that sits on them has 3 000 rows tied at its k-th distance -- beyond every
+    candidate list, so the exact fallback collects them all (capacity 4 096 per query) and the lowest indices win, like the
+    oracle's (value, index) order.  5 000 of them overflow the collection: an error, never a truncated answer."""
+    rng = np.random.default_rng(99)
+    d, k = 24, 10
+    ref = rng.standard_normal((20000, d)).astype(np.float32)
+    dup = rng.choice(20000, 3000, replace=False)
+    ref[dup] = ref[dup[0]]
+    qry = rng.standard_normal((300, d)).astype(np.float32)
+    qry[:5] = ref[dup[0]]
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert np.array_equal(idx[0], np.sort(dup)[:k]) and np.all(dist[:5] == 0)
+    dup2 = rng.choice(20000, 5000, replace=False)
+    ref[dup2] = ref[dup2[0]]
+    qry[:5] = ref[dup2[0]]
+    with pytest.raises(NotImplementedError, match="overflow"):
+        hip.knn(ref, qry, k)
+
+
 def test_exact_fallback_sliced_and_per_query_paths(oracle):
     """CM_KNN_FORCE_FALLBACK sends every query through the fp64 exact scan: the first 1024 flagged queries take the
     sliced scan + rank kernels, the rest one workgroup per query -- both must reproduce the oracle bit for bit."""
