@@ -335,23 +335,32 @@ cm_status cm_spmm_dense_dev(cm_handle_t h, const int64_t *d_indptr, const int32_
     return cm_spmm_dense_run(h, d_indptr, d_cols, d_vals, nq, d_B, n_out, b_dtype, d_out);
 }
 
+cm_status cm_locality_order_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, int64_t nq, int64_t n_ref,
+                                int32_t *d_order) {
+    CM_TRY(begin_call(h, cm_locality_order_ws_bytes(n_ref)));
+    if (nq < 0 || n_ref < 1 || !d_indptr || !d_order) CM_FAIL(h, CM_E_INVALID, "locality order: bad arguments");
+    if (nq > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "locality order: more than 2^31 rows");
+    return cm_locality_order_run(h, d_indptr, d_cols, nq, n_ref, d_order);
+}
+
 cm_status cm_spmm_csr_nnz_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                               const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
-                              int64_t n_out, int64_t *d_out_indptr) {
+                              int64_t n_out, int64_t *d_out_indptr, const int32_t *d_row_order) {
     CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + cm_align(4 * (size_t)std::max<int64_t>(nq, 1)) + 4096));
     if (nq < 0 || !d_out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
     int32_t *rn = (int32_t *)cm_ws_alloc(h, 4 * (size_t)std::max<int64_t>(nq, 1));
     if (!rn) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: device workspace exhausted");
-    CM_TRY(cm_spmm_csr_count_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, rn));
+    CM_TRY(cm_spmm_csr_count_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, rn, d_row_order));
     return cm_exclusive_scan_i32_to_i64(h, rn, nq, d_out_indptr);
 }
 
 cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                           const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
-                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals) {
+                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
+                          const int32_t *d_row_order) {
     CM_TRY(begin_call(h, 0));
     return cm_spmm_csr_fill_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, d_out_indptr, 0, d_out_cols,
-                                d_out_vals);
+                                d_out_vals, d_row_order);
 }
 
 cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,

@@ -383,6 +383,14 @@ __global__ __launch_bounds__(256) void spmm_narrow(const int64_t *__restrict__ i
 // added -- the barrier per neighbour no longer exposes the load latency.  The per-neighbour metadata
 // (weight, payload row bounds) sits in LDS; the next row's is prefetched into registers.  Exact zeros are dropped like
 // csr_matmat does.   MODE 0: count non-zeros per row.  MODE 1: emit (column, value) pairs in ascending column order.
+// acc[c] += x.  Measured alternative: one ds_add_f32 per entry (same bits: an IEEE single add inside the LDS unit) instead of
+// load / v_add / store -- 2.5 x SLOWER on gfx950 (437 -> 1 097 ms at 1 M cells of config 5: LDS float atomics serialise),
+// so the three-instruction form stays; -DCM_SPG_LDS_ATOMIC builds the other one.
+#ifdef CM_SPG_LDS_ATOMIC
+#define SPG_ADD(P, X) ((void)__hip_atomic_fetch_add((P), (X), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#else
+#define SPG_ADD(P, X) (*(P) = __fadd_rn(*(P), (X)))
+#endif
 constexpr int SPG_NB = 8;     // neighbours per batch (two batches of (column, value) x 2 chunks live in registers)
 constexpr int SPG_MK = 512;   // neighbours per metadata chunk (one per thread)
 template <int MODE>
@@ -392,7 +400,9 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                                                     const float *__restrict__ bvals, int n_out, int ct,
                                                     int32_t *__restrict__ row_nnz, const int64_t *__restrict__ out_indptr,
                                                     int64_t out_base, int32_t *__restrict__ ocols, float *__restrict__ ovals,
-                                                    int dbg) {
+                                                    int dbg, const int32_t *__restrict__ order) {
+    // order != nullptr: output row r is the product row of mapping-matrix row order[r] (indptr is then the FULL array):
+    // a processing order in which consecutive rows share neighbours keeps the gathered payload rows in L2.
     extern __shared__ __align__(16) unsigned char smem[];
     float *acc = reinterpret_cast<float *>(smem);                       // [ct] (ct is a multiple of 4)
     int64_t *m_b0 = reinterpret_cast<int64_t *>(acc + ct);              // [SPG_MK] first entry of the neighbour's payload row
@@ -404,8 +414,9 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
     auto fetch_meta = [&](int64_t row, int64_t off, float &ma, int64_t &mb0, int &mlen) {
         ma = 0.f; mb0 = 0; mlen = 0;
         if (row < nq) {
-            const int64_t p = indptr[row] + off + tid;
-            if (p < indptr[row + 1]) {
+            const int64_t src = order ? (int64_t)order[row] : row;
+            const int64_t p = indptr[src] + off + tid;
+            if (p < indptr[src + 1]) {
                 const int64_t j = cols[p];
                 ma = vals[p];
                 mb0 = bptr[j];
@@ -417,7 +428,8 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
     int64_t pre_deg = 0, pre_out = 0;              // ... its degree and (MODE 1) the start of its output
     auto fetch_row = [&](int64_t row) {
         fetch_meta(row, 0, pre_a, pre_b0, pre_len);
-        pre_deg = row < nq ? indptr[row + 1] - indptr[row] : 0;
+        const int64_t src = (order && row < nq) ? (int64_t)order[row] : row;
+        pre_deg = row < nq ? indptr[src + 1] - indptr[src] : 0;
         pre_out = (MODE == 1 && row < nq) ? out_indptr[row] : 0;
     };
     fetch_row(blockIdx.x);
@@ -429,7 +441,10 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
         int total = 0;   // non-zeros of this row emitted by earlier column passes
         for (int c0 = 0; c0 < n_out; c0 += ct) {
             const int cw = (n_out - c0 < ct) ? n_out - c0 : ct;
-            for (int c = tid; c < cw; c += nt) acc[c] = 0.f;
+            {   // clear the accumulator (16 bytes per store; acc holds ct floats, ct a multiple of 4 >= cw)
+                float4 *a4 = reinterpret_cast<float4 *>(acc);
+                for (int c = tid; c < (cw + 3) / 4; c += nt) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             for (int64_t off = 0; off < deg || off == 0; off += SPG_MK) {
                 float ma; int64_t mb0; int mlen;
                 if (off == 0) { ma = f_a; mb0 = f_b0; mlen = f_len; }
@@ -442,23 +457,32 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                 // is added (straight-line code, so the compiler counts the outstanding loads instead of draining them)
                 int ca[SPG_NB][2] = {}, cbv[SPG_NB][2] = {};
                 float va[SPG_NB][2] = {}, vb[SPG_NB][2] = {};
-                auto uni = [&](int u, int64_t &b0, int &len, float &wa) {   // metadata of neighbour u (scalar registers)
-                    len = 0; b0 = 0; wa = 0.f;
-                    if (u < nchunk) {
-                        len = __builtin_amdgcn_readfirstlane(m_len[u]);
-                        const int64_t b = m_b0[u];
-                        b0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
-                        wa = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_a[u])));
-                    }
+                // metadata of a batch: lane l holds neighbour ub + (l & 7) (one LDS round trip per batch); a neighbour's values
+                // reach the scalar registers by v_readlane
+                struct BMeta { int len; int blo, bhi; float a; };
+                auto batch_meta = [&](int ub) {
+                    BMeta m;
+                    const int u = ub + (lane & (SPG_NB - 1));
+                    const bool in = u < nchunk;
+                    const int64_t b = in ? m_b0[u] : 0;
+                    m.len = in ? m_len[u] : 0;
+                    m.blo = (int)(b & 0xffffffffll);
+                    m.bhi = (int)(b >> 32);
+                    m.a = in ? m_a[u] : 0.f;
+                    return m;
                 };
-                auto load_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], int ub) {
+                auto uni = [&](const BMeta &m, int nidx, int64_t &b0, int &len, float &wa) {
+                    len = __builtin_amdgcn_readlane(m.len, nidx);
+                    b0 = ((int64_t)__builtin_amdgcn_readlane(m.bhi, nidx) << 32) | (uint32_t)__builtin_amdgcn_readlane(m.blo, nidx);
+                    wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.a), nidx));
+                };
+                auto load_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], const BMeta &bm) {
                     // unconditional loads from clamped (always valid) addresses inside a UNIFORM branch, raw values kept:
                     // nothing here needs a loaded value, so the compiler issues all of them back to back
 #pragma unroll
                     for (int n = 0; n < SPG_NB; ++n) {
                         int64_t b0; int len; float wa;
-                        uni(ub + n, b0, len, wa);
+                        uni(bm, n, b0, len, wa);
                         if (len > 0 && !(dbg & 4)) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
@@ -470,34 +494,40 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                         }
                     }
                 };
-                auto apply_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], int ub) {
+                auto apply_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], const BMeta &bm) {
 #pragma unroll
                     for (int n = 0; n < SPG_NB; ++n) {
                         int64_t b0; int len; float wa;
-                        uni(ub + n, b0, len, wa);
+                        uni(bm, n, b0, len, wa);
                         if (len > 0) {   // (uniform)
                             // the previous neighbour's adds are done.  (Not __syncthreads(): its fence would also wait
                             // for the prefetched loads of the next batch -- only LDS traffic has to be ordered here.)
                             if (!(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int c = cc[n][j] - c0;
-                                if (!(dbg & 6) && j * 512 + tid < len && (unsigned)c < (unsigned)cw)
-                                    acc[c] = __fadd_rn(acc[c], __fmul_rn(wa, vv[n][j]));
+                            {   // the two entries of a thread lie in one payload row: distinct columns, so both accumulator
+                                // reads go out before either write (one LDS round trip per neighbour instead of two)
+                                const int c_0 = cc[n][0] - c0, c_1 = cc[n][1] - c0;
+                                const bool p_0 = !(dbg & 6) && tid < len && (unsigned)c_0 < (unsigned)cw;
+                                const bool p_1 = !(dbg & 6) && 512 + tid < len && (unsigned)c_1 < (unsigned)cw;
+                                const float x_0 = p_0 ? acc[c_0] : 0.f, x_1 = p_1 ? acc[c_1] : 0.f;
+                                if (p_0) acc[c_0] = __fadd_rn(x_0, __fmul_rn(wa, vv[n][0]));
+                                if (p_1) acc[c_1] = __fadd_rn(x_1, __fmul_rn(wa, vv[n][1]));
                             }
                             for (int64_t t = 1024 + tid; t < len; t += 512) {   // payload rows longer than 1 024 entries
                                 const int c = bcols[b0 + t] - c0;
-                                if ((unsigned)c < (unsigned)cw) acc[c] = __fadd_rn(acc[c], __fmul_rn(wa, bvals[b0 + t]));
+                                if ((unsigned)c < (unsigned)cw) SPG_ADD(acc + c, __fmul_rn(wa, bvals[b0 + t]));
                             }
                         }
                     }
                 };
-                load_batch(ca, va, 0);
+                BMeta ma_ = batch_meta(0), mb_;
+                load_batch(ca, va, ma_);
                 for (int ub = 0; ub < nchunk; ub += 2 * SPG_NB) {
-                    load_batch(cbv, vb, ub + SPG_NB);
-                    apply_batch(ca, va, ub);
-                    load_batch(ca, va, ub + 2 * SPG_NB);
-                    apply_batch(cbv, vb, ub + SPG_NB);
+                    mb_ = batch_meta(ub + SPG_NB);
+                    load_batch(cbv, vb, mb_);
+                    apply_batch(ca, va, ma_);
+                    ma_ = batch_meta(ub + 2 * SPG_NB);
+                    load_batch(ca, va, ma_);
+                    apply_batch(cbv, vb, mb_);
                 }
             }
             __syncthreads();   // all adds of the pass are done
@@ -683,7 +713,7 @@ constexpr int SPG_CT = 32768;   // output columns per pass of the A3 accumulator
 static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_out,
                                int32_t *d_row_nnz, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols,
-                               float *d_out_vals) {
+                               float *d_out_vals, const int32_t *d_order = nullptr) {
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm_csr: payload has no columns");
     if (n_out > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: more than 2^31 output columns");
     if (nq == 0) return CM_OK;
@@ -704,12 +734,12 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
         auto kern = spgemm_rows<0>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg);
+                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg, d_order);
     } else {
         auto kern = spgemm_rows<1>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg);
+                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg, d_order);
     }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
@@ -717,15 +747,54 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
 
 cm_status cm_spmm_csr_count_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
-                                int64_t n_out, int32_t *d_row_nnz) {
-    return spgemm_launch(h, 0, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, d_row_nnz, nullptr, 0, nullptr, nullptr);
+                                int64_t n_out, int32_t *d_row_nnz, const int32_t *d_order) {
+    return spgemm_launch(h, 0, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, d_row_nnz, nullptr, 0, nullptr, nullptr, d_order);
 }
 // out_base: value subtracted from d_out_indptr[row] to address d_out_cols / d_out_vals (query tiles of a larger output:
 // the tile's buffers start at the tile's first entry)
 cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
-                               int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals) {
-    return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, out_base, d_out_cols, d_out_vals);
+                               int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals,
+                               const int32_t *d_order) {
+    return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, out_base, d_out_cols, d_out_vals,
+                         d_order);
+}
+
+// ---- locality order of the mapping-matrix rows: rows grouped by their smallest neighbour column (counting sort over the
+// column range).  Queries that share a neighbour sit close to each other, so consecutive rows of this order gather mostly
+// the same payload rows.  Within a group the order is the arrival order of the scatter (any order serves the purpose).
+namespace {
+__global__ void lo_hist(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols, int64_t nq, int64_t n_ref, int *__restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int64_t p = indptr[i];
+    const int64_t key = p < indptr[i + 1] ? (int64_t)cols[p] : n_ref;   // empty rows last
+    atomicAdd(&hist[key], 1);
+}
+__global__ void lo_scatter(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols, int64_t nq, int64_t n_ref,
+                           const int64_t *__restrict__ start, int *__restrict__ cursor, int32_t *__restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int64_t p = indptr[i];
+    const int64_t key = p < indptr[i + 1] ? (int64_t)cols[p] : n_ref;
+    order[start[key] + atomicAdd(&cursor[key], 1)] = (int32_t)i;
+}
+}  // namespace
+size_t cm_locality_order_ws_bytes(int64_t n_ref) { return 2 * cm_align(4 * (size_t)(n_ref + 1)) + cm_align(8 * (size_t)(n_ref + 2)) + cm_scan_ws_bytes(n_ref + 1) + 4096; }
+cm_status cm_locality_order_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, int64_t nq, int64_t n_ref, int32_t *d_order) {
+    if (nq == 0) return CM_OK;
+    int *hist = (int *)cm_ws_alloc(h, 4 * (size_t)(n_ref + 1));
+    int *cursor = (int *)cm_ws_alloc(h, 4 * (size_t)(n_ref + 1));
+    int64_t *start = (int64_t *)cm_ws_alloc(h, 8 * (size_t)(n_ref + 2));
+    if (!hist || !cursor || !start) CM_FAIL(h, CM_E_NOMEM, "locality order: device workspace exhausted");
+    CM_HIP(h, hipMemsetAsync(hist, 0, 4 * (size_t)(n_ref + 1), h->stream));
+    CM_HIP(h, hipMemsetAsync(cursor, 0, 4 * (size_t)(n_ref + 1), h->stream));
+    hipLaunchKernelGGL(lo_hist, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, d_indptr, d_cols, nq, n_ref, hist);
+    CM_TRY(cm_exclusive_scan_i32_to_i64(h, hist, n_ref + 1, start));
+    hipLaunchKernelGGL(lo_scatter, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, d_indptr, d_cols, nq, n_ref, (const int64_t *)start,
+                       cursor, d_order);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
 }
 
 // ------------------------------------------------------------------ T1: precomputed-distance ingest --

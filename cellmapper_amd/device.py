@@ -142,7 +142,16 @@ class DevicePipeline:
                     self._dtype_id(B), _dp(out))
         return out
 
-    def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None):
+    def locality_order(self, indptr, cols, n_ref):
+        """Permutation of the mapping-matrix rows (int32) in which rows sharing their smallest neighbour column are adjacent:
+        a processing order for :meth:`spmm_csr` that keeps the gathered payload rows in L2."""
+        t = self.torch
+        nq = indptr.shape[0] - 1
+        order = t.empty(nq, dtype=t.int32, device=self.device)
+        self.h.call("cm_locality_order_dev", _dp(indptr), _dp(cols), nq, int(n_ref), _dp(order))
+        return order
+
+    def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None, order=None):
         """Rows [q0, q1) of ``M @ B`` for a CSR payload (A3, device tier): ``(out_indptr, out_cols, out_vals)`` of the TILE
         (``out_indptr`` starts at 0).  Count pass, exclusive scan, fill pass -- the structure of scipy's csr_matmat.
         ``out=(ptr [>= nt+1] int64, cols int32, vals float32)``: caller-provided tile buffers with room for the worst case
@@ -153,10 +162,13 @@ class DevicePipeline:
         q1 = nq_all if q1 is None else q1
         nt = q1 - q0
         n_ref = b_indptr.shape[0] - 1
-        ip = indptr[q0:q1 + 1]   # (a view: entries still index the full cols / vals)
+        # a tile is a slice of the indptr (a view: entries still index the full cols / vals), or -- with a row order -- a
+        # slice of the ORDER over the full indptr: output row r = product row of mapping-matrix row order[q0 + r]
+        ip = indptr[q0:q1 + 1] if order is None else indptr
+        od = None if order is None else order[q0:q1]
         optr = out[0] if out is not None else t.empty(nt + 1, dtype=t.int64, device=self.device)
         self.h.call("cm_spmm_csr_nnz_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
-                    int(n_out), _dp(optr))
+                    int(n_out), _dp(optr), _dp(od))
         if out is not None:
             oc, ov = out[1], out[2]
             if optr.dtype != t.int64 or oc.dtype != t.int32 or ov.dtype != t.float32 or optr.shape[0] < nt + 1:
@@ -167,7 +179,7 @@ class DevicePipeline:
             oc = t.empty(max(nnz, 1), dtype=t.int32, device=self.device)
             ov = t.empty(max(nnz, 1), dtype=t.float32, device=self.device)
         self.h.call("cm_spmm_csr_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
-                    int(n_out), _dp(optr), _dp(oc), _dp(ov))
+                    int(n_out), _dp(optr), _dp(oc), _dp(ov), _dp(od))
         return (optr, oc, ov) if nnz is None else (optr, oc[:nnz], ov[:nnz])
 
     def map_labels(self, ref, qry, k, codes, n_cat, metric="euclidean", kernel="gaussian", epsilon=1e-8,

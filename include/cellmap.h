@@ -198,13 +198,21 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
  *
  * Device tier of the same (asynchronous on the handle's stream).  cm_spmm_csr_nnz_dev writes d_out_indptr [nq+1] (exclusive
  * scan of the per-row counts, starting at 0); cm_spmm_csr_dev fills d_out_cols / d_out_vals [d_out_indptr[nq]].  For a
- * query TILE pass d_indptr + q0 (its entries index the full d_cols / d_vals) and the tile's row count as nq. */
+ * query TILE pass d_indptr + q0 (its entries index the full d_cols / d_vals) and the tile's row count as nq.
+ * d_row_order (may be NULL): output row r is the product row of mapping-matrix row d_row_order[r]; d_indptr is then the
+ * FULL indptr and a tile is a slice of the ORDER (d_row_order + q0).  cm_locality_order_dev fills such an order (int32
+ * [nq], a permutation of the rows): rows grouped by their smallest neighbour column, so consecutive rows gather mostly the
+ * same payload rows and those stay in L2 (config 5: every reference row is gathered by ~k different queries).  The order
+ * within a group is unspecified. */
+cm_status cm_locality_order_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, int64_t nq, int64_t n_ref,
+                                int32_t *d_order);
 cm_status cm_spmm_csr_nnz_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                               const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
-                              int64_t n_out, int64_t *d_out_indptr);
+                              int64_t n_out, int64_t *d_out_indptr, const int32_t *d_row_order);
 cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                           const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
-                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals);
+                          int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
+                          const int32_t *d_row_order);
 
 /* ---------------------------------------------------------------- graph tier: device-resident staged flow ----
  * Upstream, compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm / map_layers is ONE in-process flow over

@@ -113,3 +113,39 @@ def test_spgemm_device_tier_tiles_equal_the_whole(oracle):
             np.testing.assert_array_equal(np.concatenate(ptrs), want[0])
             np.testing.assert_array_equal(np.concatenate(cs), want[1])
             np.testing.assert_array_equal(np.concatenate(vs), want[2])
+
+
+def test_spgemm_row_order_is_a_pure_permutation(oracle):
+    """cm_locality_order_dev + cm_spmm_csr_*_dev with a row order: tile rows are the product rows of mapping-matrix rows
+    order[q0:q1] -- the same bits as the unordered product, only arranged for L2 reuse; the order is a permutation that keeps
+    rows with the same smallest neighbour column together."""
+    import torch
+
+    from cellmapper_amd.device import DevicePipeline
+
+    pipe = DevicePipeline(0)
+    rng = np.random.default_rng(80)
+    n_ref, nq, k, n_out = 400, 3000, 6, 500
+    indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+    B = sp.random(n_ref, n_out, density=0.05, format="csr", dtype=np.float32, random_state=rng)
+    dense = oracle.spmm_csr(indptr, cols, vals, B)
+    dev = pipe.device
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    d = dict(indptr=t(indptr, np.int64), cols=t(cols, np.int32), vals=t(vals, np.float32), bp=t(B.indptr, np.int64),
+             bc=t(B.indices, np.int32), bv=t(B.data, np.float32))
+    with torch.cuda.stream(pipe.stream):
+        order = pipe.locality_order(d["indptr"], d["cols"], n_ref)
+        pipe.synchronize()
+        o = order.cpu().numpy()
+        assert np.array_equal(np.sort(o), np.arange(nq))
+        first = np.where(np.diff(indptr) > 0, cols[np.minimum(indptr[:-1], len(cols) - 1)], n_ref)
+        assert np.all(np.diff(first[o]) >= 0), "rows must be grouped by their smallest neighbour column"
+        for q0 in range(0, nq, 1100):
+            q1 = min(nq, q0 + 1100)
+            optr, oc, ov = pipe.spmm_csr(d["indptr"], d["cols"], d["vals"], d["bp"], d["bc"], d["bv"], n_out, q0, q1, order=order)
+            pipe.synchronize()
+            op, occ, ovv = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy()
+            for r in range(q1 - q0):
+                row = dense[o[q0 + r]]
+                wc = np.flatnonzero(row)
+                assert np.array_equal(occ[op[r]:op[r + 1]], wc) and np.array_equal(ovv[op[r]:op[r + 1]], row[wc])
