@@ -172,12 +172,18 @@ def run_config5(a, pipe, torch):
     t_cols = [torch.empty(tile * row_cap, dtype=torch.int32, device=dev) for _ in range(2)]
     t_vals = [torch.empty(tile * row_cap, dtype=torch.float32, device=dev) for _ in range(2)]
     t_ptr = [torch.empty(tile + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    t_rows = [torch.empty(tile, dtype=torch.int32, device=dev) for _ in range(2)]
     out_nnz = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.set_stream(pipe.stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a3_ms = []
 
     use_order = not os.environ.get("CELLMAP_NO_ROW_ORDER")
+    one_pass = G <= pipe.SINGLE_PASS_MAX_COLS and not os.environ.get("CELLMAP_A3_TWO_PASS") and not os.environ.get("CELLMAP_SPGEMM_CT")
+    # CELLMAP_A3_COMPLETION: rows of a tile in completion order (out_rows names them; ~6 % faster) instead of the order's own
+    # sequence (offsets from the chained scan)
+    any_order = one_pass and bool(os.environ.get("CELLMAP_A3_COMPLETION"))
+    last = {}
 
     def step():
         _, _, indptr, oc, ov = _graph(pipe, xy, xy, a.k, a.kernel)
@@ -189,8 +195,10 @@ def run_config5(a, pipe, torch):
         for i, q0 in enumerate(range(0, n, tile)):
             q1 = min(n, q0 + tile)
             b = i & 1
-            pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, q0, q1, out=(t_ptr[b], t_cols[b], t_vals[b]), order=order)
+            pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, q0, q1, out=(t_ptr[b], t_cols[b], t_vals[b]), order=order,
+                          out_rows=t_rows[b] if any_order else None)
             out_nnz.add_(t_ptr[b][q1 - q0])
+            last.update(q0=q0, q1=q1, b=b, order=order)
         e1.record(pipe.stream)
         return indptr, oc, ov
 
@@ -214,14 +222,17 @@ def run_config5(a, pipe, torch):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "timed_region": "device-resident",
         "config": {"workload": f"self-mapping of {n} spatial cells, d={a.d}, k={a.k}, {a.kernel} kernel, expression imputation from a "
                                f"sparse reference.X ({G} genes, {per} non-zeros per cell, CSR) (BASELINE configs[4]); CSR product "
-                               f"produced in {tile}-row tiles{' of a locality order of the rows' if use_order else ''}, {nnz_out} "
+                               f"produced in {tile}-row tiles{' of a locality order of the rows' if use_order else ''}"
+                               f"{' (rows of a tile in completion order, named by a row-id vector)' if any_order else ''}, {nnz_out} "
                                f"non-zeros in total",
                    "baseline_config": 5, "nq": n, "n_ref": n, "d": a.d, "k": a.k, "genes": G, "nnz_per_cell": per,
                    "query_tile": tile, "output_nnz": nnz_out},
-        "roofline": {"bound": "hbm", "kernel": "spgemm_rows<0> + spgemm_rows<1> (count + fill passes of the CSR x CSR product, A3)",
+        "roofline": {"bound": "hbm", "kernel": "spgemm_rows<2> (single-pass CSR x CSR product, A3: counts, offsets, entries from one gather)"
+                     if one_pass else "spgemm_rows<0> + spgemm_rows<1> (count + fill passes of the CSR x CSR product, A3)",
                      "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
                      "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
-                     "kernel_ms_covers": "both passes over all query tiles in one step (the gather is done twice: count, fill)"},
+                     "kernel_ms_covers": ("all query tiles of one step incl. the locality sort (one gather per row)" if one_pass else
+                                          "both passes over all query tiles in one step (the gather is done twice: count, fill)")},
         "stage_ms_last_step": dict(stages, layer_spgemm=ms),
     }
     if a.check > 0:
@@ -230,10 +241,22 @@ def run_config5(a, pipe, torch):
 
         orc.build()
         indptr, oc, ov = res
-        ns = min(64, n)
-        sel_np = np.arange(0, n, max(1, n // ns))[:ns]
+        # rows of the LAST tile the timed loop produced (its buffers still hold it): tile row r is mapping-matrix row
+        # order[q0 + r] (or q0 + r), found in the tile's CSR at slot j with t_rows[j] == r (or j == r)
+        q0, q1, b = last["q0"], last["q1"], last["b"]
+        nt = q1 - q0
+        ns = min(64, nt)
+        tr = np.arange(0, nt, max(1, nt // ns))[:ns]
+        src = (last["order"][q0:q1].cpu().numpy()[tr] if last["order"] is not None else q0 + tr).astype(np.int64)
+        if any_order:
+            inv_rows = np.empty(nt, dtype=np.int64)
+            inv_rows[t_rows[b][:nt].cpu().numpy()] = np.arange(nt)
+            slots = inv_rows[tr]
+        else:
+            slots = tr
+        tp = t_ptr[b][:nt + 1].cpu().numpy()
         ipt = indptr.cpu().numpy()
-        rows_c = np.concatenate([np.arange(ipt[i], ipt[i + 1]) for i in sel_np])
+        rows_c = np.concatenate([np.arange(ipt[i], ipt[i + 1]) for i in src])
         c_np = oc[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
         v_np = ov[torch.from_numpy(rows_c).to(dev)].cpu().numpy()
         uniq, inv = np.unique(c_np, return_inverse=True)
@@ -241,14 +264,15 @@ def run_config5(a, pipe, torch):
         bc = b_cols.view(n, per)[sel_rows].cpu().numpy().ravel()
         bv = b_vals.view(n, per)[sel_rows].cpu().numpy().ravel()
         Bs = sp.csr_matrix((bv, bc, np.arange(len(uniq) + 1, dtype=np.int64) * per), shape=(len(uniq), G))
-        lens = np.array([ipt[i + 1] - ipt[i] for i in sel_np])
+        lens = np.array([ipt[i + 1] - ipt[i] for i in src])
         ip2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         dense = orc.spmm_csr(ip2, inv.astype(np.int32), v_np, Bs)   # [ns, G] float32; csr_matmat drops exact zeros
-        ok = True
-        for r, i in enumerate(sel_np.tolist()):
-            optr, gc, gv = pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, i, i + 1)
-            gc, gv = gc.cpu().numpy(), gv.cpu().numpy()
+        ok = bool(tp[0] == 0 and np.all(np.diff(tp) >= 0) and tp[-1] <= t_cols[b].shape[0])
+        for r, j in enumerate(slots.tolist()):
+            gc = t_cols[b][tp[j]:tp[j + 1]].cpu().numpy()
+            gv = t_vals[b][tp[j]:tp[j + 1]].cpu().numpy()
             wc = np.flatnonzero(dense[r])
             ok = ok and np.array_equal(gc, wc) and np.array_equal(gv, dense[r][wc])
-        result["parity_check"] = {"rows": int(ns), "csr_rows_bit_exact": bool(ok), "ok": bool(ok)}
+        result["parity_check"] = {"rows": int(ns), "csr_rows_bit_exact": bool(ok), "ok": bool(ok),
+                                  "checked": "rows of the last tile the timed loop wrote, against the CPU oracle"}
     return result

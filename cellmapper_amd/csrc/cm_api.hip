@@ -363,6 +363,22 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
                                 d_out_vals, d_row_order);
 }
 
+cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                                const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
+                                int64_t n_out, int64_t capacity, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
+                                const int32_t *d_row_order, int32_t *d_out_rows) {
+    CM_TRY(begin_call(h, cm_align(8 * (size_t)(std::max<int64_t>(nq, 0) + 2)) + 4096));
+    if (nq < 0 || capacity < 0 || !d_out_indptr || (capacity > 0 && (!d_out_cols || !d_out_vals)))
+        CM_FAIL(h, CM_E_INVALID, "spmm_csr (single pass): bad arguments");
+    if (!cm_spmm_csr_single_pass_ok(n_out))
+        CM_FAIL(h, CM_E_INVALID, "spmm_csr (single pass): %lld output columns do not fit one accumulator pass; use "
+                                 "cm_spmm_csr_nnz_dev + cm_spmm_csr_dev", (long long)n_out);
+    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, 8 * (size_t)(nq + 2));
+    if (!chain) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: device workspace exhausted");
+    return cm_spmm_csr_fused_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, d_out_indptr, d_out_cols,
+                                 d_out_vals, capacity, d_row_order, chain, d_out_rows);
+}
+
 cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                             int32_t dtype, int32_t k, int32_t metric, int32_t kernel, double epsilon,
                             const int32_t *d_codes, int32_t n_cat, int32_t *d_out_code, float *d_out_conf,

@@ -114,6 +114,11 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
                                int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals,
                                const int32_t *d_order = nullptr);
+bool cm_spmm_csr_single_pass_ok(int64_t n_out);
+cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals, int64_t capacity,
+                                const int32_t *d_order, unsigned long long *d_chain, int32_t *d_out_rows);
 size_t cm_locality_order_ws_bytes(int64_t n_ref);
 cm_status cm_locality_order_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, int64_t nq, int64_t n_ref, int32_t *d_order);
 cm_status cm_exclusive_scan_i32_to_i64(cm_handle_t h, const int32_t *d_in, int64_t n, int64_t *d_out /* n+1 */);

@@ -383,6 +383,15 @@ __global__ __launch_bounds__(256) void spmm_narrow(const int64_t *__restrict__ i
 // added -- the barrier per neighbour no longer exposes the load latency.  The per-neighbour metadata
 // (weight, payload row bounds) sits in LDS; the next row's is prefetched into registers.  Exact zeros are dropped like
 // csr_matmat does.   MODE 0: count non-zeros per row.  MODE 1: emit (column, value) pairs in ascending column order.
+// MODE 2 (single pass, n_out <= ct): count AND emit -- the row's place in the output comes from a chained scan over the rows
+// (decoupled look-back: `chain[r]` = (state, value), state 1 = the row's own count, 2 = the inclusive prefix; a row
+// publishes its count as soon as it is known, then wave 0 sums the published counts of its predecessors back to the
+// nearest inclusive prefix).  Rows are handed out by a ticket counter (`chain[nq]`), so every predecessor of a row is held
+// by a workgroup that is already running: the wait always ends.  The gather is done once instead of twice.  Rows whose end
+// would pass `capacity` entries are counted but not written (the caller compares out_indptr[nq] with its capacity).
+// The chained scan couples the workgroups (a row waits for the slowest of the ~256 rows in flight before it); with
+// `out_rows` the rows are emitted in COMPLETION order instead: one 64-bit atomic (`chain[nq + 1]`: row slot << 40 | entries)
+// hands a finished row its slot j and its first entry, out_rows[j] names the row -- nobody waits for anybody.
 // acc[c] += x.  Measured alternative: one ds_add_f32 per entry (same bits: an IEEE single add inside the LDS unit) instead of
 // load / v_add / store -- 2.5 x SLOWER on gfx950 (437 -> 1 097 ms at 1 M cells of config 5: LDS float atomics serialise),
 // so the three-instruction form stays; -DCM_SPG_LDS_ATOMIC builds the other one.
@@ -398,9 +407,10 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                                                     const float *__restrict__ vals, int64_t nq,
                                                     const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
                                                     const float *__restrict__ bvals, int n_out, int ct,
-                                                    int32_t *__restrict__ row_nnz, const int64_t *__restrict__ out_indptr,
+                                                    int32_t *__restrict__ row_nnz, int64_t *out_indptr,
                                                     int64_t out_base, int32_t *__restrict__ ocols, float *__restrict__ ovals,
-                                                    int dbg, const int32_t *__restrict__ order) {
+                                                    int dbg, const int32_t *__restrict__ order, unsigned long long *chain,
+                                                    int64_t capacity, int32_t *__restrict__ out_rows) {
     // order != nullptr: output row r is the product row of mapping-matrix row order[r] (indptr is then the FULL array):
     // a processing order in which consecutive rows share neighbours keeps the gathered payload rows in L2.
     extern __shared__ __align__(16) unsigned char smem[];
@@ -409,8 +419,11 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
     int *m_len = reinterpret_cast<int *>(m_b0 + SPG_MK);                // [SPG_MK] its length
     float *m_a = reinterpret_cast<float *>(m_len + SPG_MK);             // [SPG_MK] the neighbour's weight
     int *wsum = reinterpret_cast<int *>(m_a + SPG_MK);                  // [2][8] wave totals (by pass parity)
+    long long *tk = reinterpret_cast<long long *>(wsum + 16);           // MODE 2: [0] next ticket, [1] the row's first entry
+    float *dummy = reinterpret_cast<float *>(tk + 2);                   // [128] where lanes without an entry do their add
     const int nt = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     int parity = 0;
+    const int dix = (int)(dummy - acc) + lane;   // the lane's own slot, as an accumulator index
     auto fetch_meta = [&](int64_t row, int64_t off, float &ma, int64_t &mb0, int &mlen) {
         ma = 0.f; mb0 = 0; mlen = 0;
         if (row < nq) {
@@ -432,12 +445,23 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
         pre_deg = row < nq ? indptr[src + 1] - indptr[src] : 0;
         pre_out = (MODE == 1 && row < nq) ? out_indptr[row] : 0;
     };
-    fetch_row(blockIdx.x);
-    for (int64_t row = blockIdx.x; row < nq; row += gridDim.x) {
-        const int64_t deg = pre_deg, row_out = pre_out;
-        (void)row_out;
+    int64_t row = blockIdx.x;
+    // tickets only where a row waits for its predecessors (chained scan); completion order takes the static stride
+    const bool ticketed = MODE == 2 && !out_rows;
+    if (ticketed) {
+        if (tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
+        __syncthreads();
+        row = tk[0];
+        __syncthreads();
+    }
+    fetch_row(row);
+    while (row < nq) {
+        const int64_t deg = pre_deg;
+        int64_t row_out = pre_out;
         const float f_a = pre_a; const int64_t f_b0 = pre_b0; const int f_len = pre_len;
-        fetch_row(row + gridDim.x);
+        int64_t next_row = row + gridDim.x;
+        if (ticketed) { if (tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull); }   // (read after the first barrier below)
+        else fetch_row(next_row);
         int total = 0;   // non-zeros of this row emitted by earlier column passes
         for (int c0 = 0; c0 < n_out; c0 += ct) {
             const int cw = (n_out - c0 < ct) ? n_out - c0 : ct;
@@ -451,12 +475,15 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                 else fetch_meta(row, off, ma, mb0, mlen);
                 __syncthreads();   // previous chunk's items are done with the metadata (and: acc is zeroed)
                 m_a[tid] = ma; m_b0[tid] = mb0; m_len[tid] = mlen;
+                if (ticketed && off == 0) { next_row = tk[0]; fetch_row(next_row); }   // the next row's metadata is in flight from here
                 __syncthreads();
                 const int nchunk = (int)(deg - off < SPG_MK ? deg - off : SPG_MK);
                 // ---- batches of SPG_NB neighbours, two register sets: the loads of batch i+1 are in flight while batch i
-                // is added (straight-line code, so the compiler counts the outstanding loads instead of draining them)
-                int ca[SPG_NB][2] = {}, cbv[SPG_NB][2] = {};
-                float va[SPG_NB][2] = {}, vb[SPG_NB][2] = {};
+                // is added.  Everything per neighbour is straight-line code on uniform (scalar) row bounds: ~25 instructions
+                // per wave and neighbour (the first version spent ~100, mostly on branches and register shuffling around
+                // predicated loads -- the kernel is issue-bound, not bandwidth-bound).
+                int ca[SPG_NB][2], cbv[SPG_NB][2];
+                float va[SPG_NB][2], vb[SPG_NB][2];
                 // metadata of a batch: lane l holds neighbour ub + (l & 7) (one LDS round trip per batch); a neighbour's values
                 // reach the scalar registers by v_readlane
                 struct BMeta { int len; int blo, bhi; float a; };
@@ -477,21 +504,23 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                     wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.a), nidx));
                 };
                 auto load_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], const BMeta &bm) {
-                    // unconditional loads from clamped (always valid) addresses inside a UNIFORM branch, raw values kept:
-                    // nothing here needs a loaded value, so the compiler issues all of them back to back
+                    // unconditional loads: uniform row base + a lane index clamped to the row (an empty slot reads the first
+                    // words of indptr instead -- always there); nothing here needs a loaded value, so all of a batch's loads
+                    // are issued back to back
 #pragma unroll
                     for (int n = 0; n < SPG_NB; ++n) {
                         int64_t b0; int len; float wa;
                         uni(bm, n, b0, len, wa);
-                        if (len > 0 && !(dbg & 4)) {
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int t = j * 512 + tid;
-                                const int64_t src = b0 + (t < len ? t : len - 1);
-                                cc[n][j] = bcols[src];
-                                vv[n][j] = bvals[src];
-                            }
-                        }
+                        const bool has = len > 0;
+                        const int32_t *pc = has ? bcols + b0 : reinterpret_cast<const int32_t *>(indptr);
+                        const float *pv = has ? bvals + b0 : reinterpret_cast<const float *>(indptr);
+                        const int last = has ? len - 1 : 0;
+                        // (uniform base + 32-bit byte offset: the scalar-base form of global_load, no 64-bit vector arithmetic)
+                        const unsigned o_0 = (unsigned)min(tid, last) << 2, o_1 = (unsigned)min(tid + 512, last) << 2;
+                        cc[n][0] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_0);
+                        vv[n][0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_0);
+                        cc[n][1] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_1);
+                        vv[n][1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_1);
                     }
                 };
                 auto apply_batch = [&](int (&cc)[SPG_NB][2], float (&vv)[SPG_NB][2], const BMeta &bm) {
@@ -502,19 +531,24 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                         if (len > 0) {   // (uniform)
                             // the previous neighbour's adds are done.  (Not __syncthreads(): its fence would also wait
                             // for the prefetched loads of the next batch -- only LDS traffic has to be ordered here.)
-                            if (!(dbg & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                             {   // the two entries of a thread lie in one payload row: distinct columns, so both accumulator
-                                // reads go out before either write (one LDS round trip per neighbour instead of two)
+                                // reads go out before either write (one LDS round trip per neighbour instead of two).  A lane
+                                // without an entry (or with a column outside the pass) works on a slot of its own behind the
+                                // accumulator: no branch
                                 const int c_0 = cc[n][0] - c0, c_1 = cc[n][1] - c0;
-                                const bool p_0 = !(dbg & 6) && tid < len && (unsigned)c_0 < (unsigned)cw;
-                                const bool p_1 = !(dbg & 6) && 512 + tid < len && (unsigned)c_1 < (unsigned)cw;
-                                const float x_0 = p_0 ? acc[c_0] : 0.f, x_1 = p_1 ? acc[c_1] : 0.f;
-                                if (p_0) acc[c_0] = __fadd_rn(x_0, __fmul_rn(wa, vv[n][0]));
-                                if (p_1) acc[c_1] = __fadd_rn(x_1, __fmul_rn(wa, vv[n][1]));
+                                const bool p_0 = tid < len && (unsigned)c_0 < (unsigned)cw;
+                                const bool p_1 = 512 + tid < len && (unsigned)c_1 < (unsigned)cw;
+                                float *a_0 = acc + (p_0 ? c_0 : dix), *a_1 = acc + (p_1 ? c_1 : dix + 64);
+                                const float x_0 = *a_0, x_1 = *a_1;
+                                *a_0 = __fadd_rn(x_0, __fmul_rn(wa, vv[n][0]));
+                                *a_1 = __fadd_rn(x_1, __fmul_rn(wa, vv[n][1]));
                             }
-                            for (int64_t t = 1024 + tid; t < len; t += 512) {   // payload rows longer than 1 024 entries
-                                const int c = bcols[b0 + t] - c0;
-                                if ((unsigned)c < (unsigned)cw) SPG_ADD(acc + c, __fmul_rn(wa, bvals[b0 + t]));
+                            if (len > 1024) {   // (uniform) payload rows longer than 1 024 entries
+                                for (int64_t t = 1024 + tid; t < len; t += 512) {
+                                    const int c = bcols[b0 + t] - c0;
+                                    if ((unsigned)c < (unsigned)cw) SPG_ADD(acc + c, __fmul_rn(wa, bvals[b0 + t]));
+                                }
                             }
                         }
                     }
@@ -545,7 +579,59 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
             int before = 0, all = 0;
             for (int w = 0; w < nw; ++w) { const int s_ = wsum[parity * 8 + w]; all += s_; if (w < wave) before += s_; }
             parity ^= 1;
-            if (MODE == 1 && !(dbg & 8)) {
+            bool fits = true;
+            if (MODE == 2 && out_rows) {
+                if (tid == 0) {
+                    const unsigned long long old = atomicAdd(chain + nq + 1, (1ull << 40) | (unsigned long long)all);
+                    const long long j = (long long)(old >> 40), o = (long long)(old & ((1ull << 40) - 1ull));
+                    out_indptr[j] = o;
+                    if (j == nq - 1) out_indptr[nq] = o + all;
+                    out_rows[j] = (int32_t)row;
+                    tk[1] = o;
+                }
+                __syncthreads();
+                row_out = tk[1];
+                fits = row_out + all <= capacity;
+            } else if (MODE == 2) {
+                constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
+                if (wave == 0) {
+                    if (lane == 0)
+                        __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    long long excl = 0;
+                    for (int64_t pos = row - 1; pos >= 0;) {   // 64 predecessors at a time, nearest on lane 0
+                        const int64_t i = pos - lane;
+                        unsigned long long v, empty, incl;
+                        for (;;) {
+                            v = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                            empty = __ballot((v >> 62) == 0ull);
+                            incl = __ballot((v >> 62) == 2ull);
+                            // usable when the nearest inclusive prefix has no unpublished row in front of it, or all 64 are counts
+                            if (empty == 0ull || (incl != 0ull && __ffsll((long long)incl) < __ffsll((long long)empty))) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        const int fi = incl ? __ffsll((long long)incl) - 1 : 63;
+                        long long part = lane <= fi ? (long long)(v & VMASK) : 0ll;
+#pragma unroll
+                        for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+                        excl += part;
+                        if (incl) break;
+                        pos -= 64;
+                    }
+                    if (lane == 0) {
+                        if (row > 0)
+                            __hip_atomic_store(chain + row, (2ull << 62) | (unsigned long long)(excl + all), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        else out_indptr[0] = 0;
+                        out_indptr[row + 1] = excl + all;
+                        tk[1] = excl;
+                    }
+                }
+                __syncthreads();
+                row_out = tk[1];
+                fits = row_out + all <= capacity;
+            }
+            if (MODE >= 1 && fits && !(dbg & 8)) {
                 int64_t o = row_out - out_base + total + before;
                 for (int c = lo; c < hi; c += 64) {
                     const float v = (c + lane < hi) ? acc[c + lane] : 0.f;
@@ -563,6 +649,7 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
             __syncthreads();   // the accumulator is free for the next pass / row
         }
         if (MODE == 0 && tid == 0) row_nnz[row] = total;
+        row = next_row;
     }
 }
 
@@ -713,7 +800,8 @@ constexpr int SPG_CT = 32768;   // output columns per pass of the A3 accumulator
 static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_out,
                                int32_t *d_row_nnz, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols,
-                               float *d_out_vals, const int32_t *d_order = nullptr) {
+                               float *d_out_vals, const int32_t *d_order = nullptr, unsigned long long *d_chain = nullptr,
+                               int64_t capacity = 0, int32_t *d_out_rows = nullptr) {
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm_csr: payload has no columns");
     if (n_out > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: more than 2^31 output columns");
     if (nq == 0) return CM_OK;
@@ -721,7 +809,7 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
     if (const char *e = getenv("CELLMAP_SPGEMM_CT")) { int v = atoi(e); if (v >= 4 && v <= SPG_CT) ct = v & ~3; }   // testing: force column passes
     if (n_out < ct) ct = (int)((n_out + 3) & ~3LL);
     const int dbg = getenv("CELLMAP_SPGEMM_DBG") ? atoi(getenv("CELLMAP_SPGEMM_DBG")) : 0;   // timing experiments only (wrong results)
-    size_t lds = (size_t)ct * 4 + (size_t)SPG_MK * 16 + 128;
+    size_t lds = (size_t)ct * 4 + (size_t)SPG_MK * 16 + 128 + 512;
     if (h->n_cu <= 0) {
         hipDeviceProp_t pr;
         CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
@@ -730,16 +818,25 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
     // resident workgroups: the accumulator decides how many fit a CU's 160 KB of LDS
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 1024)));
     unsigned grid = (unsigned)std::min<int64_t>(nq, (int64_t)h->n_cu * per_cu);
+    int64_t *optr = const_cast<int64_t *>(d_out_indptr);   // (written by the single-pass mode only)
+    if (mode == 2 && (n_out > ct || !d_chain)) CM_FAIL(h, CM_E_INVALID, "spmm_csr: the single-pass product needs n_out <= %d", ct);
     if (mode == 0) {
         auto kern = spgemm_rows<0>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg, d_order);
-    } else {
+                           (int)n_out, ct, d_row_nnz, optr, out_base, d_out_cols, d_out_vals, dbg, d_order, d_chain, capacity, d_out_rows);
+    } else if (mode == 1) {
         auto kern = spgemm_rows<1>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
-                           (int)n_out, ct, d_row_nnz, d_out_indptr, out_base, d_out_cols, d_out_vals, dbg, d_order);
+                           (int)n_out, ct, d_row_nnz, optr, out_base, d_out_cols, d_out_vals, dbg, d_order, d_chain, capacity, d_out_rows);
+    } else {
+        auto kern = spgemm_rows<2>;
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (d_out_rows && nq >= (1LL << 24)) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: rows in completion order: at most 2^24 - 1 rows per call");
+        CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals,
+                           (int)n_out, ct, d_row_nnz, optr, out_base, d_out_cols, d_out_vals, dbg, d_order, d_chain, capacity, d_out_rows);
     }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
@@ -758,6 +855,19 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
                                const int32_t *d_order) {
     return spgemm_launch(h, 1, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, out_base, d_out_cols, d_out_vals,
                          d_order);
+}
+
+// Single pass (n_out <= SPG_CT): counts, output offsets (chained scan, or completion order with d_out_rows) and entries from
+// ONE gather.  d_chain: nq + 2 words of scratch.  d_out_indptr[0..nq] is written in full; entries of rows that end beyond
+// `capacity` are not.
+bool cm_spmm_csr_single_pass_ok(int64_t n_out) { return n_out >= 1 && n_out <= SPG_CT && !getenv("CELLMAP_SPGEMM_CT"); }
+cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals, int64_t capacity,
+                                const int32_t *d_order, unsigned long long *d_chain, int32_t *d_out_rows) {
+    if (nq == 0) { CM_HIP(h, hipMemsetAsync(d_out_indptr, 0, 8, h->stream)); return CM_OK; }
+    return spgemm_launch(h, 2, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, n_out, nullptr, d_out_indptr, 0, d_out_cols,
+                         d_out_vals, d_order, d_chain, capacity, d_out_rows);
 }
 
 // ---- locality order of the mapping-matrix rows: rows grouped by their smallest neighbour column (counting sort over the

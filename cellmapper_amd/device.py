@@ -6,6 +6,7 @@ compute goes through ``libcellmap_hip.so``.  Tensors must live on the handle's G
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -151,12 +152,20 @@ class DevicePipeline:
         self.h.call("cm_locality_order_dev", _dp(indptr), _dp(cols), nq, int(n_ref), _dp(order))
         return order
 
-    def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None, order=None):
+    SINGLE_PASS_MAX_COLS = 32768
+
+    def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None, order=None,
+                 single_pass=None, out_rows=None):
         """Rows [q0, q1) of ``M @ B`` for a CSR payload (A3, device tier): ``(out_indptr, out_cols, out_vals)`` of the TILE
-        (``out_indptr`` starts at 0).  Count pass, exclusive scan, fill pass -- the structure of scipy's csr_matmat.
-        ``out=(ptr [>= nt+1] int64, cols int32, vals float32)``: caller-provided tile buffers with room for the worst case
-        (``nt * min(n_out, k * max payload row)`` entries) -- no host read between the passes; the tile's entry count is
-        ``ptr[nt]`` on the device."""
+        (``out_indptr`` starts at 0).  Without ``out``: count pass, exclusive scan, exact allocation, fill pass -- the
+        structure of scipy's csr_matmat.  ``out=(ptr [>= nt+1] int64, cols int32, vals float32)``: caller-provided tile
+        buffers with room for the worst case (``nt * min(n_out, k * max payload row)`` entries) -- no host read at all, the
+        tile's entry count is ``ptr[nt]`` on the device; with ``n_out <= 32 768`` the product is then made in ONE pass
+        (``cm_spmm_csr_fused_dev``: offsets from a chained scan inside the kernel; rows that would end beyond the buffers
+        are counted but not written).  ``single_pass=False`` forces the two-pass pair.  ``out_rows`` (int32 [>= nt], single
+        pass only): rows are emitted in COMPLETION order, output row j = product row of tile row ``out_rows[j]`` -- no
+        workgroup waits for its predecessors' counts (the fastest form; the arrangement differs from run to run, the
+        content of a row does not)."""
         t = self.torch
         nq_all = indptr.shape[0] - 1
         q1 = nq_all if q1 is None else q1
@@ -167,12 +176,27 @@ class DevicePipeline:
         ip = indptr[q0:q1 + 1] if order is None else indptr
         od = None if order is None else order[q0:q1]
         optr = out[0] if out is not None else t.empty(nt + 1, dtype=t.int64, device=self.device)
-        self.h.call("cm_spmm_csr_nnz_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
-                    int(n_out), _dp(optr), _dp(od))
         if out is not None:
             oc, ov = out[1], out[2]
             if optr.dtype != t.int64 or oc.dtype != t.int32 or ov.dtype != t.float32 or optr.shape[0] < nt + 1:
                 raise ValueError("spmm_csr(out=...): need (int64 [>= nt+1], int32, float32) device tensors")
+            if single_pass is None:
+                single_pass = int(n_out) <= self.SINGLE_PASS_MAX_COLS and not os.environ.get("CELLMAP_SPGEMM_CT") \
+                    and not os.environ.get("CELLMAP_A3_TWO_PASS")
+            if out_rows is not None and (out_rows.dtype != t.int32 or out_rows.shape[0] < nt):
+                raise ValueError("spmm_csr(out_rows=...): need an int32 device tensor with one entry per tile row")
+            if single_pass:
+                self.h.call("cm_spmm_csr_fused_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals),
+                            n_ref, int(n_out), int(min(oc.shape[0], ov.shape[0])), _dp(optr), _dp(oc), _dp(ov), _dp(od),
+                            _dp(out_rows))
+                return optr, oc, ov
+        elif single_pass:
+            raise ValueError("spmm_csr(single_pass=True) needs caller-provided tile buffers (out=...)")
+        if out_rows is not None:
+            raise ValueError("spmm_csr(out_rows=...): completion order exists for the single-pass form only")
+        self.h.call("cm_spmm_csr_nnz_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals), n_ref,
+                    int(n_out), _dp(optr), _dp(od))
+        if out is not None:
             nnz = None
         else:
             nnz = int(optr[-1].item())   # (one host read per tile: the tile's output has to be allocated)

@@ -213,6 +213,19 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
                           const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                           int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
                           const int32_t *d_row_order);
+/* Single-pass form for callers that own a tile buffer with room for the worst case (n_out <= 32 768 columns, else
+ * CM_E_INVALID: use the pair above): counts, offsets and entries come from ONE gather of the payload rows -- the rows'
+ * places in the output are found by a chained scan inside the kernel.  d_out_indptr [nq+1] is always written in full
+ * (exact counts); the entries of rows that would end beyond `capacity` (entries available in d_out_cols / d_out_vals) are
+ * NOT written: the caller compares d_out_indptr[nq] with its capacity.  Same result bits as the pair above.
+ * d_out_rows == NULL: output row r is input row r (of the order); the chained scan makes a row wait for the rows in front of
+ * it.  d_out_rows != NULL (int32 [nq], nq < 2^24): rows are emitted in COMPLETION order -- output row j is the product row of
+ * input row d_out_rows[j] (a permutation of 0..nq-1 that differs from run to run; the content of a row does not), and no
+ * workgroup waits for another: the fastest form, for consumers that address rows through d_out_rows. */
+cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
+                                const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
+                                int64_t n_out, int64_t capacity, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
+                                const int32_t *d_row_order, int32_t *d_out_rows);
 
 /* ---------------------------------------------------------------- graph tier: device-resident staged flow ----
  * Upstream, compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm / map_layers is ONE in-process flow over

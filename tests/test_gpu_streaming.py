@@ -149,3 +149,72 @@ def test_spgemm_row_order_is_a_pure_permutation(oracle):
                 row = dense[o[q0 + r]]
                 wc = np.flatnonzero(row)
                 assert np.array_equal(occ[op[r]:op[r + 1]], wc) and np.array_equal(ovv[op[r]:op[r + 1]], row[wc])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_order", [False, True])
+def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order):
+    """cm_spmm_csr_fused_dev (one gather, offsets from the chained scan inside the kernel) against the oracle and the count +
+    fill pair: identical indptr / columns / values, with ragged and EMPTY mapping rows, payload values of both signs (exact
+    zeros from cancellation are dropped, csr_matmat's rule), thousands of rows (look-back over more than 64 predecessors
+    and many rounds of tickets) and a capacity that is too small (counts stay exact, rows beyond it are not written)."""
+    import torch
+
+    from cellmapper_amd.device import DevicePipeline
+
+    pipe = DevicePipeline(0)
+    rng = np.random.default_rng(81)
+    n_ref, nq, k, n_out = 300, 7000, 5, 700
+    indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+    vals = np.full_like(vals, 0.25)                         # equal weights: +v and -v cancel exactly
+    B = sp.random(n_ref, n_out, density=0.04, format="csr", dtype=np.float32, random_state=rng)
+    B.data = rng.choice(np.array([-2.0, -1.0, 1.0, 2.0], dtype=np.float32), size=B.data.shape[0])
+    dense = oracle.spmm_csr(indptr, cols, vals, B)
+    Babs = B.copy()
+    Babs.data = np.abs(Babs.data)
+    assert ((dense == 0) & (oracle.spmm_csr(indptr, cols, vals, Babs) != 0)).any(), "the case needs exact cancellations"
+    dev = pipe.device
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    d = dict(indptr=t(indptr, np.int64), cols=t(cols, np.int32), vals=t(vals, np.float32), bp=t(B.indptr, np.int64),
+             bc=t(B.indices, np.int32), bv=t(B.data, np.float32))
+    args = (d["indptr"], d["cols"], d["vals"], d["bp"], d["bc"], d["bv"], n_out)
+    with torch.cuda.stream(pipe.stream):
+        order = pipe.locality_order(d["indptr"], d["cols"], n_ref) if with_order else None
+        rows = order.cpu().numpy() if with_order else np.arange(nq)
+        want_ptr = np.concatenate([[0], np.cumsum([(dense[r] != 0).sum() for r in rows])])
+        cap = int(want_ptr[-1])
+        for capacity in (cap + 17, cap, cap // 2):
+            out = (torch.full((nq + 1,), -1, dtype=torch.int64, device=dev), torch.full((max(capacity, 1),), -7, dtype=torch.int32, device=dev),
+                   torch.full((max(capacity, 1),), -7.0, dtype=torch.float32, device=dev))
+            optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True)
+            pipe.synchronize()
+            op, occ, ovv = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy()
+            assert np.array_equal(op, want_ptr)
+            n_ok = int(np.searchsorted(want_ptr, capacity, side="right")) - 1     # rows that end within the capacity
+            for r in range(0, n_ok, 13):
+                row = dense[rows[r]]
+                wc = np.flatnonzero(row)
+                assert np.array_equal(occ[op[r]:op[r + 1]], wc) and np.array_equal(ovv[op[r]:op[r + 1]], row[wc])
+            assert np.all(occ[want_ptr[n_ok]:capacity] == -7), "rows beyond the capacity must not be written"
+        # completion order: a permutation of the rows, each row's content unchanged
+        out = (torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+               torch.empty(cap, dtype=torch.float32, device=dev))
+        ids = torch.full((nq,), -1, dtype=torch.int32, device=dev)
+        optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True, out_rows=ids)
+        pipe.synchronize()
+        op, occ, ovv, idn = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy(), ids.cpu().numpy()
+        assert np.array_equal(np.sort(idn), np.arange(nq)) and op[0] == 0 and op[-1] == cap
+        assert np.array_equal(np.diff(op), np.diff(want_ptr)[idn])
+        for j in range(0, nq, 11):
+            row = dense[rows[idn[j]]]
+            wc = np.flatnonzero(row)
+            assert np.array_equal(occ[op[j]:op[j + 1]], wc) and np.array_equal(ovv[op[j]:op[j + 1]], row[wc])
+        # the two-pass pair on the same buffers gives the same bytes
+        bufs = lambda: (torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                        torch.empty(cap, dtype=torch.float32, device=dev))
+        out1, out2 = bufs(), bufs()
+        pipe.spmm_csr(*args, out=out1, order=order, single_pass=True)
+        pipe.spmm_csr(*args, out=out2, order=order, single_pass=False)
+        pipe.synchronize()
+        for x, y in zip(out1, out2):
+            assert torch.equal(x, y)
