@@ -183,6 +183,7 @@ def run_config5(a, pipe, torch):
     # CELLMAP_A3_COMPLETION: rows of a tile in completion order (out_rows names them; ~6 % faster) instead of the order's own
     # sequence (offsets from the chained scan)
     any_order = one_pass and bool(os.environ.get("CELLMAP_A3_COMPLETION"))
+    sliced = one_pass and not os.environ.get("CELLMAP_A3_BARRIER")   # wave-sliced kernel (payload index) unless asked otherwise
     last = {}
 
     def step():
@@ -192,11 +193,13 @@ def run_config5(a, pipe, torch):
         # rows in LOCALITY order (inside the timed region): a tile's rows share neighbours, the gathered payload rows stay
         # in L2; tile i holds the product rows of mapping-matrix rows order[q0:q1]
         order = pipe.locality_order(indptr, oc, n) if use_order else None
+        # payload index (a property of reference.X, rebuilt every step so that it is inside the timed region)
+        pidx = pipe.payload_index(b_indptr, b_cols, G) if sliced else None
         for i, q0 in enumerate(range(0, n, tile)):
             q1 = min(n, q0 + tile)
             b = i & 1
             pipe.spmm_csr(indptr, oc, ov, b_indptr, b_cols, b_vals, G, q0, q1, out=(t_ptr[b], t_cols[b], t_vals[b]), order=order,
-                          out_rows=t_rows[b] if any_order else None)
+                          out_rows=t_rows[b] if any_order else None, payload_index=pidx)
             out_nnz.add_(t_ptr[b][q1 - q0])
             last.update(q0=q0, q1=q1, b=b, order=order)
         e1.record(pipe.stream)
@@ -227,11 +230,13 @@ def run_config5(a, pipe, torch):
                                f"non-zeros in total",
                    "baseline_config": 5, "nq": n, "n_ref": n, "d": a.d, "k": a.k, "genes": G, "nnz_per_cell": per,
                    "query_tile": tile, "output_nnz": nnz_out},
-        "roofline": {"bound": "hbm", "kernel": "spgemm_rows<2> (single-pass CSR x CSR product, A3: counts, offsets, entries from one gather)"
+        "roofline": {"bound": "hbm", "kernel": ("spgemm_sliced (single-pass CSR x CSR product, A3: every wave owns an eighth of the output "
+                                                "columns; counts, offsets, entries from one gather)" if sliced else
+                                                "spgemm_rows<2> (single-pass CSR x CSR product, A3: counts, offsets, entries from one gather)")
                      if one_pass else "spgemm_rows<0> + spgemm_rows<1> (count + fill passes of the CSR x CSR product, A3)",
                      "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
                      "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
-                     "kernel_ms_covers": ("all query tiles of one step incl. the locality sort (one gather per row)" if one_pass else
+                     "kernel_ms_covers": ("all query tiles of one step incl. the locality sort and the payload index (one gather per row)" if one_pass else
                                           "both passes over all query tiles in one step (the gather is done twice: count, fill)")},
         "stage_ms_last_step": dict(stages, layer_spgemm=ms),
     }

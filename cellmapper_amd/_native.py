@@ -35,7 +35,7 @@ EXPORTS = [
     "cm_version", "cm_device_count", "cm_create", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
-    "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
+    "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
     "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
@@ -83,7 +83,10 @@ def load_library():
         lib.cm_spmm_csr.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp]
         lib.cm_spmm_csr_nnz_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp]
         lib.cm_spmm_csr_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, vp, vp, vp, vp]
-        lib.cm_spmm_csr_fused_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
+        lib.cm_spmm_csr_fused_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+        lib.cm_payload_index_len.argtypes = [i64, i64]
+        lib.cm_payload_index_len.restype = i64
+        lib.cm_payload_index_dev.argtypes = [vp, vp, vp, i64, i64, vp]
         lib.cm_locality_order_dev.argtypes = [vp, vp, vp, i64, i64, vp]
         lib.cm_map_labels_dev.argtypes = [vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, dbl, vp, i32, vp, vp, vp, vp]
         lib.cm_csr_normalize.argtypes = [vp, vp, vp, i64, vp]
@@ -113,7 +116,7 @@ def load_library():
         lib.cm_device_count.argtypes = []
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("cm_version", "cm_device_count", "cm_last_error"):
+            if name not in ("cm_version", "cm_device_count", "cm_last_error", "cm_payload_index_len"):
                 fn.restype = C.c_int
         _lib = lib
         return lib

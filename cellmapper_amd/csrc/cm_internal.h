@@ -115,6 +115,15 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
                                int64_t n_out, const int64_t *d_out_indptr, int64_t out_base, int32_t *d_out_cols, float *d_out_vals,
                                const int32_t *d_order = nullptr);
 bool cm_spmm_csr_single_pass_ok(int64_t n_out);
+int cm_a3_bucket_width(int64_t n_out);
+int64_t cm_payload_index_len_impl(int64_t n_ref, int64_t n_out);
+cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32_t *d_bcols, int64_t n_ref, int64_t n_out,
+                               int32_t *d_index, int *d_flag);
+cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                 const int32_t *d_index, int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols,
+                                 float *d_out_vals, int64_t capacity, const int32_t *d_order, unsigned long long *d_chain,
+                                 int32_t *d_out_rows);
 cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
                                 int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals, int64_t capacity,

@@ -870,6 +870,353 @@ cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const in
                          d_out_vals, d_order, d_chain, capacity, d_out_rows);
 }
 
+// ============================================================ A3, wave-sliced single pass ===============
+// The barrier per neighbour of spgemm_rows exists because two neighbours' entries of one output column are added by
+// different waves.  With a PAYLOAD INDEX -- for every payload row, the positions where its (ascending) columns cross the
+// multiples of W -- wave w of a workgroup takes from every neighbour row exactly the entries of columns [w W, (w+1) W): an
+// output column belongs to ONE wave, whose LDS operations are executed in program order, so the adds of a column happen in
+// neighbour order (csr_matmat's sequence) with no synchronisation at all.  The waves run the whole gather independently
+// (each keeps 2 x 8 neighbours' entries in flight in registers) and meet twice per row: for the row's entry count (sum of
+// the waves' counts) and for its place in the output (chained scan or completion order, as in spgemm_rows<2>).  A wave
+// fetches its own neighbour metadata (weight, slice start, slice length: lane l <-> neighbours l and l + 64), the next
+// row's in four stages spread over the current row.
+namespace {
+constexpr int SLC_NB = 8;   // neighbours per batch and register set
+
+__device__ __forceinline__ int a3_bucket_width(int n_out) {   // (same formula on the host: cm_a3_bucket_width)
+    const int w = (((n_out + 7) / 8) + 63) & ~63;
+    return w < 64 ? 64 : w;
+}
+
+// idx[j][b], b = 0..nb: number of entries of payload row j with column < b W.  One wave per row; also checks that the
+// row's columns are strictly ascending and inside [0, n_out) (flag[0] = 1 otherwise).
+__global__ __launch_bounds__(256) void payload_index(const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols, int64_t n_ref,
+                                                     int n_out, int W, int nb, int32_t *__restrict__ idx, int *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_ref) return;
+    const int64_t lo = bptr[j], hi = bptr[j + 1];
+    int32_t *out = idx + j * (nb + 1);
+    const int len = (int)(hi - lo);
+    if (hi < lo || hi - lo > 0x7fffffffLL) { if (lane == 0) flag[0] = 1; return; }
+    if (len == 0) { for (int b = lane; b <= nb; b += 64) out[b] = 0; return; }
+    bool bad = false;
+    for (int i = lane; i < len; i += 64) {
+        const int c = bcols[lo + i];
+        const int cn = i + 1 < len ? bcols[lo + i + 1] : 0x7fffffff;
+        bad = bad || c < 0 || c >= n_out || (i + 1 < len && cn <= c);
+        const int b0 = (unsigned)c < (unsigned)n_out ? c / W : nb;                  // bucket of this entry
+        const int b1 = i + 1 < len ? ((unsigned)cn < (unsigned)n_out ? cn / W : nb) : nb;   // bucket of the next one (nb: past the end)
+        if (i == 0) for (int b = 0; b <= b0 && b <= nb; ++b) out[b] = 0;
+        for (int b = b0 + 1; b <= b1 && b <= nb; ++b) out[b] = i + 1;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) flag[0] = 1;
+}
+
+__global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+                                                      const float *__restrict__ vals, int64_t nq,
+                                                      const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
+                                                      const float *__restrict__ bvals, const int32_t *__restrict__ bidx, int nb1,
+                                                      int n_out, int W, int64_t *out_indptr, int32_t *__restrict__ ocols,
+                                                      float *__restrict__ ovals, const int32_t *__restrict__ order,
+                                                      unsigned long long *chain, int64_t capacity, int32_t *__restrict__ out_rows) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *acc = reinterpret_cast<float *>(smem);                       // [8 W]
+    int *wsum = reinterpret_cast<int *>(acc + 8 * W);                   // [2][8] wave totals (by row parity)
+    long long *tk = reinterpret_cast<long long *>(wsum + 16);           // [0] ticket of the row after next, [1] the row's first entry
+    float *dummy = reinterpret_cast<float *>(tk + 2);                   // [128] where lanes without an entry do their add
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wlo = wave * W, whi = (wlo + W < n_out) ? wlo + W : n_out;   // this wave's output columns (possibly none)
+    const int dix = (int)(dummy - acc) + lane;
+    const bool ticketed = !out_rows;   // chained scan: rows by ticket (a predecessor is always held by a running workgroup)
+    int parity = 0;
+
+    int64_t row, nxt;
+    if (ticketed) {
+        // one ticket at a time (a workgroup's rows must interleave with the other workgroups' rows: a row waits for the counts
+        // of ALL rows in front of it, and a ticket held back here is a row nobody works on)
+        if (tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
+        __syncthreads();
+        row = tk[0]; nxt = nq;   // (the next row's ticket is taken when this one starts)
+        __syncthreads();
+    } else {
+        row = blockIdx.x; nxt = row + gridDim.x;
+    }
+
+    // ---- neighbour metadata of a row, per wave: lane l holds neighbours l and l + 64 (slice start, slice length, weight)
+    struct Meta { int slo[2], shi[2], len[2]; float a[2]; int deg; int64_t p0; };
+    struct Stage { int64_t src, p0; int deg; int j[2]; float a[2]; int64_t b0[2]; int s[2], e[2]; };
+    auto stage0 = [&](Stage &g, int64_t r) { g.src = r < nq ? (order ? (int64_t)order[r] : r) : -1; };
+    auto stage1 = [&](Stage &g) {
+        g.p0 = 0; g.deg = 0;
+        if (g.src >= 0) { g.p0 = indptr[g.src]; g.deg = (int)(indptr[g.src + 1] - g.p0); }
+    };
+    auto stage2 = [&](Stage &g) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int u = h * 64 + lane;
+            const bool in = u < g.deg;
+            g.j[h] = in ? cols[g.p0 + u] : -1;
+            g.a[h] = in ? vals[g.p0 + u] : 0.f;
+        }
+    };
+    auto stage3 = [&](Stage &g) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            g.b0[h] = 0; g.s[h] = 0; g.e[h] = 0;
+            if (g.j[h] >= 0 && wave < nb1 - 1) {   // (a wave beyond the last bucket has no columns)
+                g.b0[h] = bptr[g.j[h]];
+                const int32_t *ip = bidx + (int64_t)g.j[h] * nb1 + wave;
+                g.s[h] = ip[0]; g.e[h] = ip[1];
+            }
+        }
+    };
+    auto finish = [&](const Stage &g, Meta &m) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t st = g.b0[h] + g.s[h];
+            m.slo[h] = (int)(st & 0xffffffffll); m.shi[h] = (int)(st >> 32);
+            m.len[h] = g.e[h] - g.s[h];
+            m.a[h] = g.a[h];
+        }
+        m.deg = g.deg; m.p0 = g.p0;
+    };
+    Stage g;
+    Meta cur;
+    stage0(g, row); stage1(g); stage2(g); stage3(g); finish(g, cur);
+    if (!ticketed) stage0(g, nxt);
+
+    while (row < nq) {
+        // the next row: static stride, its metadata fetched in four stages spread over this row -- or, with tickets, taken
+        // now, known to the waves after the first barrier and fetched during the emission (a ticket held for longer is a
+        // row the other workgroups wait for)
+        const int64_t nxt2 = nxt + gridDim.x;
+        if (ticketed && tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
+        // ---- clear this wave's slice
+        {
+            float4 *a4 = reinterpret_cast<float4 *>(acc + wlo);
+            for (int c = lane; c < W / 4; c += 64) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!ticketed) stage1(g);
+        // ---- the gather: batches of SLC_NB neighbours, two register sets
+        const int nn = cur.deg < 128 ? cur.deg : 128;
+        int ca[SLC_NB][2], cb[SLC_NB][2];
+        float va[SLC_NB][2], vb[SLC_NB][2];
+        struct BM { int slo, shi, len; float a; int base; };
+        auto pick = [&](int ub) {   // the metadata registers that hold neighbours ub .. ub + 7 (ub is a multiple of 8)
+            BM m;
+            const bool hi = ub >= 64, none = ub >= 128;
+            m.slo = hi ? cur.slo[1] : cur.slo[0];
+            m.shi = hi ? cur.shi[1] : cur.shi[0];
+            m.len = none ? 0 : (hi ? cur.len[1] : cur.len[0]);
+            m.a = hi ? cur.a[1] : cur.a[0];
+            m.base = ub & 63;
+            return m;
+        };
+        auto uni = [&](const BM &m, int n, int64_t &st, int &len, float &wa) {
+            const int l = m.base + n;
+            len = __builtin_amdgcn_readlane(m.len, l);
+            st = ((int64_t)__builtin_amdgcn_readlane(m.shi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(m.slo, l);
+            wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.a), l));
+        };
+        auto load_batch = [&](int (&cc)[SLC_NB][2], float (&vv)[SLC_NB][2], const BM &bm) {
+#pragma unroll
+            for (int n = 0; n < SLC_NB; ++n) {
+                int64_t st; int len; float wa;
+                uni(bm, n, st, len, wa);
+                const bool has = len > 0;
+                const int32_t *pc = has ? bcols + st : reinterpret_cast<const int32_t *>(indptr);
+                const float *pv = has ? bvals + st : reinterpret_cast<const float *>(indptr);
+                const int last = has ? len - 1 : 0;
+                const unsigned o_0 = (unsigned)min(lane, last) << 2, o_1 = (unsigned)min(lane + 64, last) << 2;
+                cc[n][0] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_0);
+                vv[n][0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_0);
+                cc[n][1] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_1);
+                vv[n][1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_1);
+            }
+        };
+        auto apply_batch = [&](int (&cc)[SLC_NB][2], float (&vv)[SLC_NB][2], const BM &bm) {
+#pragma unroll
+            for (int n = 0; n < SLC_NB; ++n) {
+                int64_t st; int len; float wa;
+                uni(bm, n, st, len, wa);
+                if (len > 0) {   // (uniform)
+                    const bool p_0 = lane < len, p_1 = lane + 64 < len;
+                    float *a_0 = acc + (p_0 ? cc[n][0] : dix), *a_1 = acc + (p_1 ? cc[n][1] : dix + 64);
+                    const float x_0 = *a_0, x_1 = *a_1;
+                    *a_0 = __fadd_rn(x_0, __fmul_rn(wa, vv[n][0]));
+                    *a_1 = __fadd_rn(x_1, __fmul_rn(wa, vv[n][1]));
+                    if (len > 128) {   // (uniform) a slice longer than 128 entries
+                        for (int t = 128 + lane; t < len; t += 64) {
+                            float *ap = acc + bcols[st + t];
+                            *ap = __fadd_rn(*ap, __fmul_rn(wa, bvals[st + t]));
+                        }
+                    }
+                }
+            }
+        };
+        BM ma = pick(0), mb;
+        load_batch(ca, va, ma);
+        for (int ub = 0; ub < nn; ub += 2 * SLC_NB) {
+            mb = pick(ub + SLC_NB);
+            load_batch(cb, vb, mb);
+            apply_batch(ca, va, ma);
+            if (ub == 0 && !ticketed) stage2(g);
+            ma = pick(ub + 2 * SLC_NB);
+            load_batch(ca, va, ma);
+            apply_batch(cb, vb, mb);
+        }
+        if (nn == 0 && !ticketed) stage2(g);   // (a row without neighbours: the loop above did not run)
+        // neighbours beyond the 128 held in registers (rows of very high degree): one at a time
+        for (int u = 128; u < cur.deg; ++u) {
+            const int64_t jn = cols[cur.p0 + u];
+            const float wa = vals[cur.p0 + u];
+            const int64_t b0 = bptr[jn];
+            const bool own = wave < nb1 - 1;
+            const int s_ = own ? bidx[jn * nb1 + wave] : 0, e_ = own ? bidx[jn * nb1 + wave + 1] : 0;
+            for (int t = s_ + lane; t < e_; t += 64) {
+                float *ap = acc + bcols[b0 + t];
+                *ap = __fadd_rn(*ap, __fmul_rn(wa, bvals[b0 + t]));
+            }
+        }
+        if (!ticketed) stage3(g);
+        // ---- count this wave's slice
+        int wcount = 0;
+        for (int c = wlo; c < whi; c += 64) {
+            const bool nz = (c + lane < whi) && acc[c + lane] != 0.f;
+            wcount += __popcll(__ballot(nz));
+        }
+        if (lane == 0) wsum[parity * 8 + wave] = wcount;
+        __syncthreads();
+        if (ticketed) {
+            nxt = tk[0];
+            if (wave != 0) { stage0(g, nxt); stage1(g); }
+        }
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const int s_ = wsum[parity * 8 + w]; all += s_; if (w < wave) before += s_; }
+        parity ^= 1;
+        // ---- the row's place in the output
+        if (!ticketed) {
+            if (tid == 0) {
+                const unsigned long long old = atomicAdd(chain + nq + 1, (1ull << 40) | (unsigned long long)all);
+                const long long j = (long long)(old >> 40), o = (long long)(old & ((1ull << 40) - 1ull));
+                out_indptr[j] = o;
+                if (j == nq - 1) out_indptr[nq] = o + all;
+                out_rows[j] = (int32_t)row;
+                tk[1] = o;
+            }
+        } else if (wave == 0) {
+            constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
+            if (lane == 0)
+                __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            long long excl = 0;
+            for (int64_t pos = row - 1; pos >= 0;) {   // 64 predecessors at a time, nearest on lane 0
+                const int64_t i = pos - lane;
+                unsigned long long v, empty, incl;
+                for (;;) {
+                    v = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                    empty = __ballot((v >> 62) == 0ull);
+                    incl = __ballot((v >> 62) == 2ull);
+                    if (empty == 0ull || (incl != 0ull && __ffsll((long long)incl) < __ffsll((long long)empty))) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                const int fi = incl ? __ffsll((long long)incl) - 1 : 63;
+                long long part = lane <= fi ? (long long)(v & VMASK) : 0ll;
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+                excl += part;
+                if (incl) break;
+                pos -= 64;
+            }
+            if (lane == 0) {
+                if (row > 0)
+                    __hip_atomic_store(chain + row, (2ull << 62) | (unsigned long long)(excl + all), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else out_indptr[0] = 0;
+                out_indptr[row + 1] = excl + all;
+                tk[1] = excl;
+            }
+        }
+        if (ticketed && wave == 0) { stage0(g, nxt); stage1(g); }
+        __syncthreads();
+        const int64_t row_out = tk[1];
+        if (ticketed) stage2(g);
+        // ---- emit this wave's slice (ascending columns; consecutive lanes write consecutive entries)
+        if (row_out + all <= capacity) {
+            int64_t o = row_out + before;
+            for (int c = wlo; c < whi; c += 64) {
+                const float v = (c + lane < whi) ? acc[c + lane] : 0.f;
+                const bool nz = v != 0.f;
+                const unsigned long long m = __ballot(nz);
+                if (nz) {
+                    const int64_t q = o + __popcll(m & ((1ull << lane) - 1ull));
+                    ocols[q] = c + lane;
+                    ovals[q] = v;
+                }
+                o += __popcll(m);
+            }
+        }
+        // ---- next row
+        if (ticketed) stage3(g);
+        finish(g, cur);
+        row = nxt;
+        if (!ticketed) { nxt = nxt2; stage0(g, nxt); }
+    }
+}
+}  // namespace
+
+int cm_a3_bucket_width(int64_t n_out) {
+    const int64_t w = (((n_out + 7) / 8) + 63) & ~63LL;
+    return (int)(w < 64 ? 64 : w);
+}
+int64_t cm_payload_index_len_impl(int64_t n_ref, int64_t n_out) {
+    if (n_ref < 0 || n_out < 1 || n_out > SPG_CT) return -1;
+    const int W = cm_a3_bucket_width(n_out);
+    const int nb = (int)((n_out + W - 1) / W);
+    return n_ref * (nb + 1);
+}
+// d_flag: one int of scratch, 1 afterwards if a payload row is not canonical (columns strictly ascending, inside [0, n_out))
+cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32_t *d_bcols, int64_t n_ref, int64_t n_out,
+                               int32_t *d_index, int *d_flag) {
+    if (n_out < 1 || n_out > SPG_CT) CM_FAIL(h, CM_E_INVALID, "payload index: 1 .. %d output columns", SPG_CT);
+    const int W = cm_a3_bucket_width(n_out);
+    const int nb = (int)((n_out + W - 1) / W);
+    CM_HIP(h, hipMemsetAsync(d_flag, 0, 4, h->stream));
+    if (n_ref > 0)
+        hipLaunchKernelGGL(payload_index, dim3((unsigned)((n_ref + 3) / 4)), dim3(256), 0, h->stream, d_bptr, d_bcols, n_ref, (int)n_out, W, nb,
+                           d_index, d_flag);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
+                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                 const int32_t *d_index, int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols,
+                                 float *d_out_vals, int64_t capacity, const int32_t *d_order, unsigned long long *d_chain,
+                                 int32_t *d_out_rows) {
+    if (n_out < 1 || n_out > SPG_CT) CM_FAIL(h, CM_E_INVALID, "spmm_csr (single pass): 1 .. %d output columns", SPG_CT);
+    if (nq == 0) { CM_HIP(h, hipMemsetAsync(d_out_indptr, 0, 8, h->stream)); return CM_OK; }
+    if (d_out_rows && nq >= (1LL << 24)) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: rows in completion order: at most 2^24 - 1 rows per call");
+    const int W = cm_a3_bucket_width(n_out);
+    const int nb = (int)((n_out + W - 1) / W);
+    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 512;
+    if (h->n_cu <= 0) {
+        hipDeviceProp_t pr;
+        CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
+        h->n_cu = pr.multiProcessorCount;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 1024)));
+    const unsigned grid = (unsigned)std::min<int64_t>(nq, (int64_t)h->n_cu * per_cu);
+    auto kern = spgemm_sliced;
+    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, d_index, nb + 1,
+                       (int)n_out, W, d_out_indptr, d_out_cols, d_out_vals, d_order, d_chain, capacity, d_out_rows);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
 // ---- locality order of the mapping-matrix rows: rows grouped by their smallest neighbour column (counting sort over the
 // column range).  Queries that share a neighbour sit close to each other, so consecutive rows of this order gather mostly
 // the same payload rows.  Within a group the order is the arrival order of the scatter (any order serves the purpose).

@@ -154,8 +154,21 @@ class DevicePipeline:
 
     SINGLE_PASS_MAX_COLS = 32768
 
+    def payload_index(self, b_indptr, b_cols, n_out):
+        """Index of a CSR payload for the single-pass :meth:`spmm_csr` (``cm_payload_index_dev``, built once per payload,
+        synchronous): lets every wave of a workgroup own an eighth of the output columns, so the product needs no barrier
+        per neighbour.  Raises ``ValueError`` if a payload row is not canonical CSR (strictly ascending columns)."""
+        t = self.torch
+        n_ref = b_indptr.shape[0] - 1
+        n = int(self.h.lib.cm_payload_index_len(n_ref, int(n_out)))
+        if n < 0:
+            raise ValueError(f"payload_index: the single-pass product covers 1 .. {self.SINGLE_PASS_MAX_COLS} output columns")
+        index = t.empty(max(n, 1), dtype=t.int32, device=self.device)
+        self.h.call("cm_payload_index_dev", _dp(b_indptr), _dp(b_cols), n_ref, int(n_out), _dp(index))
+        return index
+
     def spmm_csr(self, indptr, cols, vals, b_indptr, b_cols, b_vals, n_out, q0=0, q1=None, out=None, order=None,
-                 single_pass=None, out_rows=None):
+                 single_pass=None, out_rows=None, payload_index=None):
         """Rows [q0, q1) of ``M @ B`` for a CSR payload (A3, device tier): ``(out_indptr, out_cols, out_vals)`` of the TILE
         (``out_indptr`` starts at 0).  Without ``out``: count pass, exclusive scan, exact allocation, fill pass -- the
         structure of scipy's csr_matmat.  ``out=(ptr [>= nt+1] int64, cols int32, vals float32)``: caller-provided tile
@@ -165,7 +178,8 @@ class DevicePipeline:
         are counted but not written).  ``single_pass=False`` forces the two-pass pair.  ``out_rows`` (int32 [>= nt], single
         pass only): rows are emitted in COMPLETION order, output row j = product row of tile row ``out_rows[j]`` -- no
         workgroup waits for its predecessors' counts (the fastest form; the arrangement differs from run to run, the
-        content of a row does not)."""
+        content of a row does not).  ``payload_index`` (from :meth:`payload_index`, single pass only): the wave-sliced
+        kernel -- no barrier per neighbour, same bits."""
         t = self.torch
         nq_all = indptr.shape[0] - 1
         q1 = nq_all if q1 is None else q1
@@ -188,7 +202,7 @@ class DevicePipeline:
             if single_pass:
                 self.h.call("cm_spmm_csr_fused_dev", _dp(ip), _dp(cols), _dp(vals), nt, _dp(b_indptr), _dp(b_cols), _dp(b_vals),
                             n_ref, int(n_out), int(min(oc.shape[0], ov.shape[0])), _dp(optr), _dp(oc), _dp(ov), _dp(od),
-                            _dp(out_rows))
+                            _dp(out_rows), _dp(payload_index))
                 return optr, oc, ov
         elif single_pass:
             raise ValueError("spmm_csr(single_pass=True) needs caller-provided tile buffers (out=...)")

@@ -225,7 +225,18 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
 cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
                                 const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                                 int64_t n_out, int64_t capacity, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
-                                const int32_t *d_row_order, int32_t *d_out_rows);
+                                const int32_t *d_row_order, int32_t *d_out_rows, const int32_t *d_payload_index);
+/* Payload index for cm_spmm_csr_fused_dev (d_payload_index, may be NULL there): for every payload row the positions where
+ * its ascending columns cross the multiples of the bucket width (n_out / 8 rounded up to 64), int32
+ * [cm_payload_index_len(n_ref, n_out)].  With it every wave of a workgroup owns one eighth of the output columns and takes
+ * exactly its entries from each neighbour row: the adds of a column stay in neighbour order without the workgroup barrier
+ * per neighbour -- same bits, ~1.4 x faster.  Build it once per payload (a few ms at 4 M x 900 non-zeros) and reuse it for
+ * every query tile.  cm_payload_index_dev is SYNCHRONOUS: it returns CM_E_INVALID if a payload row is not canonical CSR
+ * (strictly ascending columns inside [0, n_out)) -- the barrier kernel (NULL index) only needs distinct columns per row.
+ * cm_payload_index_len: -1 if n_out is outside 1 .. 32 768. */
+int64_t cm_payload_index_len(int64_t n_ref, int64_t n_out);
+cm_status cm_payload_index_dev(cm_handle_t h, const int64_t *d_b_indptr, const int32_t *d_b_cols, int64_t n_ref, int64_t n_out,
+                               int32_t *d_index);
 
 /* ---------------------------------------------------------------- graph tier: device-resident staged flow ----
  * Upstream, compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm / map_layers is ONE in-process flow over

@@ -152,12 +152,13 @@ def test_spgemm_row_order_is_a_pure_permutation(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_order", [False, True])
-def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order):
+@pytest.mark.parametrize("with_order,with_index", [(False, False), (True, False), (False, True), (True, True)])
+def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order, with_index):
     """cm_spmm_csr_fused_dev (one gather, offsets from the chained scan inside the kernel) against the oracle and the count +
     fill pair: identical indptr / columns / values, with ragged and EMPTY mapping rows, payload values of both signs (exact
     zeros from cancellation are dropped, csr_matmat's rule), thousands of rows (look-back over more than 64 predecessors
-    and many rounds of tickets) and a capacity that is too small (counts stay exact, rows beyond it are not written)."""
+    and many rounds of tickets) and a capacity that is too small (counts stay exact, rows beyond it are not written).
+    with_index: the wave-sliced kernel (cm_payload_index_dev), no barrier per neighbour."""
     import torch
 
     from cellmapper_amd.device import DevicePipeline
@@ -180,13 +181,14 @@ def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order):
     args = (d["indptr"], d["cols"], d["vals"], d["bp"], d["bc"], d["bv"], n_out)
     with torch.cuda.stream(pipe.stream):
         order = pipe.locality_order(d["indptr"], d["cols"], n_ref) if with_order else None
+        pidx = pipe.payload_index(d["bp"], d["bc"], n_out) if with_index else None
         rows = order.cpu().numpy() if with_order else np.arange(nq)
         want_ptr = np.concatenate([[0], np.cumsum([(dense[r] != 0).sum() for r in rows])])
         cap = int(want_ptr[-1])
         for capacity in (cap + 17, cap, cap // 2):
             out = (torch.full((nq + 1,), -1, dtype=torch.int64, device=dev), torch.full((max(capacity, 1),), -7, dtype=torch.int32, device=dev),
                    torch.full((max(capacity, 1),), -7.0, dtype=torch.float32, device=dev))
-            optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True)
+            optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True, payload_index=pidx)
             pipe.synchronize()
             op, occ, ovv = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy()
             assert np.array_equal(op, want_ptr)
@@ -200,7 +202,7 @@ def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order):
         out = (torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                torch.empty(cap, dtype=torch.float32, device=dev))
         ids = torch.full((nq,), -1, dtype=torch.int32, device=dev)
-        optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True, out_rows=ids)
+        optr, oc, ov = pipe.spmm_csr(*args, out=out, order=order, single_pass=True, out_rows=ids, payload_index=pidx)
         pipe.synchronize()
         op, occ, ovv, idn = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy(), ids.cpu().numpy()
         assert np.array_equal(np.sort(idn), np.arange(nq)) and op[0] == 0 and op[-1] == cap
@@ -213,8 +215,52 @@ def test_spgemm_single_pass_equals_the_two_pass_pair(oracle, with_order):
         bufs = lambda: (torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                         torch.empty(cap, dtype=torch.float32, device=dev))
         out1, out2 = bufs(), bufs()
-        pipe.spmm_csr(*args, out=out1, order=order, single_pass=True)
+        pipe.spmm_csr(*args, out=out1, order=order, single_pass=True, payload_index=pidx)
         pipe.spmm_csr(*args, out=out2, order=order, single_pass=False)
         pipe.synchronize()
         for x, y in zip(out1, out2):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_spgemm_sliced_kernel_shapes(oracle):
+    """The wave-sliced product on shapes that leave its fast paths: a slice of more than 128 entries per neighbour row (dense
+    payload rows), mapping rows with more than 128 neighbours, fewer buckets than waves (narrow payloads), an output width
+    that is no multiple of the bucket width; and the index builder's refusal of a payload that is not canonical CSR."""
+    import torch
+
+    from cellmapper_amd.device import DevicePipeline
+
+    pipe = DevicePipeline(0)
+    dev = pipe.device
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    for seed, (n_ref, nq, k, n_out, density) in enumerate([(120, 300, 7, 3000, 0.6), (400, 150, 200, 900, 0.05), (60, 200, 4, 90, 0.3),
+                                                            (80, 100, 3, 1000, 0.2)]):
+        rng = np.random.default_rng(90 + seed)
+        indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
+        B = sp.random(n_ref, n_out, density=density, format="csr", dtype=np.float32, random_state=rng)
+        B.sort_indices()
+        dense = oracle.spmm_csr(indptr, cols, vals, B)
+        want_ptr = np.concatenate([[0], np.cumsum((dense != 0).sum(1))])
+        cap = int(want_ptr[-1])
+        d = dict(indptr=t(indptr, np.int64), cols=t(cols, np.int32), vals=t(vals, np.float32), bp=t(B.indptr, np.int64),
+                 bc=t(B.indices, np.int32), bv=t(B.data, np.float32))
+        with torch.cuda.stream(pipe.stream):
+            pidx = pipe.payload_index(d["bp"], d["bc"], n_out)
+            out = (torch.empty(nq + 1, dtype=torch.int64, device=dev), torch.empty(max(cap, 1), dtype=torch.int32, device=dev),
+                   torch.empty(max(cap, 1), dtype=torch.float32, device=dev))
+            optr, oc, ov = pipe.spmm_csr(d["indptr"], d["cols"], d["vals"], d["bp"], d["bc"], d["bv"], n_out, out=out, single_pass=True,
+                                         payload_index=pidx)
+            pipe.synchronize()
+        op, occ, ovv = optr.cpu().numpy(), oc.cpu().numpy(), ov.cpu().numpy()
+        assert np.array_equal(op, want_ptr)
+        for r in range(nq):
+            wc = np.flatnonzero(dense[r])
+            assert np.array_equal(occ[op[r]:op[r + 1]], wc) and np.array_equal(ovv[op[r]:op[r + 1]], dense[r][wc]), (seed, r)
+    # not canonical: a row with descending columns
+    bad_cols = B.indices.copy()
+    lo, hi = B.indptr[1], B.indptr[2]
+    assert hi - lo >= 2
+    bad_cols[lo:hi] = bad_cols[lo:hi][::-1]
+    with pytest.raises(ValueError, match="ascending"):
+        pipe.payload_index(d["bp"], t(bad_cols, np.int32), n_out)
