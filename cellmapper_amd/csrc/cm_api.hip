@@ -364,7 +364,7 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
 }
 
 cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
-                                const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t /*n_ref*/,
+                                const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                                 int64_t n_out, int64_t capacity, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
                                 const int32_t *d_row_order, int32_t *d_out_rows, const int32_t *d_payload_index) {
     CM_TRY(begin_call(h, cm_align(8 * (size_t)(std::max<int64_t>(nq, 0) + 2)) + 4096));
@@ -376,7 +376,7 @@ cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const in
     unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, 8 * (size_t)(nq + 2));
     if (!chain) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: device workspace exhausted");
     if (d_payload_index)
-        return cm_spmm_csr_sliced_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, d_payload_index, n_out,
+        return cm_spmm_csr_sliced_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_ref, d_payload_index, n_out,
                                       d_out_indptr, d_out_cols, d_out_vals, capacity, d_row_order, chain, d_out_rows);
     return cm_spmm_csr_fused_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_out, d_out_indptr, d_out_cols,
                                  d_out_vals, capacity, d_row_order, chain, d_out_rows);
@@ -392,10 +392,13 @@ cm_status cm_payload_index_dev(cm_handle_t h, const int64_t *d_b_indptr, const i
         CM_FAIL(h, CM_E_INVALID, "payload index: the single-pass product covers 1 .. 32768 output columns (got %lld)", (long long)n_out);
     int *flag = (int *)cm_ws_alloc(h, 64);
     if (!flag) CM_FAIL(h, CM_E_NOMEM, "payload index: device workspace exhausted");
+    h->a3_index = nullptr;   // (an index rebuilt at the same address: the header kept on the handle is stale)
     CM_TRY(cm_payload_index_run(h, d_b_indptr, d_b_cols, n_ref, n_out, d_index, flag));
     int bad = 0;
     CM_HIP(h, hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, h->stream));
     CM_TRY(sync(h));
+    int max_slice; long long nnz;
+    CM_TRY(cm_payload_index_header(h, d_index, &max_slice, &nnz));
     if (bad)
         CM_FAIL(h, CM_E_INVALID, "payload index: every payload row needs strictly ascending column indices inside [0, n_out) "
                                  "(canonical CSR: scipy's sum_duplicates() / sort_indices())");

@@ -19,6 +19,9 @@ struct cm_handle_s {
     size_t ws_off = 0;
     int64_t knn_stats[4] = {0, 0, 0, 0};
     int n_cu = 0;   // compute units of the device (lazily queried)
+    const void *a3_index = nullptr;   // last payload index whose header this handle has read (A3, wave-sliced kernel)
+    int a3_max_slice = 0;             // ... its longest (payload row, column bucket) slice
+    long long a3_nnz = 0, a3_rows = 0;
     // staged search: the filter level that certified most queries on the previous call with this (d, k, metric); lets
     // repeated calls on similar data skip the pilot (a stale hint only costs time: the ladder still escalates)
     int staged_hint_level = 0, staged_hint_d = 0, staged_hint_k = 0, staged_hint_metric = 0;
@@ -117,10 +120,11 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
 bool cm_spmm_csr_single_pass_ok(int64_t n_out);
 int cm_a3_bucket_width(int64_t n_out);
 int64_t cm_payload_index_len_impl(int64_t n_ref, int64_t n_out);
+cm_status cm_payload_index_header(cm_handle_t h, const int32_t *d_index, int *max_slice, long long *nnz);
 cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32_t *d_bcols, int64_t n_ref, int64_t n_out,
                                int32_t *d_index, int *d_flag);
 cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
-                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_ref,
                                  const int32_t *d_index, int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols,
                                  float *d_out_vals, int64_t capacity, const int32_t *d_order, unsigned long long *d_chain,
                                  int32_t *d_out_rows);

@@ -890,13 +890,14 @@ __device__ __forceinline__ int a3_bucket_width(int n_out) {   // (same formula o
 
 // idx[j][b], b = 0..nb: number of entries of payload row j with column < b W.  One wave per row; also checks that the
 // row's columns are strictly ascending and inside [0, n_out) (flag[0] = 1 otherwise).
+constexpr int A3_HDR = 8;   // header words of a payload index: [0] longest slice, [1] bucket width, [2..3] non-zeros (int64), rest 0
 __global__ __launch_bounds__(256) void payload_index(const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols, int64_t n_ref,
                                                      int n_out, int W, int nb, int32_t *__restrict__ idx, int *__restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_ref) return;
     const int64_t lo = bptr[j], hi = bptr[j + 1];
-    int32_t *out = idx + j * (nb + 1);
+    int32_t *out = idx + A3_HDR + j * (nb + 1);
     const int len = (int)(hi - lo);
     if (hi < lo || hi - lo > 0x7fffffffLL) { if (lane == 0) flag[0] = 1; return; }
     if (len == 0) { for (int b = lane; b <= nb; b += 64) out[b] = 0; return; }
@@ -912,19 +913,41 @@ __global__ __launch_bounds__(256) void payload_index(const int64_t *__restrict__
     }
     if (__ballot(bad) != 0ull && lane == 0) flag[0] = 1;
 }
+// header: the longest slice (decides how many entries per lane the product kernel keeps in registers) and the entry count
+__global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb, int W, int32_t *__restrict__ idx) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) idx[1] = W;
+    int mx = 0; long long nz = 0;
+    if (j < n_ref) {
+        const int32_t *r = idx + A3_HDR + j * (nb + 1);
+        for (int b = 0; b < nb; ++b) { const int l = r[b + 1] - r[b]; mx = l > mx ? l : mx; }
+        nz = r[nb];
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) { const int o = __shfl_xor(mx, sft); mx = o > mx ? o : mx; nz += __shfl_xor(nz, sft); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(idx + 0, mx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(idx + 2), (unsigned long long)nz);
+    }
+}
 
+template <int EPL>
 __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
                                                       const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
-                                                      const float *__restrict__ bvals, const int32_t *__restrict__ bidx, int nb1,
+                                                      const float *__restrict__ bvals, const int32_t *__restrict__ bidx_, int nb1,
                                                       int n_out, int W, int64_t *out_indptr, int32_t *__restrict__ ocols,
                                                       float *__restrict__ ovals, const int32_t *__restrict__ order,
                                                       unsigned long long *chain, int64_t capacity, int32_t *__restrict__ out_rows) {
+    // EPL entries per lane and neighbour are held in registers (slices of up to 64 EPL entries; longer ones take a scalar
+    // loop), NBATCH = 16 / EPL neighbours per register set: the same 2 x 32 registers of payload in flight per lane
+    constexpr int NBATCH = 16 / EPL;
+    const int32_t *__restrict__ bidx = bidx_ + A3_HDR;
     extern __shared__ __align__(16) unsigned char smem[];
     float *acc = reinterpret_cast<float *>(smem);                       // [8 W]
     int *wsum = reinterpret_cast<int *>(acc + 8 * W);                   // [2][8] wave totals (by row parity)
     long long *tk = reinterpret_cast<long long *>(wsum + 16);           // [0] ticket of the row after next, [1] the row's first entry
-    float *dummy = reinterpret_cast<float *>(tk + 2);                   // [128] where lanes without an entry do their add
+    float *dummy = reinterpret_cast<float *>(tk + 2);                   // [512] where lanes without an entry do their add
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wlo = wave * W, whi = (wlo + W < n_out) ? wlo + W : n_out;   // this wave's output columns (possibly none)
     const int dix = (int)(dummy - acc) + lane;
@@ -998,12 +1021,12 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             for (int c = lane; c < W / 4; c += 64) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (!ticketed) stage1(g);
-        // ---- the gather: batches of SLC_NB neighbours, two register sets
+        // ---- the gather: batches of NBATCH neighbours, two register sets
         const int nn = cur.deg < 128 ? cur.deg : 128;
-        int ca[SLC_NB][2], cb[SLC_NB][2];
-        float va[SLC_NB][2], vb[SLC_NB][2];
+        int ca[NBATCH][EPL], cb[NBATCH][EPL];
+        float va[NBATCH][EPL], vb[NBATCH][EPL];
         struct BM { int slo, shi, len; float a; int base; };
-        auto pick = [&](int ub) {   // the metadata registers that hold neighbours ub .. ub + 7 (ub is a multiple of 8)
+        auto pick = [&](int ub) {   // the metadata registers that hold neighbours ub .. ub + NBATCH - 1 (ub is a multiple of NBATCH)
             BM m;
             const bool hi = ub >= 64, none = ub >= 128;
             m.slo = hi ? cur.slo[1] : cur.slo[0];
@@ -1019,35 +1042,40 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             st = ((int64_t)__builtin_amdgcn_readlane(m.shi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(m.slo, l);
             wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m.a), l));
         };
-        auto load_batch = [&](int (&cc)[SLC_NB][2], float (&vv)[SLC_NB][2], const BM &bm) {
+        auto load_batch = [&](int (&cc)[NBATCH][EPL], float (&vv)[NBATCH][EPL], const BM &bm) {
 #pragma unroll
-            for (int n = 0; n < SLC_NB; ++n) {
+            for (int n = 0; n < NBATCH; ++n) {
                 int64_t st; int len; float wa;
                 uni(bm, n, st, len, wa);
                 const bool has = len > 0;
                 const int32_t *pc = has ? bcols + st : reinterpret_cast<const int32_t *>(indptr);
                 const float *pv = has ? bvals + st : reinterpret_cast<const float *>(indptr);
                 const int last = has ? len - 1 : 0;
-                const unsigned o_0 = (unsigned)min(lane, last) << 2, o_1 = (unsigned)min(lane + 64, last) << 2;
-                cc[n][0] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_0);
-                vv[n][0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_0);
-                cc[n][1] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_1);
-                vv[n][1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_1);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const unsigned o_ = (unsigned)min(lane + 64 * e, last) << 2;
+                    cc[n][e] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(pc) + o_);
+                    vv[n][e] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pv) + o_);
+                }
             }
         };
-        auto apply_batch = [&](int (&cc)[SLC_NB][2], float (&vv)[SLC_NB][2], const BM &bm) {
+        auto apply_batch = [&](int (&cc)[NBATCH][EPL], float (&vv)[NBATCH][EPL], const BM &bm) {
 #pragma unroll
-            for (int n = 0; n < SLC_NB; ++n) {
+            for (int n = 0; n < NBATCH; ++n) {
                 int64_t st; int len; float wa;
                 uni(bm, n, st, len, wa);
                 if (len > 0) {   // (uniform)
-                    const bool p_0 = lane < len, p_1 = lane + 64 < len;
-                    float *a_0 = acc + (p_0 ? cc[n][0] : dix), *a_1 = acc + (p_1 ? cc[n][1] : dix + 64);
-                    const float x_0 = *a_0, x_1 = *a_1;
-                    *a_0 = __fadd_rn(x_0, __fmul_rn(wa, vv[n][0]));
-                    *a_1 = __fadd_rn(x_1, __fmul_rn(wa, vv[n][1]));
-                    if (len > 128) {   // (uniform) a slice longer than 128 entries
-                        for (int t = 128 + lane; t < len; t += 64) {
+                    // the entries of one neighbour row have distinct columns: all reads go out before the writes
+                    float *ap_[EPL]; float x_[EPL];
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        ap_[e] = acc + (lane + 64 * e < len ? cc[n][e] : dix + 64 * e);
+                        x_[e] = *ap_[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) *ap_[e] = __fadd_rn(x_[e], __fmul_rn(wa, vv[n][e]));
+                    if (len > 64 * EPL) {   // (uniform) a slice longer than the registers hold
+                        for (int t = 64 * EPL + lane; t < len; t += 64) {
                             float *ap = acc + bcols[st + t];
                             *ap = __fadd_rn(*ap, __fmul_rn(wa, bvals[st + t]));
                         }
@@ -1057,12 +1085,12 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
         };
         BM ma = pick(0), mb;
         load_batch(ca, va, ma);
-        for (int ub = 0; ub < nn; ub += 2 * SLC_NB) {
-            mb = pick(ub + SLC_NB);
+        for (int ub = 0; ub < nn; ub += 2 * NBATCH) {
+            mb = pick(ub + NBATCH);
             load_batch(cb, vb, mb);
             apply_batch(ca, va, ma);
             if (ub == 0 && !ticketed) stage2(g);
-            ma = pick(ub + 2 * SLC_NB);
+            ma = pick(ub + 2 * NBATCH);
             load_batch(ca, va, ma);
             apply_batch(cb, vb, mb);
         }
@@ -1175,7 +1203,7 @@ int64_t cm_payload_index_len_impl(int64_t n_ref, int64_t n_out) {
     if (n_ref < 0 || n_out < 1 || n_out > SPG_CT) return -1;
     const int W = cm_a3_bucket_width(n_out);
     const int nb = (int)((n_out + W - 1) / W);
-    return n_ref * (nb + 1);
+    return A3_HDR + n_ref * (nb + 1);
 }
 // d_flag: one int of scratch, 1 afterwards if a payload row is not canonical (columns strictly ascending, inside [0, n_out))
 cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32_t *d_bcols, int64_t n_ref, int64_t n_out,
@@ -1184,14 +1212,31 @@ cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32
     const int W = cm_a3_bucket_width(n_out);
     const int nb = (int)((n_out + W - 1) / W);
     CM_HIP(h, hipMemsetAsync(d_flag, 0, 4, h->stream));
-    if (n_ref > 0)
+    CM_HIP(h, hipMemsetAsync(d_index, 0, 4 * A3_HDR, h->stream));
+    if (n_ref > 0) {
         hipLaunchKernelGGL(payload_index, dim3((unsigned)((n_ref + 3) / 4)), dim3(256), 0, h->stream, d_bptr, d_bcols, n_ref, (int)n_out, W, nb,
                            d_index, d_flag);
+        hipLaunchKernelGGL(payload_index_stats, dim3((unsigned)((n_ref + 255) / 256)), dim3(256), 0, h->stream, n_ref, nb, W, d_index);
+    }
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
+// The header of an index (host copy): read once per index and kept on the handle.
+cm_status cm_payload_index_header(cm_handle_t h, const int32_t *d_index, int *max_slice, long long *nnz) {
+    if (h->a3_index != d_index) {
+        int32_t hdr[A3_HDR];
+        CM_HIP(h, hipMemcpyAsync(hdr, d_index, sizeof(hdr), hipMemcpyDeviceToHost, h->stream));
+        CM_HIP(h, hipStreamSynchronize(h->stream));
+        h->a3_index = d_index;
+        h->a3_max_slice = hdr[0];
+        h->a3_nnz = (long long)(((unsigned long long)(uint32_t)hdr[3] << 32) | (uint32_t)hdr[2]);
+    }
+    *max_slice = h->a3_max_slice;
+    *nnz = h->a3_nnz;
+    return CM_OK;
+}
 cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
-                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
+                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals, int64_t n_ref,
                                  const int32_t *d_index, int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols,
                                  float *d_out_vals, int64_t capacity, const int32_t *d_order, unsigned long long *d_chain,
                                  int32_t *d_out_rows) {
@@ -1200,7 +1245,14 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     if (d_out_rows && nq >= (1LL << 24)) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: rows in completion order: at most 2^24 - 1 rows per call");
     const int W = cm_a3_bucket_width(n_out);
     const int nb = (int)((n_out + W - 1) / W);
-    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 512;
+    // entries per lane held in registers: enough for the longest slice when that is at most 512 entries, else for 1.5 x the
+    // mean slice (longer slices take the scalar loop)
+    int max_slice = 0; long long nnz = 0;
+    CM_TRY(cm_payload_index_header(h, d_index, &max_slice, &nnz));
+    int want = max_slice;
+    if (max_slice > 512 && n_ref > 0) want = (int)std::min<long long>(512, (3 * nnz) / (2 * n_ref * nb) + 1);
+    const int epl = want <= 128 ? 2 : (want <= 256 ? 4 : 8);
+    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 2048;
     if (h->n_cu <= 0) {
         hipDeviceProp_t pr;
         CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
@@ -1208,7 +1260,7 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 1024)));
     const unsigned grid = (unsigned)std::min<int64_t>(nq, (int64_t)h->n_cu * per_cu);
-    auto kern = spgemm_sliced;
+    auto kern = epl == 2 ? spgemm_sliced<2> : (epl == 4 ? spgemm_sliced<4> : spgemm_sliced<8>);
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, d_index, nb + 1,

@@ -234,8 +234,10 @@ def test_spgemm_sliced_kernel_shapes(oracle):
     pipe = DevicePipeline(0)
     dev = pipe.device
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    # (slices of ~225 entries: 4 per lane in registers; > 128 neighbours; 2 buckets for 8 waves; short slices; slices of ~130..250;
+    #  slices of ~700 entries: 8 per lane + the scalar loop)
     for seed, (n_ref, nq, k, n_out, density) in enumerate([(120, 300, 7, 3000, 0.6), (400, 150, 200, 900, 0.05), (60, 200, 4, 90, 0.3),
-                                                            (80, 100, 3, 1000, 0.2)]):
+                                                            (80, 100, 3, 1000, 0.2), (100, 200, 5, 4000, 0.35), (50, 120, 4, 8000, 0.7)]):
         rng = np.random.default_rng(90 + seed)
         indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
         B = sp.random(n_ref, n_out, density=density, format="csr", dtype=np.float32, random_state=rng)
