@@ -131,7 +131,7 @@ def main():
                       open(os.path.join(P, "phase1_hbm_traffic.json"), "w"), indent=1)
         mfma_block(f, "d128", "knn_cand_f16", "config 4's per-GPU share: 1.5 M x 1.5 M x d=128 (K = 128 kernel)")
         for tag, kern, what, bpq in (("c3", "spmm_wide", "A2 dense layer product, 300 k queries x 20 000 genes, k=30", lambda b: b["roofline"]["bytes_per_query"] * b["config"]["nq"]),
-                                     ("c5", "spgemm_rows", "A3 sparse layer product (count + fill), 400 k cells x 30 000 genes, k=90", lambda b: b["roofline"]["algorithmic_bytes"])):
+                                     ("c5", "spgemm_sliced", "A3 sparse layer product (single pass, wave-sliced), 400 k cells x 30 000 genes, k=90", lambda b: b["roofline"]["algorithmic_bytes"])):
             tr = traffic(tag, kern, largest=False)
             b = bench_line(f"trace_{tag}")
             f.write(f"## {kern} -- {what}\n\n")
