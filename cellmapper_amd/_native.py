@@ -21,7 +21,9 @@ BUILD_HINT = (
 )
 
 CM_F32, CM_F64 = 0, 1
-METRICS = {"euclidean": 0, "l2": 0, "cosine": 1}
+# metric names as sklearn spells them (the reference hands `metric` to sklearn, knn.py:343,429); minkowski: p = 2, its default
+METRICS = {"euclidean": 0, "l2": 0, "minkowski": 0, "cosine": 1, "manhattan": 2, "cityblock": 2, "l1": 2, "chebyshev": 3, "infinity": 3}
+SUPPORTED_METRICS_TEXT = "euclidean / l2 / minkowski (p = 2), cosine, manhattan / cityblock / l1, chebyshev / infinity"
 FORMS = {"auto": 0, "gemm": 1, "direct": 2}
 KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
 CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK, CM_KNN_F64_OUT = 1, 2, 4
@@ -192,7 +194,7 @@ class Handle:
     # ------------------------------------------------------------------ host tier (numpy in / numpy out)
     def knn(self, ref: np.ndarray, qry: np.ndarray, k: int, metric: str = "euclidean", form: str = "auto"):
         if metric not in METRICS:
-            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: {SUPPORTED_METRICS_TEXT}).")
         ref = np.ascontiguousarray(ref)
         qry = np.ascontiguousarray(qry)
         if ref.ndim != 2 or qry.ndim != 2 or ref.shape[1] != qry.shape[1]:
@@ -424,7 +426,7 @@ class DeviceGraph:
 
     def __init__(self, handle: Handle, ref: DeviceRep, qry: DeviceRep, k: int, metric: str = "euclidean", form: str = "auto"):
         if metric not in METRICS:
-            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: {SUPPORTED_METRICS_TEXT}).")
         if ref.shape[1] != qry.shape[1]:
             raise ValueError(f"Incompatible representation shapes {ref.shape} and {qry.shape}.")
         self.h = handle

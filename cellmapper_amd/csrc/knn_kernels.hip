@@ -16,6 +16,7 @@
 cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
 // grid_knn.hip: uniform-grid candidate search for d <= 3
 size_t cm_grid_ws_bytes(int64_t n_ref, int64_t ncell_max);
 int64_t cm_grid_ncell_max(int64_t n_ref, int k);
@@ -356,6 +357,7 @@ __global__ void prep_rows_lowd(const T *__restrict__ X, int64_t n, int d, int64_
 //   GEMM form   : (|q|^2 + (-2 * q.y)) + |y|^2 with fma chains, clamped at 0      (EuclideanArgKmin)
 //   DIRECT form : sum_j (q_j - y_j)^2, multiply and add rounded separately        (KDTree rdist)
 //   cosine      : clip(1 - q.y / (|q| |y|), 0, 2)                                 (pairwise cosine_distances)
+//   manhattan / chebyshev : sum / max of |q_j - y_j| in coordinate order           (DistanceMetric dist, see below)
 template <typename T>
 __device__ __forceinline__ double pair_value(const double *__restrict__ q, double xn, const T *__restrict__ y, int d,
                                              int metric, int form) {
@@ -367,6 +369,18 @@ __device__ __forceinline__ double pair_value(const double *__restrict__ q, doubl
         if (!(ny > 0.0)) ny = 1.0;
         double s = 1.0 - dot / (nx * ny);
         return s < 0.0 ? 0.0 : (s > 2.0 ? 2.0 : s);
+    }
+    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
+        // sklearn's DistanceMetric: |q_j - y_j| joins a float64 accumulator in coordinate order.  Brute force on float32 data
+        // (DistanceMetric32) takes the difference in float32 and returns a float32: one more rounding of the result.  The
+        // kd-tree (DIRECT form) works on float64 copies of the data: everything in float64.
+        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
+        double acc = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double t = f32 ? (double)fabsf(__fsub_rn((float)q[c], (float)y[c])) : fabs(q[c] - (double)y[c]);
+            acc = metric == CM_METRIC_MANHATTAN ? __dadd_rn(acc, t) : fmax(acc, t);
+        }
+        return f32 ? (double)(float)acc : acc;
     }
     if (form == CM_FORM_DIRECT) {
         double acc = 0.0;
@@ -533,6 +547,10 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             double dlt = sizeof(T) == 8 ? 2.0 * 5.9604645e-8 * (double)__uint_as_float(gmax[4]) : 0.0;
             double big = fmax(sk, (double)tau);
             double eps = crel * big + 2.0 * dlt * sqrt((double)d) * sqrt(big) + (double)d * dlt * dlt;
+            // sum / max of |q_j - y_j|: a coordinate rounded by dlt moves a term by at most dlt (two coordinates per term);
+            // the float32 rounding of the reported value (DistanceMetric32) is inside crel
+            if (metric == CM_METRIC_MANHATTAN) eps = crel * big + 2.0 * dlt * (double)d;
+            if (metric == CM_METRIC_CHEBYSHEV) eps = crel * big + 2.0 * dlt;
             certified = sk + eps < (double)tau - eps;
         }
         if (!certified || over || (flags & CM_KNN_FORCE_FALLBACK)) {
@@ -1390,7 +1408,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                          int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int bs = 256;
-    const int path = phase1_path(d, k);
+    const bool lp_metric = metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV;
+    const int path = lp_metric ? 2 : phase1_path(d, k);   // (Manhattan / Chebyshev: the VALU direct kernel is the only filter)
     // dynamic LDS of prep_rows_f16 when a block's source rows fit (64 KB without opting in): coalesced staging
     const size_t prep_lds = (size_t)bs * (d + 1) * sizeof(T) <= 64 * 1024 ? (size_t)bs * (d + 1) * sizeof(T) : 0;
     const bool wide = path == 3;     // 62 <= d <= 128: K = 128 kernels, no direct level
@@ -1680,6 +1699,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         bool pruned = false;
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
+            if (level == 4 && lp_metric) return cm_p1lowd_metric_launch(h, dl, metric == CM_METRIC_MANHATTAN ? 1 : 2, p2.grid, p2.lds, x);
             if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
             if (w3) return cm_p1f16w_launch(h, p2.grid, p2.lds, x);
             if (q4 && !x.wlist && !x.seed_len) {
@@ -2023,7 +2043,7 @@ template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
-    if (phase1_path(d, k) != 0)
+    if (phase1_path(d, k) != 0 || metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV)
         return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     KnnPlan p;
     CM_TRY(make_plan(h, n_ref, nq, d, k, &p));
@@ -2146,7 +2166,14 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
     if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
     if (d > RR_DMAX - 1) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, RR_DMAX - 1);
-    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE) CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
+    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV)
+        CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
+    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
+        if (lowd_dpad(d) > 64)
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev metrics are provided for up to 64 dimensions (got %d)", d);
+        if (k + knn_slack(k) + 2 * cmk2::CL > 512)
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors = %d is too large for the manhattan / chebyshev metrics", k);
+    }
     if (form == CM_FORM_AUTO) form = (d > 15 || k >= n_ref / 2) ? CM_FORM_GEMM : CM_FORM_DIRECT;
     if (nq == 0) return CM_OK;
     if (dtype == CM_F32)

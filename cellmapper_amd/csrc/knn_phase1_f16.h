@@ -901,7 +901,8 @@ constexpr int BRL = 512;  // reference rows per tile of the low-d kernel (d <= 1
 __host__ __device__ constexpr int lowd_rows(int D) { return D <= 15 ? BRL : 128; }
 __host__ __device__ constexpr int lowd_tile_bytes(int D) { return lowd_rows(D) * D * 4; }
 
-template <int D>
+// OP: 0 = sum (q - y)^2 (Euclidean), 1 = sum |q - y| (Manhattan), 2 = max |q - y| (Chebyshev: exact in fp32 for fp32 rows).
+template <int D, int OP = 0>
 __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     constexpr int TILEB = lowd_tile_bytes(D);
     constexpr int NCHUNK = TILEB / 1024;
@@ -979,8 +980,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
                     for (int e = 0; e < D; ++e) {
                         const float ye = y[e];
                         const float d0 = q0[e] - ye, d1 = q1[e] - ye;
-                        s0 = fmaf(d0, d0, s0);
-                        s1 = fmaf(d1, d1, s1);
+                        if (OP == 0) { s0 = fmaf(d0, d0, s0); s1 = fmaf(d1, d1, s1); }
+                        else if (OP == 1) { s0 += fabsf(d0); s1 += fabsf(d1); }
+                        else { s0 = fmaxf(s0, fabsf(d0)); s1 = fmaxf(s1, fabsf(d1)); }
                     }
                     acc0[rr] = s0;
                     acc1[rr] = s1;

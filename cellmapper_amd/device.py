@@ -53,7 +53,7 @@ class DevicePipeline:
         """``out=(dist, idx)``: caller-provided contiguous [nq, k] tensors (e.g. planes of a packed exchange buffer)."""
         t = self.torch
         nq = qry.shape[0]
-        out_dt = t.float64 if (METRICS[metric] == 0 or f64_out) else ref.dtype
+        out_dt = t.float64 if (METRICS[metric] != 1 or f64_out) else ref.dtype   # (sklearn: float32 cosine stays float32)
         if out is None:
             dist = t.empty((nq, k), dtype=out_dt, device=self.device)
             idx = t.empty((nq, k), dtype=t.int64, device=self.device)

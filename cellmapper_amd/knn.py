@@ -199,7 +199,7 @@ class Neighbors:
                     n_neighbors)
         h = _native.default_handle()
         if metric not in _native.METRICS:
-            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: euclidean, cosine).")
+            raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: {_native.SUPPORTED_METRICS_TEXT}).")
         nx, ny = self.xrep.shape[0], self.yrep.shape[0]
         # both representations go to the device ONCE (same dtype rule as the host tier: float32 only if both are);
         # the results stay there (NeighborsResults materialises numpy arrays on first access)

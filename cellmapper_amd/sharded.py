@@ -46,7 +46,8 @@ class HipOps:
 
     def local_knn_packed(self, ref_shard, qry, k, metric, idx_offset, nq_pad):
         """Local exact top-k written straight into the PACKED exchange buffer ``[2, nq_pad, k]`` of 8-byte words:
-        plane 0 = float64 ranking values (squared for euclidean, float64 cosine distances), plane 1 = int64 global indices.
+        plane 0 = float64 ranking values (squared for euclidean; float64 cosine / manhattan / chebyshev distances), plane 1 = int64
+        global indices.
         One buffer = one collective per exchange.  Padded rows are zero (never merged: slices are cut at nq)."""
         t = self.t
         nq = qry.shape[0]
@@ -58,7 +59,7 @@ class HipOps:
 
     def merge_packed(self, buf, nparts, part_stride, dist_off, idx_off, nq, k, metric):
         """k-way merge of ``nparts`` lists per query living in one packed buffer (offsets / stride in 8-byte words)."""
-        return self.p.merge_strided(buf, nparts, part_stride, dist_off, idx_off, nq, k, sqrt_out=(metric != "cosine"))
+        return self.p.merge_strided(buf, nparts, part_stride, dist_off, idx_off, nq, k, sqrt_out=(metric == "euclidean"))
 
     def moments(self, dist, idx, center=None):
         return self.p.moments(dist, idx, center)
@@ -108,7 +109,7 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int):
     return mine
 
 
-SUPPORTED_METRICS = ("euclidean", "cosine")
+SUPPORTED_METRICS = ("euclidean", "cosine", "manhattan", "chebyshev")
 
 
 def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, codes, n_cat, metric="euclidean",
@@ -126,7 +127,7 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
     for float32 input), so the merged order -- and therefore every index -- equals the unsharded result.
     """
     if metric not in SUPPORTED_METRICS:
-        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, cosine).")
+        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, cosine, manhattan, chebyshev).")
     n_all = dist_mod.get_world_size()
     world = n_all if ref_world is None else ref_world
     rank = dist_mod.get_rank() if ref_rank is None else ref_rank

@@ -49,6 +49,13 @@ typedef enum {
 /* metric (knn.py:343 `metric`, passed to sklearn.neighbors.NearestNeighbors, knn.py:429) */
 #define CM_METRIC_EUCLIDEAN 0
 #define CM_METRIC_COSINE 1
+/* Metric pass-through of the reference (knn.py:343,429 hands `metric` to sklearn): the two other Minkowski-family metrics
+ * sklearn's trees and brute force share.  Exact like the rest (float64 re-rank in sklearn's arithmetic -- for float32 data
+ * brute force the coordinate difference is a float32 and the distance is rounded to float32 once, as DistanceMetric32
+ * does -- certificate, fallback); the filter is the fp32 VALU direct-difference kernel, so they are VALU-bound, and the
+ * row width is limited to d <= 64.  CM_E_UNSUPPORTED beyond that. */
+#define CM_METRIC_MANHATTAN 2
+#define CM_METRIC_CHEBYSHEV 3
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt

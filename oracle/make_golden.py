@@ -248,6 +248,29 @@ def main():
         np.savez_compressed(os.path.join(OUT, "joint_embedding.npz"), **joint_embedding_case(utils_mod))
         print("joint_embedding.npz written")
         return
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "metrics":
+        # metric pass-through (knn.py:343,429 hands `metric` to sklearn): manhattan and chebyshev, brute force (d = 50,
+        # float32 and float64) and kd_tree (d = 2 self-mapping, d = 10 two-sample)
+        def synth_(seed, n_ref, nq, dd, dtype):
+            rng_ = np.random.default_rng(seed)
+            return rng_.standard_normal((n_ref, dd)).astype(dtype), rng_.standard_normal((nq, dd)).astype(dtype)
+        xr, yr = synth_(20, 1536, 192, 50, np.float32)
+        xr64, yr64 = synth_(21, 1024, 128, 50, np.float64)
+        xr10, yr10 = synth_(22, 1500, 100, 10, np.float32)
+        coords = np.random.default_rng(23).uniform(0, 2000, (1500, 2)).astype(np.float32)
+        cases = {
+            "synth_f32_manhattan_k15": (xr, yr, 15, "manhattan", "X_emb"),
+            "synth_f64_manhattan_k30": (xr64, yr64, 30, "manhattan", "X_emb"),
+            "synth_f32_chebyshev_k15": (xr, yr, 15, "chebyshev", "X_emb"),
+            "synth_f64_chebyshev_k15": (xr64, yr64, 15, "chebyshev", "X_emb"),
+            "synth_d10_manhattan_k15": (xr10, yr10, 15, "manhattan", "X_emb"),
+            "spatial32_self_manhattan_k20": (coords, coords, 20, "manhattan", "spatial"),
+            "spatial32_self_chebyshev_k20": (coords, coords, 20, "chebyshev", "spatial"),
+        }
+        for name, (a_, b_, k_, m_, key_) in cases.items():
+            np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_mapping_case(cm_mod, name, a_, b_, k_, metric=m_, rep_key=key_, G=24))
+            print(name, "written")
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "expr_eval":
         np.savez_compressed(os.path.join(OUT, "expr_eval.npz"), **expr_eval_case())
         print("expr_eval.npz written")

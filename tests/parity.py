@@ -36,6 +36,10 @@ def exact_dist(ref, qry_row, cols, metric):
         rn = r / np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-300)
         qn = q / max(np.linalg.norm(q), 1e-300)
         return np.clip(1.0 - rn @ qn, 0.0, 2.0)
+    if metric == "manhattan":
+        return np.abs(r - q).sum(1)
+    if metric == "chebyshev":
+        return np.abs(r - q).max(1)
     return np.sqrt(((r - q) ** 2).sum(1))
 
 

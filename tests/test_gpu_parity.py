@@ -730,3 +730,43 @@ def test_weights_and_vote_row_groupings(hip, oracle, k):
         ocode, oconf = oracle.label_vote(oip, oc, ov32, codes, 11)
         np.testing.assert_allclose(conf, oconf, rtol=1e-5)
         assert (code != ocode).mean() < 2e-3                    # top-2 class sums within float32 rounding
+
+
+@pytest.mark.parametrize("metric,dtype,d,n_ref,nq,k", [
+    ("manhattan", np.float32, 50, 12000, 700, 30),      # brute force: float32 differences, distance rounded to float32
+    ("manhattan", np.float64, 33, 9000, 500, 15),
+    ("chebyshev", np.float32, 50, 12000, 700, 30),
+    ("chebyshev", np.float64, 64, 6000, 400, 10),       # the widest row the direct kernel takes
+    ("manhattan", np.float32, 3, 6000, 6000, 20),       # kd-tree arithmetic: float64 copies of the coordinates
+    ("chebyshev", np.float32, 10, 12000, 800, 8),
+])
+def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, nq, k):
+    """knn.py:343,429 hand `metric` to sklearn: manhattan / chebyshev through the VALU direct filter + float64 re-rank must
+    give the oracle's neighbours and distances bit for bit (the oracle is pinned on sklearn by tests/golden/*manhattan*,
+    *chebyshev*).  Duplicated reference rows force exact ties (lowest index first) and some queries through the fallback."""
+    rng = np.random.default_rng(123 + d)
+    ref = (rng.standard_normal((n_ref, d)) * (50.0 if d <= 3 else 1.0)).astype(dtype)
+    ref[100:140] = ref[100]
+    qry = ref.copy() if nq == n_ref else (rng.standard_normal((nq, d)) * (50.0 if d <= 3 else 1.0)).astype(dtype)
+    qry[3] = ref[100]
+    dist, idx = hip.knn(ref, qry, k, metric=metric)
+    od, oi = oracle.knn_minkowski_family(ref, qry, k, metric)
+    assert dist.dtype == np.float64 and np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert idx[3, 0] == 100 and np.all(dist[3, :min(k, 40)] == 0)
+    # aliases as sklearn spells them
+    alias = {"manhattan": "cityblock", "chebyshev": "infinity"}[metric]
+    d2, i2 = hip.knn(ref[:5000], qry[:200], k, metric=alias)
+    d3, i3 = hip.knn(ref[:5000], qry[:200], k, metric=metric)
+    assert np.array_equal(d2, d3) and np.array_equal(i2, i3)
+
+
+def test_metric_passthrough_limits_and_names(hip):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((500, 65)).astype(np.float32)
+    with pytest.raises(NotImplementedError, match="64 dimensions"):
+        hip.knn(x, x[:10], 5, metric="manhattan")
+    with pytest.raises(ValueError, match="not supported"):
+        hip.knn(x, x[:10], 5, metric="braycurtis")
+    d0, i0 = hip.knn(x, x[:10], 5, metric="minkowski")     # sklearn's default p = 2
+    d1, i1 = hip.knn(x, x[:10], 5, metric="euclidean")
+    assert np.array_equal(d0, d1) and np.array_equal(i0, i1)

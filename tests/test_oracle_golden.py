@@ -24,6 +24,8 @@ def test_oracle_matches_reference(name, oracle):
     xrep, yrep = rep(g)
     if metric == "cosine":
         dist, idx = oracle.knn_cosine(xrep, yrep, k)
+    elif metric in ("manhattan", "chebyshev"):
+        dist, idx = oracle.knn_minkowski_family(xrep, yrep, k, metric)
     else:
         dist, idx = oracle.knn_euclidean(xrep, yrep, k)
     assert dist.dtype == g["yx_dist"].dtype

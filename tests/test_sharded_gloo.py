@@ -24,6 +24,10 @@ class OracleOps:
         if metric == "cosine":   # float64 inputs in the test: the oracle's cosine values are already float64
             d, i = self.o.knn_cosine(ref_shard.numpy(), qry.numpy(), k)
             v = d.astype(np.float64)
+        elif metric in ("manhattan", "chebyshev"):
+            # the form (brute force or kd-tree arithmetic) is that of the WHOLE problem; at d = 20 it is brute force either way
+            d, i = self.o.knn_minkowski_family(ref_shard.numpy(), qry.numpy(), k, metric, form="gemm")
+            v = d
         else:
             d, i = self.o.knn_euclidean(ref_shard.numpy(), qry.numpy(), k)
             v = d * d
@@ -40,7 +44,7 @@ class OracleOps:
                       for p in range(nparts)], 1).reshape(nq, -1)
         order = np.lexsort((i, d), axis=1)[:, :k]
         dd = np.take_along_axis(d, order, 1)
-        return (self.t.from_numpy(dd if metric == "cosine" else np.sqrt(dd)),
+        return (self.t.from_numpy(np.sqrt(dd) if metric == "euclidean" else dd),
                 self.t.from_numpy(np.take_along_axis(i, order, 1)))
 
     def moments(self, dist, idx, center=None):
@@ -105,7 +109,7 @@ def test_sharded_rejects_unsupported_metric():
     from cellmapper_amd.sharded import sharded_map_labels
 
     with pytest.raises(ValueError, match="not supported"):
-        sharded_map_labels(None, None, None, 0, 10, None, 3, None, 2, metric="manhattan")
+        sharded_map_labels(None, None, None, 0, 10, None, 3, None, 2, metric="braycurtis")
 
 
 @pytest.mark.parametrize("world,ref_shards,exchange,kernel,metric", [
@@ -115,11 +119,12 @@ def test_sharded_rejects_unsupported_metric():
     (3, 3, "alltoall", "scarches", "euclidean"),       # odd world, ragged slices
     (2, None, "alltoall", "gaussian", "cosine"),       # cosine: merged values are NOT square-rooted
     (3, 3, "allgather", "inverse_distance", "cosine"),
+    (2, None, "alltoall", "gaussian", "manhattan"),    # metric pass-through: merged values are the distances themselves
 ])
 def test_sharded_choreography(world, ref_shards, exchange, kernel, metric, tmp_path, oracle):
     import torch.multiprocessing as mp
 
-    port = 29500 + (os.getpid() % 2000) + world * 7 + (0 if exchange == "alltoall" else 1) + (3 if metric == "cosine" else 0)
+    port = 29500 + (os.getpid() % 2000) + world * 7 + (0 if exchange == "alltoall" else 1) + (3 if metric == "cosine" else (5 if metric == "manhattan" else 0))
     mp.spawn(_worker, args=(world, port, exchange, kernel, str(tmp_path), ref_shards, metric), nprocs=world, join=True)
     rng = np.random.default_rng(0)
     n_ref, nq, d, k, n_cat = 3001, 203, 20, 12, 7
