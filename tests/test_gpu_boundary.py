@@ -29,7 +29,8 @@ def build_pair(g, rep_key="X_emb", sparse_x=False):
 @pytest.mark.parametrize("name,kern", [("synth_f32_k30", "gaussian"), ("synth_f32_k30", "scarches"),
                                        ("synth_f32_k15", "inverse_distance"), ("synth_f32_k30", "equal"),
                                        ("synth_f64_k30", "gaussian"), ("synth_clustered_k30", "gaussian"),
-                                       ("synth_d64_trunc50_k15", "gaussian"), ("synth_d10_k15", "gaussian")])
+                                       ("synth_d64_trunc50_k15", "gaussian"), ("synth_d10_k15", "gaussian"),
+                                       ("synth_f32_manhattan_k15", "gaussian"), ("synth_f64_chebyshev_k15", "gaussian")])
 def test_map_matches_reference(name, kern):
     from cellmapper_amd import CellMapper
 
@@ -37,11 +38,11 @@ def test_map_matches_reference(name, kern):
     qry, ref = build_pair(g)
     cm = CellMapper(qry, ref)
     out = cm.map(obs_keys=["label", "num"], obsm_keys="X_umap", layer_key="X", n_neighbors=int(g["k"]),
-                 use_rep="X_emb", knn_method="sklearn", only_yx=True, mapping_method=kern)
+                 use_rep="X_emb", knn_method="sklearn", metric=str(g["metric"]), only_yx=True, mapping_method=kern)
     assert out is cm and cm.only_yx is True and cm.prediction_postfix == "pred" and cm.confidence_postfix == "conf"
     n = min(50, g["xrep"].shape[1])
     assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, g["yx_dist"], g["yx_idx"], g["xrep"][:, :n],
-                      g["yrep"][:, :n])
+                      g["yrep"][:, :n], str(g["metric"]))
     assert cm.knn.yx.n_targets == ref.n_obs and cm.knn.xx is None
     mm = cm.mapping_matrix
     assert isinstance(mm, csr_matrix) and mm.dtype == np.float32 and mm.shape == (qry.n_obs, ref.n_obs)
@@ -188,7 +189,7 @@ def test_mapping_matrix_setter_and_errors():
     with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
         cm.compute_neighbors(n_neighbors=10**6, use_rep="X_emb")
     with pytest.raises(ValueError, match="not supported"):
-        cm.compute_neighbors(n_neighbors=5, use_rep="X_emb", metric="manhattan")
+        cm.compute_neighbors(n_neighbors=5, use_rep="X_emb", metric="braycurtis")
     cm.map(use_rep="X_emb", n_neighbors=5)  # no keys: warning only
 
 
