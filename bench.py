@@ -66,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--tile", type=int, default=0, help="configs 3/5: query rows per output tile (0 = automatic)")
     ap.add_argument("--ncat", type=int, default=20)
     ap.add_argument("--kernel", default="gaussian")
-    ap.add_argument("--metric", default="euclidean", choices=["euclidean", "cosine"])
+    ap.add_argument("--metric", default="euclidean", choices=["euclidean", "cosine", "manhattan", "chebyshev"])
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--ref-shards", type=int, default=0,
                     help="reference shards R (world = query groups x R); 0 = default (2 when world is even; the whole "
