@@ -150,6 +150,165 @@ __global__ __launch_bounds__(256) void weights_rows(const double *__restrict__ d
     if (gl == 0) cntp[i] = m;
 }
 
+// The same, register-resident (k <= 128 neighbours per row, column indices below 2^25): one row per group of G lanes with S
+// entries per lane.  The kernel above ranks every entry by counting over the row in LDS -- O(k^2) LDS reads and a serial float64
+// row sum that re-reads LDS, 8 % of the HBM roofline at k = 30 and 16 x off it at k = 90.  Here the entries are SORTED by
+// (column, stored position) with a bitonic network across the lanes (keys in registers, partners by lane shuffles), so the
+// output position of an entry is its element index, its weight follows by one shuffle from the lane that loaded it, and
+// the float64 row sum runs over the sorted weights by lane broadcasts in CSR order -- the arithmetic of the kernel above
+// (COO -> CSR conversion + scipy's row normalisation), no LDS traffic.  A row with a duplicated column (legal, rare:
+// precomputed graphs) finishes on one lane through a small LDS scratch: duplicates summed in stored order into the first.
+template <int G, int S>
+__global__ __launch_bounds__(256) void weights_rows_sorted(const double *__restrict__ dist, const int64_t *__restrict__ idx,
+                                                            int64_t nq, int k, int kernel, const double *__restrict__ param_p,
+                                                            double eps, int32_t *__restrict__ cols, float *__restrict__ vals,
+                                                            int32_t *__restrict__ cntp, double *__restrict__ conn) {
+    constexpr int N = G * S, RPB = 256 / G;
+    constexpr unsigned KINV = 0xffffffffu;
+    __shared__ int s_col[RPB][N];
+    __shared__ double s_w[RPB][N];
+    const int lane = threadIdx.x & 63, gl = threadIdx.x % G, g = threadIdx.x / G, gbase = lane & ~(G - 1);
+    const int64_t i = (int64_t)blockIdx.x * RPB + g;
+    const bool live = i < nq;
+    const double param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? *param_p : 0.0;
+    const double two_s2 = 2.0 * (param * param);
+    unsigned key[S];
+    double w[S];
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl) {
+        const int e = sl * G + gl;
+        key[sl] = KINV;
+        w[sl] = 0.0;
+        if (live && e < k) {
+            const double dd = dist[i * k + e];
+            const int64_t c = idx[i * k + e];
+            if (c != -1 && isfinite(dd)) {
+                double wt;
+                switch (kernel) {
+                case CM_KERNEL_GAUSSIAN: wt = exp(-(dd * dd) / two_s2); break;
+                case CM_KERNEL_SCARCHES: wt = exp(-dd / param); break;
+                case CM_KERNEL_INVERSE_DISTANCE: wt = 1.0 / (dd + eps); break;
+                case CM_KERNEL_IDENTITY: wt = dd; break;
+                default: wt = 1.0;
+                }
+                w[sl] = wt;
+                key[sl] = ((unsigned)c << 7) | (unsigned)e;
+            }
+        }
+    }
+    // ---- bitonic sort of the N keys of a row (element index = slot * G + lane of the group), ascending
+#pragma unroll
+    for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= G) {   // (S == 2, last merge: the partner is the lane's other slot, ascending)
+                const unsigned lo = key[0] < key[S - 1] ? key[0] : key[S - 1], hi = key[0] < key[S - 1] ? key[S - 1] : key[0];
+                key[0] = lo; key[S - 1] = hi;
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) {
+                    const unsigned other = (unsigned)__shfl_xor((int)key[sl], j, 64);
+                    const int e = sl * G + gl;
+                    const bool asc = (e & kk) == 0, lower = (gl & j) == 0;
+                    const unsigned mn = key[sl] < other ? key[sl] : other, mx = key[sl] < other ? other : key[sl];
+                    key[sl] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+    // ---- the sorted entries: column, weight (from the lane and slot that loaded it), duplicates
+    int col[S];
+    double ws[S];
+    bool valid[S];
+    int m = 0;
+    bool dup = false;
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl) {
+        valid[sl] = key[sl] != KINV;
+        col[sl] = (int)(key[sl] >> 7);
+        const int pos = (int)(key[sl] & 127u), srcl = gbase | (pos & (G - 1));
+        double v = __shfl(w[0], srcl, 64);
+        if (S > 1) { const double v1 = __shfl(w[S - 1], srcl, 64); v = pos >= G ? v1 : v; }
+        ws[sl] = valid[sl] ? __dadd_rn(0.0, v) : 0.0;
+        unsigned long long bal = __ballot(valid[sl]);
+        if (G == 32) bal = (bal >> gbase) & 0xffffffffull;
+        m += __popcll(bal);
+    }
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl) {
+        int prev = __shfl_up(col[sl], 1, G);                     // element e - 1 (same slot)
+        if (sl > 0) { const int last = __shfl(col[sl - 1], gbase | (G - 1), 64); prev = gl == 0 ? last : prev; }
+        const int e = sl * G + gl;
+        dup = dup || (valid[sl] && e > 0 && prev == col[sl]);
+    }
+    unsigned long long dbal = __ballot(dup);
+    if (G == 32) dbal = (dbal >> gbase) & 0xffffffffull;
+    if (dbal == 0ull) {
+        // float64 row sum in CSR order (scipy csr_matvec against ones), zero -> 1, multiply by the reciprocal
+        // (the sorted weights reach every lane through scalar registers: v_readlane with a uniform index, no LDS crossbar)
+        auto bcast = [](double x, int l) {
+            const long long b = __double_as_longlong(x);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        double sum = 0.0;
+        if (G == 64) {
+            const int m0 = m < 64 ? m : 64;
+            for (int r = 0; r < m0; ++r) sum = sum + bcast(ws[0], r) * 1.0;
+            if (S > 1) for (int r = 64; r < m; ++r) sum = sum + bcast(ws[S - 1], r - 64) * 1.0;
+        } else {   // two rows per wave: the row of the lower half in lanes 0..31, of the upper half in lanes 32..63
+            const int ma = __builtin_amdgcn_readlane(m, 0), mb = __builtin_amdgcn_readlane(m, 32);
+            const int mm = ma > mb ? ma : mb;
+            for (int r = 0; r < mm; ++r) {
+                const double va = bcast(ws[0], r), vb = bcast(ws[0], 32 + r);
+                const double v = lane < 32 ? va : vb;
+                sum = r < m ? sum + v * 1.0 : sum;
+            }
+        }
+        if (sum == 0.0) sum = 1.0;
+        const double rinv = 1.0 / sum;
+        if (live) {
+#pragma unroll
+            for (int sl = 0; sl < S; ++sl) {
+                const int e = sl * G + gl;
+                if (e < k) {
+                    const bool on = e < m;
+                    cols[i * k + e] = on ? col[sl] : 0;
+                    vals[i * k + e] = on ? (float)(ws[sl] * rinv) : 0.f;
+                    if (conn) conn[i * k + e] = on ? ws[sl] : 0.0;
+                }
+            }
+            if (gl == 0) cntp[i] = m;
+        }
+    } else {
+        // a duplicated column in this row: one lane merges the sorted run (summing in stored order into the first occurrence)
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) { s_col[g][sl * G + gl] = col[sl]; s_w[g][sl * G + gl] = ws[sl]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (live && gl == 0) {
+            int p = 0;
+            for (int r = 0; r < m; ++r) {
+                if (r > 0 && s_col[g][r] == s_col[g][p - 1]) s_w[g][p - 1] = s_w[g][p - 1] + s_w[g][r];
+                else { s_col[g][p] = s_col[g][r]; s_w[g][p] = s_w[g][r]; ++p; }
+            }
+            double sum = 0.0;
+            for (int r = 0; r < p; ++r) sum = sum + s_w[g][r] * 1.0;
+            if (sum == 0.0) sum = 1.0;
+            const double rinv = 1.0 / sum;
+            for (int r = 0; r < k; ++r) {
+                const bool on = r < p;
+                cols[i * k + r] = on ? s_col[g][r] : 0;
+                vals[i * k + r] = on ? (float)(s_w[g][r] * rinv) : 0.f;
+                if (conn) conn[i * k + r] = on ? s_w[g][r] : 0.0;
+            }
+            cntp[i] = p;
+        }
+    }
+}
+
 // Presence scores (evaluate.py:426-521): column sums of the un-normalised gaussian connectivities, overall (column 0)
 // and per query group (columns 1..G).  One thread per (query, neighbour) entry, float64 atomics into [n_ref, G+1].
 __global__ void presence_scatter(const double *__restrict__ dist, const int64_t *__restrict__ idx, int64_t nq, int k,
@@ -685,12 +844,23 @@ cm_status cm_param_run(cm_handle_t h, const double *d_m3, int32_t kernel, double
 }
 
 cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t nq, int32_t k,
-                         int64_t /*n_ref*/, int32_t kernel, const double *d_param, double eps, int32_t *d_cols,
+                         int64_t n_ref, int32_t kernel, const double *d_param, double eps, int32_t *d_cols,
                          float *d_vals, int32_t *d_cnt, double *d_conn) {
     if (k < 1 || k > W_KMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "mapping matrix: %d neighbours per row exceeds the supported %d", k, W_KMAX);
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     if (nq == 0) return CM_OK;
-    if (k <= 32) {   // two rows per wave
+    const bool reg_ok = n_ref > 0 && n_ref <= (1LL << 25) && !getenv("CELLMAP_WEIGHTS_LDS");   // (n_ref <= 0: unknown column range)
+    if (reg_ok && k <= 128) {   // register-resident sort: one row per 32 lanes, per wave, or per wave with two entries per lane
+        if (k <= 32)
+            hipLaunchKernelGGL((weights_rows_sorted<32, 1>), dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,
+                               kernel, d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+        else if (k <= 64)
+            hipLaunchKernelGGL((weights_rows_sorted<64, 1>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,
+                               kernel, d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+        else
+            hipLaunchKernelGGL((weights_rows_sorted<64, 2>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,
+                               kernel, d_param, eps, d_cols, d_vals, d_cnt, d_conn);
+    } else if (k <= 32) {   // two rows per wave
         const size_t lds = 8 * ((size_t)k * 28 + 32) + 16;
         hipLaunchKernelGGL(weights_rows<32>, dim3((unsigned)((nq + 7) / 8)), dim3(256), lds, h->stream, d_dist, d_idx, nq, k, kernel,
                            d_param, eps, d_cols, d_vals, d_cnt, d_conn);

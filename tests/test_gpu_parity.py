@@ -705,8 +705,8 @@ def test_full_size_properties_config2(oracle, monkeypatch):
     assert bool(((code >= 0) & (code < 20)).all()) and bool(((conf > 0) & (conf <= 1 + 1e-5)).all())
 
 
-@pytest.mark.parametrize("k", [8, 30, 32, 33, 64, 100])
-def test_weights_and_vote_row_groupings(hip, oracle, k):
+@pytest.mark.parametrize("k", [8, 30, 32, 33, 64, 65, 100, 128, 130])
+def test_weights_and_vote_row_groupings(hip, oracle, monkeypatch, k):
     """Mapping matrix and label vote over ragged rows (padding, duplicate columns, unsorted columns) for row lengths on
     both sides of the 32-entry boundary (two rows per wave below it, one above): identical structure, float64
     connectivities to 1e-14, normalised float32 weights to 2e-7, vote equal to the oracle's."""
@@ -725,6 +725,11 @@ def test_weights_and_vote_row_groupings(hip, oracle, k):
         assert np.array_equal(indptr, oip) and np.array_equal(cols, oc)
         np.testing.assert_allclose(conn, ov64, rtol=1e-14)
         np.testing.assert_allclose(vals, ov32, rtol=2e-7)
+        # the register-resident kernel (k <= 128) and the LDS kernel run the same arithmetic: identical bits
+        monkeypatch.setenv("CELLMAP_WEIGHTS_LDS", "1")
+        indptr2, cols2, vals2, conn2, _ = hip.mapping_matrix(dist, idx, n_ref, kern, want_conn=True)
+        monkeypatch.delenv("CELLMAP_WEIGHTS_LDS")
+        assert np.array_equal(indptr, indptr2) and np.array_equal(cols, cols2) and np.array_equal(vals, vals2) and np.array_equal(conn, conn2)
         codes = rng.integers(0, 11, n_ref).astype(np.int32)
         code, conf = hip.label_vote(indptr, cols, vals, codes, 11)
         ocode, oconf = oracle.label_vote(oip, oc, ov32, codes, 11)
