@@ -296,7 +296,7 @@ def main_rank(a):
     default_shards = world if a.config == 4 else None
     n_groups, ref_shards = grid_2d(world, a.ref_shards or default_shards)
     qgroup, ref_rank = rank // ref_shards, rank % ref_shards
-    pg = make_groups(dist, world, n_groups, ref_shards) if world > 1 else None
+    pg = make_groups(dist, world, n_groups, ref_shards, a.exchange) if world > 1 else None
     lo, hi = shard_bounds(ref_full_rows, ref_shards, ref_rank)
     gq_lo, gq_hi = shard_bounds(a.nq, n_groups, qgroup)  # this query group's rows
     # every rank draws the same stream and keeps its shard, so the global problem is independent of N; chunks that do

@@ -92,13 +92,26 @@ def grid_2d(world: int, ref_shards: int | None = None):
     return world // ref_shards, ref_shards
 
 
-def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int):
-    """Process groups of the 2-D layout: rank = group * ref_shards + shard.  Every rank creates every group (required by
-    torch.distributed) and gets back the one it belongs to (None when a group is the whole world or a single rank)."""
+class WorldSlice:
+    """The reference-shard group [first, first + count) of a 2-D layout, addressed THROUGH THE WORLD communicator: the
+    all-to-all exchange of a group is an ``all_to_all_single`` of the whole world whose split sizes are zero outside the
+    group.  No sub-communicator is created (no ``new_group`` / communicator split): the only RCCL communicator of a run is
+    the default one."""
+
+    def __init__(self, first: int, count: int):
+        self.first, self.count = int(first), int(count)
+
+
+def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int, exchange: str = "alltoall"):
+    """Process groups of the 2-D layout: rank = group * ref_shards + shard.  For the all-to-all exchange a WorldSlice (see
+    there); for the all-gather exchange a real sub-group: every rank creates every group (required by torch.distributed)
+    and gets back the one it belongs to.  None when a group is the whole world or a single rank."""
     if world == 1 or ref_shards == 1:
         return None
     if n_groups == 1:
         return None  # the exchange runs on the default (world) group
+    if exchange == "alltoall":
+        return WorldSlice((dist_mod.get_rank() // ref_shards) * ref_shards, ref_shards)
     mine = None
     rank = dist_mod.get_rank()
     for g in range(n_groups):
@@ -146,10 +159,16 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
             # chunk j of the send buffer = what rank j merges: [2][per][k] of query slice j
             packed = send.view(2, world, pk).transpose(0, 1).contiguous().view(-1)
             recv = ops.empty_words(world * 2 * pk, send)
-            dist_mod.all_to_all_single(recv, packed, group=group)
+            if isinstance(group, WorldSlice):   # the group's all-to-all inside the world's: empty chunks for everybody else
+                splits = [2 * pk if group.first <= r < group.first + group.count else 0 for r in range(n_all)]
+                dist_mod.all_to_all_single(recv, packed, output_split_sizes=splits, input_split_sizes=splits)
+            else:
+                dist_mod.all_to_all_single(recv, packed, group=group)
             dist, idx = ops.merge_packed(recv, world, 2 * pk, 0, pk, n_mine, k, metric)
         elif exchange == "allgather":
             recv = ops.empty_words(world * 2 * nq_pad * k, send)
+            if isinstance(group, WorldSlice):
+                raise ValueError("the all-gather exchange of a 2-D layout needs a process group (make_groups(..., exchange='allgather'))")
             dist_mod.all_gather_into_tensor(recv, send.view(-1), group=group)
             dist, idx = ops.merge_packed(recv, world, 2 * nq_pad * k, rank * pk, nq_pad * k + rank * pk, n_mine, k, metric)
         else:

@@ -16,6 +16,9 @@ for ex in alltoall allgather; do
     bench.py --gpus 1 --steps 1 --warmup 1 --force-dist --exchange $ex --nq 300000 --nref 400000 --cpu-sample 0 --check 0 \
     >> $LOG 2>&1 || { echo "RCCL smoke ($ex) FAILED" >> $LOG; exit 1; }
 done
+# (a2) the split-size all_to_all_single of the 2-D layout (no sub-communicators), one rank on RCCL
+timeout -k 10 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 \
+    scripts/rccl_split_probe.py >> $LOG 2>&1 || { echo "RCCL split probe FAILED" >> $LOG; exit 1; }
 for n in 2 4; do
   timeout -k 10 250 python bench.py --gpus $n --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather \
     --nq 300000 --nref 400000 --cpu-sample 0 --check 0 --master-port 2953$n >> $LOG 2>&1 || { echo "rehearsal N=$n FAILED" >> $LOG; exit 1; }
@@ -25,4 +28,4 @@ timeout -k 10 250 python bench.py --gpus 2 --steps 1 --warmup 1 --backend gloo -
 # config 4's shape (d=128, K = 128 kernel family, reference sharded over ALL ranks) at a reduced size, 4 shards
 timeout -k 10 250 python bench.py --gpus 4 --config 4 --steps 1 --warmup 1 --backend gloo --share-gpu --exchange allgather \
     --nq 120000 --nref 600000 --cpu-sample 0 --check 0 --master-port 29538 >> $LOG 2>&1 || { echo "rehearsal config 4 FAILED" >> $LOG; exit 1; }
-grep -E "rehearsal|n_gpus" $LOG | cut -c1-220
+grep -E "rehearsal|rccl probe|n_gpus" $LOG | cut -c1-220

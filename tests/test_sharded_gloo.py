@@ -92,7 +92,7 @@ def _worker(rank, world, port, exchange, kernel, out_dir, ref_shards=None, metri
     codes = rng.integers(0, n_cat, n_ref).astype(np.int32)
     n_groups, rshards = grid_2d(world, ref_shards)
     qgroup, ref_rank = rank // rshards, rank % rshards
-    pg = make_groups(dist, world, n_groups, rshards)
+    pg = make_groups(dist, world, n_groups, rshards, exchange)
     lo, hi = shard_bounds(n_ref, rshards, ref_rank)
     g_lo, g_hi = shard_bounds(nq, n_groups, qgroup)
     code, conf, (q_lo, q_hi), dd, ii = sharded_map_labels(
@@ -115,7 +115,8 @@ def test_sharded_rejects_unsupported_metric():
 @pytest.mark.parametrize("world,ref_shards,exchange,kernel,metric", [
     (2, None, "alltoall", "gaussian", "euclidean"),    # 1 query group x 2 reference shards (pure reference sharding)
     (2, None, "allgather", "scarches", "euclidean"),
-    (4, 2, "alltoall", "gaussian", "euclidean"),       # 2 query groups x 2 reference shards: sub-group exchange, world-wide sigma
+    (4, 2, "alltoall", "gaussian", "euclidean"),       # 2 query groups x 2 reference shards: the groups' all-to-all inside the world's (split sizes), world-wide sigma
+    (4, 2, "allgather", "gaussian", "euclidean"),      # ... and through real sub-groups (new_group)
     (3, 3, "alltoall", "scarches", "euclidean"),       # odd world, ragged slices
     (2, None, "alltoall", "gaussian", "cosine"),       # cosine: merged values are NOT square-rooted
     (3, 3, "allgather", "inverse_distance", "cosine"),
