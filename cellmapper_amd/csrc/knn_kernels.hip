@@ -414,7 +414,12 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    const int *__restrict__ qmap, int pilot_kc,
                                                    const float *__restrict__ qlo, int level, const int *__restrict__ rmap,
                                                    const float *__restrict__ qnc = nullptr,
-                                                   const float *__restrict__ qcen = nullptr, int ncap = 0) {
+                                                   const float *__restrict__ qcen = nullptr, int ncap = 0,
+                                                   float *__restrict__ seedb = nullptr) {
+    // seedb != nullptr (staged search): `bound` is initialised (+inf) and kept MONOTONE over the stages (any stage's k-th
+    // candidate value bounds the true k-th value from above), and a flagged query leaves a starting threshold for its next
+    // stage in seedb[io]: bound - |q'|^2 + this stage's filter error, in filter units -- the k candidates behind the bound
+    // have filter values at or below it on every level whose error does not exceed this one's.
     // ncap > 0 (bucket pruning: many lists per query, most of them empty): the LDS holds ncap candidates; the valid
     // entries of the lists are compacted first, a query with more than ncap of them is left to the next stage.
     // qnc / qcen != nullptr (bucket-centred filter): |q' - c| and |c| of every packed row; qmap entries < 0 are padding.
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         for (int s = 0; s < S; ++s) tau = fminf(tau, cthr[i * S + s]);
         if (scale3) tau *= scale3[2];  // phase-1 values were computed on rows scaled by sc: back to input units
         bool certified = true;
+        double seed_eps = -1.0, seed_qn2 = 0.0;   // (set by the MFMA-level branch: what the next stage's seed needs)
         if (tau < INFINITY && c_eps >= 0.f) {
             // phase 1 ranked by |y'|^2 - 2 q'.y' = D - |q'|^2 with D = d^2 (cosine: 2*dist) and q', y' the rows as
             // prepared for the filter (cosine: normalised; split-fp16 path: centred at the reference mean)
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             } else {
                 eps += (double)c_split * 2.0 * qn * ymax;
             }
+            seed_eps = eps; seed_qn2 = qn2;
             double tau_d = (double)tau;
             if (pilot_kc > 0) {
                 const double vkc = s_kc[w];
@@ -556,7 +563,21 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (!certified || over || (flags & CM_KNN_FORCE_FALLBACK)) {
             int pos = atomicAdd(flag_cnt, 1);
             flag_list[pos] = (int)io;
-            bound[io] = kth;
+            if (seedb) {
+                const double b = fmin(bound[io], kth);
+                bound[io] = b;
+                float sv = INFINITY;
+                if (b < INFINITY && seed_eps >= 0.0) {
+                    double x = (((metric == CM_METRIC_COSINE) ? 2.0 * b : b) - seed_qn2 + seed_eps);
+                    x += 1e-6 * fabs(x) + 1e-30;
+                    if (scale3) x /= (double)scale3[2];
+                    sv = (float)x;
+                    if ((double)sv < x) sv = nextafterf(sv, INFINITY);
+                }
+                seedb[io] = sv;
+            } else {
+                bound[io] = kth;
+            }
         }
     }
 }
@@ -742,6 +763,20 @@ __global__ __launch_bounds__(256) void knn_merge(const double *__restrict__ pd, 
     }
 }
 
+// bound[] = +inf, seed[] = +inf (staged search: monotone k-th-value bounds and next-stage threshold seeds per query)
+__global__ void init_bounds(double *bound, float *seedb, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bound[i] = INFINITY; seedb[i] = INFINITY; }
+}
+// thr0[pos] = seed of the query the packed position holds (positions beyond the subset: +inf)
+__global__ void seed_gather(const float *__restrict__ seedb, const int *__restrict__ qmap, int64_t nsub, int64_t n_pad,
+                            float *__restrict__ thr0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    float v = INFINITY;
+    if (i < nsub) { const int q = qmap[i]; if (q >= 0) v = seedb[q]; }
+    thr0[i] = v;
+}
 __global__ void zero_words(unsigned *p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
@@ -1442,6 +1477,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const int n_pilot = nq >= 32768 ? 2048 : 0;
     int *sample = (int *)cm_ws_alloc(h, sizeof(int) * 4096);
     double *bound = (double *)cm_ws_alloc(h, sizeof(double) * (nq + 1));
+    float *seedb = (float *)cm_ws_alloc(h, sizeof(float) * (nq + 1));                     // next-stage threshold seed per query
+    float *seed_sub = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));      // ... gathered in a subset's packed order
     unsigned *words = (unsigned *)cm_ws_alloc(h, 128);  // [0..1] gmax, [2] flag count, [3] overflow, [4] maxabs, [8..10] scale
     int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
@@ -1455,12 +1492,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * CMEAN_COLS);
     double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_COLS);
     if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
-        !Qp || !kept || !lbuf || !cpart || !d_mean)
+        !Qp || !kept || !lbuf || !cpart || !d_mean || !seedb || !seed_sub)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     if (pf.grid > 320) CM_FAIL(h, CM_E_INTERNAL, "k-NN: unexpected resident workgroup count %d", pf.grid);
     float *scale3 = reinterpret_cast<float *>(words + 8);
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
+    hipLaunchKernelGGL(init_bounds, dim3((unsigned)((nq + 1 + 255) / 256)), dim3(256), 0, st, bound, seedb, nq + 1);
     // centre at the reference mean (translation leaves every distance unchanged), common power-of-two scale
     hipLaunchKernelGGL(colmean_partial<T>, dim3(CMEAN_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d, metric, cpart);
     hipLaunchKernelGGL(colmean_final, dim3(1), dim3(CMEAN_COLS), 0, st, cpart, n_ref, d, d_mean);
@@ -1868,6 +1906,18 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 a.no_sched = 1;
             }
             last_seeded = seed;
+            // Subset stages start from what their queries already know: the previous stage left, per flagged query, the k-th
+            // exact candidate value less |q'|^2 plus its filter error (knn_rerank, seedb) -- at least k rows have filter
+            // values at or below it on this level too, so the scan appends a few times K' rows instead of K' ln(n / K') and
+            // merges when a log fills.  Queries without a bound (fewer than k candidates so far) start from +inf.
+            const bool sub_seed = !seed && !marks && !pilot && rerank && qmap && !cenl && level != 4 && !w3 && !forced &&
+                                  !(flags & CM_KNN_FORCE_FALLBACK) && !getenv("CELLMAP_NO_SUBSEED") && !getenv("CELLMAP_NO_SEED");
+            if (sub_seed) {
+                hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
+                                   (int64_t)p2.nq_pad, seed_sub);
+                a.thr0 = seed_sub;
+                a.no_sched = 1;
+            }
             CM_TRY(launch(a));
         }
         if (marks) cm_mark(h, 2);
@@ -1879,7 +1929,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
                            idx_offset, flags, d_out_dist, d_out_idx, flag_out, (int *)(words + 2), bound, qmap, pilot_kc,
                            level == 4 ? (const float *)nullptr : (const float *)qlo, level, (const int *)rperm,
-                           cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr, rr_ncap);
+                           cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr, rr_ncap,
+                           pilot ? (float *)nullptr : seedb);
         CM_HIP(h, hipGetLastError());
         if (marks) cm_mark(h, 3);
         return CM_OK;
@@ -2135,6 +2186,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
             b += cm_align(sizeof(int) * (size_t)extra * (Kc + 16)) + cm_align(4 * (size_t)extra);
         }
         b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
+        b += cm_align(4 * (size_t)(nq + 1)) + cm_align(4 * (size_t)(nq_pad + 1024 + 256 * 512)) + 4096;   // per-query seeds of the subset stages
         b += cm_align((size_t)(n_ref / 16 + 512) * 136) + cm_align(4 * (size_t)(n_ref / 16 + 256)) +
              cm_align(4 * (size_t)(nq_pad + 1024)) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
