@@ -1051,13 +1051,6 @@ cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const in
 // fetches its own neighbour metadata (weight, slice start, slice length: lane l <-> neighbours l and l + 64), the next
 // row's in four stages spread over the current row.
 namespace {
-constexpr int SLC_NB = 8;   // neighbours per batch and register set
-
-__device__ __forceinline__ int a3_bucket_width(int n_out) {   // (same formula on the host: cm_a3_bucket_width)
-    const int w = (((n_out + 7) / 8) + 63) & ~63;
-    return w < 64 ? 64 : w;
-}
-
 // idx[j][b], b = 0..nb: number of entries of payload row j with column < b W.  One wave per row; also checks that the
 // row's columns are strictly ascending and inside [0, n_out) (flag[0] = 1 otherwise).
 constexpr int A3_HDR = 8;   // header words of a payload index: [0] longest slice, [1] bucket width, [2..3] non-zeros (int64), rest 0
