@@ -2015,6 +2015,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (!next) break;
         int64_t nf = 0;
         CM_TRY(read_flags(&nf));
+        // The bucket-centred level is the most precise of the matrix-core filters on clustered data; when it leaves more than
+        // a fifth of its queries uncertified the clusters are tight against their offsets and the three-product level fails
+        // for most of them as well (40 clusters, sigma 0.1: 69 % again): go straight to the direct-difference filter.
+        // A small remainder is cheaper on the three-product level (sigma 0.2: 6 ms against 36).
+        int next_level = next;
+        if (level == 5 && next == 3 && have_direct && nf * 5 > nsub && !getenv("CELLMAP_NO_SKIP3")) next_level = 4;
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
             const bool good = (level == 1 || level == 5) && nf * 2 <= nq;
             h->staged_hint_level = good ? level : (level == 5 ? -5 : 0);
@@ -2046,7 +2052,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             qmap = flag_s;
         }
         flag_out = flag_out == flag_a ? flag_b : flag_a;
-        level = next;
+        level = next_level;
     }
     if (g_dbg_ctr) {
         unsigned long long hc2[32] = {0};
