@@ -418,8 +418,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                                                    float *__restrict__ seedb = nullptr) {
     // seedb != nullptr (staged search): `bound` is initialised (+inf) and kept MONOTONE over the stages (any stage's k-th
     // candidate value bounds the true k-th value from above), and a flagged query leaves a starting threshold for its next
-    // stage in seedb[io]: bound - |q'|^2 + this stage's filter error, in filter units -- the k candidates behind the bound
-    // have filter values at or below it on every level whose error does not exceed this one's.
+    // stage in seedb[io]: bound - |q'|^2 + twice this stage's filter error, in filter units -- the k candidates behind the
+    // bound have filter values below it on every level whose error does not exceed this one's, with room for that level's
+    // certificate.
     // ncap > 0 (bucket pruning: many lists per query, most of them empty): the LDS holds ncap candidates; the valid
     // entries of the lists are compacted first, a query with more than ncap of them is left to the next stage.
     // qnc / qcen != nullptr (bucket-centred filter): |q' - c| and |c| of every packed row; qmap entries < 0 are padding.
@@ -568,7 +569,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                 bound[io] = b;
                 float sv = INFINITY;
                 if (b < INFINITY && seed_eps >= 0.0) {
-                    double x = (((metric == CM_METRIC_COSINE) ? 2.0 * b : b) - seed_qn2 + seed_eps);
+                    // (2 x the filter error: the next stage's certificate needs s_k + its own error below the threshold, and the
+                    //  threshold cannot exceed the seed -- its error is at most this stage's on the levels that are seeded)
+                    double x = (((metric == CM_METRIC_COSINE) ? 2.0 * b : b) - seed_qn2 + 2.0 * seed_eps);
                     x += 1e-6 * fabs(x) + 1e-30;
                     if (scale3) x /= (double)scale3[2];
                     sv = (float)x;
@@ -776,6 +779,27 @@ __global__ void seed_gather(const float *__restrict__ seedb, const int *__restri
     float v = INFINITY;
     if (i < nsub) { const int q = qmap[i]; if (q >= 0) v = seedb[q]; }
     thr0[i] = v;
+}
+// the same into slot 0 of the bucket-pruned stage's per-query threshold slots (stride S): pass A starts from it.  direct != 0:
+// the direct-difference filter ranks by the distance value itself (cosine rows are normalised: 2 x the cosine distance), so
+// its seed is the query's bound plus that filter's relative error.
+__global__ void seed_scatter_slot0(const float *__restrict__ seedb, const double *__restrict__ bound, const int *__restrict__ qmap,
+                                   int64_t nsub, int S, int direct, int is_cosine, double crel, float *__restrict__ cthr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsub) return;
+    const int q = qmap[i];
+    if (q < 0) return;
+    float v = INFINITY;
+    if (!direct) v = seedb[q];
+    else {
+        const double b = bound[q];
+        if (b < INFINITY) {
+            const double x = (is_cosine ? 2.0 * b : b) * (1.0 + crel) + 1e-30;
+            v = (float)x;
+            if ((double)v < x) v = nextafterf(v, INFINITY);
+        }
+    }
+    cthr[i * S] = v;
 }
 __global__ void zero_words(unsigned *p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1610,6 +1634,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int img = -1;          // reference image currently in Rp: 0 full [hi|lo] tiles, 1 hi-only tiles, 2 direct (fp32 rows)
     int last_Kc = Kc_max, last_S = 1;
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
+    int seeds_from_level = 0;   // level of the stage whose re-rank wrote the current per-query seeds (0: none)
     auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
         int level = level_in;
         last_seeded = false;
@@ -1807,6 +1832,21 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = ivf_S; b.perm_mul = 1;
             b.wlist = ivf_wla; b.n_wlist = p2.nqb;
             b.wctr = ivf_ctr + 8;
+            // subset stage: pass A starts from the bound its queries already have (see the unpruned case below): the
+            // resulting thresholds -- the plan's radii -- can only be tighter, and stay valid (at least k rows of the FULL set
+            // lie at or below the seed, whether pass A's tiles hold them or not)
+            // (the direct-difference level ranks by the distance value itself: bound x (1 + 4 x its certificate's relative
+            //  error), float32 inputs only -- float64 inputs add a coordinate-rounding term the seed does not model)
+            const bool seed_a = !marks && !pilot && rerank && qmap && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !w3 && !cenl &&
+                                seeds_from_level >= 1 && (level == 4 ? (sizeof(T) == 4 && seeds_from_level != 4)
+                                                                     : (seeds_from_level <= 3 && seeds_from_level <= level)) &&
+                                !getenv("CELLMAP_NO_SUBSEED") && !getenv("CELLMAP_NO_SEED");
+            if (seed_a) {
+                hipLaunchKernelGGL(seed_scatter_slot0, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, st, (const float *)seedb,
+                                   (const double *)bound, qmap, nsub, ivf_S, level == 4 ? 1 : 0, metric == CM_METRIC_COSINE ? 1 : 0,
+                                   16.0 * (double)(d + 4) * 5.9604645e-8, ivf_cthr);
+                b.thr0_slot0 = 1;
+            }
             auto side_items = [&](const int4 *wl, int n_items) {   // centred level: side values of the pairs a list visits
                 if (!cenl || side_full || n_items < 1) return;
                 hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, 4), dim3(256), 0, st, d_ref, n_ref, d, metric,
@@ -1910,7 +1950,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // exact candidate value less |q'|^2 plus its filter error (knn_rerank, seedb) -- at least k rows have filter
             // values at or below it on this level too, so the scan appends a few times K' rows instead of K' ln(n / K') and
             // merges when a log fills.  Queries without a bound (fewer than k candidates so far) start from +inf.
+            // (only after a level whose error bounds this level's from above: 1, 2, 3 -- not the bucket-centred level, whose
+            //  error on tight clusters is far below the plain levels')
             const bool sub_seed = !seed && !marks && !pilot && rerank && qmap && !cenl && level != 4 && !w3 && !forced &&
+                                  seeds_from_level >= 1 && seeds_from_level <= 3 && seeds_from_level <= level &&
                                   !(flags & CM_KNN_FORCE_FALLBACK) && !getenv("CELLMAP_NO_SUBSEED") && !getenv("CELLMAP_NO_SEED");
             if (sub_seed) {
                 hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
@@ -2052,6 +2095,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             qmap = flag_s;
         }
         flag_out = flag_out == flag_a ? flag_b : flag_a;
+        seeds_from_level = level;   // (the stage that just ran flagged these queries and left their seeds)
         level = next_level;
     }
     if (g_dbg_ctr) {
