@@ -485,6 +485,27 @@ def main_rank(a):
                 parity_ok = idx_ok and dist_ok and conf_ok and lab >= 0.9999
                 result["parity_check"] = {"queries": ns, "indices_bit_exact": idx_ok, "distances_bit_exact": dist_ok,
                                           "label_agreement": lab, "confidences_within_1e-5": conf_ok, "ok": parity_ok}
+        if a.check > 0 and a.metric != "euclidean":
+            # other metrics: a small sample through the numpy restatements of the oracle (no CPU throughput leg)
+            from oracle import oracle as orc
+            orc.build()
+            ns = min(a.check, 256 if a.metric == "cosine" else 16)
+            o = orc.run_path(ref_np, qry_np[:ns], a.k, metric=a.metric, kernel=a.kernel, labels=codes_np, n_cat=a.ncat)
+            code, conf, d_gpu, i_gpu = pipe.map_labels(ref, qry[:ns].contiguous(), a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel,
+                                                      want_graph=True)
+            torch.cuda.synchronize()
+            check_overflow()
+            i_np, d_np = i_gpu.cpu().numpy(), d_gpu.cpu().numpy()
+            idx_ok = bool(np.array_equal(i_np, o["idx"]))
+            # (float32 cosine: sklearn ranks float32 values, the fused pipeline the float64 ones -- tie order at rounding level)
+            dist_ok = bool(np.array_equal(d_np, o["dist"])) if a.metric != "cosine" else bool(np.allclose(d_np, o["dist"], rtol=0, atol=4e-7))
+            if a.metric == "cosine" and not idx_ok:
+                idx_ok = bool((np.sort(i_np, 1) == np.sort(o["idx"], 1)).mean() > 0.9999)
+            conf_ok = bool(np.allclose(conf.cpu().numpy(), o["conf"], rtol=1e-5, atol=1e-7))
+            lab = float((code.cpu().numpy() == o["pred_code"]).mean())
+            parity_ok = idx_ok and dist_ok and conf_ok and lab >= 0.999
+            result["parity_check"] = {"queries": ns, "indices_exact": idx_ok, "distances_exact": dist_ok, "label_agreement": lab,
+                                      "confidences_within_1e-5": conf_ok, "ok": parity_ok}
         if not a.no_host_leg and a.config == 2:
             pipe.h.set_profiling(False)
             result["host_inclusive"] = host_inclusive_leg(a, ref_np, qry_np, codes_np)
