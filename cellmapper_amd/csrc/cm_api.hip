@@ -902,7 +902,7 @@ cm_status cm_graph_label_vote(cm_handle_t h, cm_graph_t g, const int32_t *codes,
     DevBuf dcodes, ocode, oconf;
     CM_TRY(dcodes.alloc(h, 4 * (size_t)n_ref)); CM_TRY(ocode.alloc(h, 4 * (size_t)g->nq)); CM_TRY(oconf.alloc(h, 4 * (size_t)g->nq));
     CM_TRY(h2d(h, dcodes.p, codes, 4 * (size_t)n_ref));
-    CM_TRY(cm_vote_run(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, 0, nullptr, dcodes.as<int32_t>(), n_cat,
+    CM_TRY(cm_vote_run(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, g->k, nullptr, dcodes.as<int32_t>(), n_cat,
                        ocode.as<int32_t>(), oconf.as<float>()));
     CM_TRY(d2h(h, out_code, ocode.p, 4 * (size_t)g->nq));
     CM_TRY(d2h(h, out_conf, oconf.p, 4 * (size_t)g->nq));

@@ -921,7 +921,9 @@ cm_status cm_vote_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_c
                       float *d_out_conf) {
     if (n_cat < 1) CM_FAIL(h, CM_E_INVALID, "label vote: n_cat must be >= 1");
     if (nq == 0) return CM_OK;
-    if (!d_indptr && ell_k <= 32)   // padded rows of the k-NN path: two rows per wave
+    // rows of at most 32 entries (padded rows of the k-NN path, or a CSR mapping matrix built from a k <= 32 graph: ell_k is
+    // then only the hint): two rows per wave.  Longer CSR rows are still handled by that kernel's global-memory path.
+    if (ell_k > 0 && ell_k <= 32)
         hipLaunchKernelGGL(vote_rows<32>, dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, h->stream, d_indptr, d_cols, d_vals, nq, ell_k,
                            d_cnt, d_codes, d_out_code, d_out_conf);
     else
