@@ -17,6 +17,7 @@ cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, cons
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1direct_wide_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
 // grid_knn.hip: uniform-grid candidate search for d <= 3
 size_t cm_grid_ws_bytes(int64_t n_ref, int64_t ncell_max);
 int64_t cm_grid_ncell_max(int64_t n_ref, int k);
@@ -885,7 +886,8 @@ cm_status make_plan2(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, int
     p->rowb = path == 2 ? (size_t)dl * 4 : (size_t)cmk2::row_bytes(p->KSTEPS);
     p->lds = (path == 1 ? cmk2::ring_depth(false) : 2) * p->tileb + 64;   // knn_cand_f16: see ring_depth (set per level)
     if (p->lds > 160 * 1024) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip merge scratch", k);
-    const int qb = path == 3 ? cmk2::QBW : cmk2::QB;  // queries per workgroup pass of the chosen kernel
+    // queries per workgroup pass of the chosen kernel (the direct kernel takes one query per lane beyond 64 floats per row)
+    const int qb = path == 3 ? cmk2::QBW : (path == 2 ? cmk2::lowd_qb(dl) : cmk2::QB);
     p->nq_pad = (nq + qb - 1) / qb * qb;
     p->nqb = (int)(p->nq_pad / qb);
     p->n_tiles = (int)((n_ref + tile_rows - 1) / tile_rows);
@@ -1474,7 +1476,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const bool wide = path == 3;     // 62 <= d <= 128: K = 128 kernels, no direct level
     const bool lowp = path == 2;     // d <= 15 (or CELLMAP_PHASE1=direct): no MFMA levels, the direct kernel is the filter
     const int dl = lowd_dpad(d);     // row stride of the direct kernel
-    const bool have_direct = !wide && dl <= 64;
+    const bool have_direct = dl <= 128;   // (rows of up to 64 floats: two queries per lane; up to 128: one)
     // level 0: uniform-grid search (grid_knn.hip) for spatial coordinates; worth its set-up from a few thousand rows on
     const bool have_grid = lowp && d <= 3 && metric == CM_METRIC_EUCLIDEAN && n_ref >= 4096 &&
                            !(getenv("CELLMAP_LOWD") && !strcmp(getenv("CELLMAP_LOWD"), "brute"));
@@ -1508,8 +1510,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
     // any tile image: <= 256 B per row (K <= 64) / 512 B per row + side block (K = 128)
-    char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (wide ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
-    char *Qp = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * (wide ? 512 : 256));
+    const bool big_rows = wide || dl > 64;   // 512 B per prepared row: K = 128 images, direct rows of more than 64 floats
+    char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (big_rows ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
+    char *Qp = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * (big_rows ? 512 : 256));
     // (x 128 queries per wave: the four-accumulator kernel; the two-accumulator kernels use half of it)
     uint2 *kept = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 128 * Kc_max);
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 128 * 2 * cmk2::CL);
@@ -1762,7 +1765,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         bool pruned = false;
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
-            if (level == 4 && lp_metric) return cm_p1lowd_metric_launch(h, dl, metric == CM_METRIC_MANHATTAN ? 1 : 2, p2.grid, p2.lds, x);
+            const int op = lp_metric ? (metric == CM_METRIC_MANHATTAN ? 1 : 2) : 0;
+            if (level == 4 && dl > 64) return cm_p1direct_wide_launch(h, dl, op, p2.grid, p2.lds, x);
+            if (level == 4 && lp_metric) return cm_p1lowd_metric_launch(h, dl, op, p2.grid, p2.lds, x);
             if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
             if (w3) return cm_p1f16w_launch(h, p2.grid, p2.lds, x);
             if (q4 && !x.wlist && !x.seed_len) {
@@ -2271,8 +2276,8 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
     if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
-        if (lowd_dpad(d) > 64)
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev metrics are provided for up to 64 dimensions (got %d)", d);
+        if (lowd_dpad(d) > 128)
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev metrics are provided for up to 128 dimensions (got %d)", d);
         if (k + knn_slack(k) + 2 * cmk2::CL > 512)
             CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors = %d is too large for the manhattan / chebyshev metrics", k);
     }

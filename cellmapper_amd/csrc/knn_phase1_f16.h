@@ -902,13 +902,17 @@ __host__ __device__ constexpr int lowd_rows(int D) { return D <= 15 ? BRL : 128;
 __host__ __device__ constexpr int lowd_tile_bytes(int D) { return lowd_rows(D) * D * 4; }
 
 // OP: 0 = sum (q - y)^2 (Euclidean), 1 = sum |q - y| (Manhattan), 2 = max |q - y| (Chebyshev: exact in fp32 for fp32 rows).
+// Rows wider than 64 floats (65 <= d <= 128: the direct level of the K = 128 family, and the other metrics at those widths):
+// ONE query per lane instead of two (128 VGPRs of coordinates), 32 queries per wave, 256 per workgroup (LOWD_QB).
+__host__ __device__ constexpr int lowd_nj(int D) { return D <= 64 ? 2 : 1; }
+__host__ __device__ constexpr int lowd_qb(int D) { return NW * 32 * lowd_nj(D); }   // queries per workgroup pass
 template <int D, int OP = 0>
 __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
     constexpr int TILEB = lowd_tile_bytes(D);
     constexpr int NCHUNK = TILEB / 1024;
     constexpr int BRLD = lowd_rows(D);   // rows per tile
     constexpr int NST = BRLD / 32;
-    constexpr int NJ_ = 2;
+    constexpr int NJ_ = lowd_nj(D);
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;  // [2][TILEB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -940,12 +944,15 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
             t0 = split * a.tiles_per_split;
             t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
         }
-        const int64_t qbase = (int64_t)qb * QB + wave * 64;
-        float q0[D], q1[D];
+        const int64_t qbase = (int64_t)qb * lowd_qb(D) + wave * (32 * NJ_);
+        float q0[D], q1[NJ_ == 2 ? D : 1];
 #pragma unroll
-        for (int e = 0; e < D; ++e) { q0[e] = Qf[(qbase + c) * D + e]; q1[e] = Qf[(qbase + 32 + c) * D + e]; }
+        for (int e = 0; e < D; ++e) {
+            q0[e] = Qf[(qbase + c) * D + e];
+            if (NJ_ == 2) q1[e] = Qf[(qbase + 32 + c) * D + e];
+        }
         float thr[2] = {INFINITY, INFINITY};
-        if (a.thr0_slot0) { thr[0] = a.cthr[(qbase + c) * a.S]; thr[1] = a.cthr[(qbase + 32 + c) * a.S]; }
+        if (a.thr0_slot0) { thr[0] = a.cthr[(qbase + c) * a.S]; if (NJ_ == 2) thr[1] = a.cthr[(qbase + 32 + c) * a.S]; }
         int cnt[2] = {0, 0};
         int keptn[2] = {0, 0};
 
@@ -979,13 +986,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
 #pragma unroll
                     for (int e = 0; e < D; ++e) {
                         const float ye = y[e];
-                        const float d0 = q0[e] - ye, d1 = q1[e] - ye;
-                        if (OP == 0) { s0 = fmaf(d0, d0, s0); s1 = fmaf(d1, d1, s1); }
-                        else if (OP == 1) { s0 += fabsf(d0); s1 += fabsf(d1); }
-                        else { s0 = fmaxf(s0, fabsf(d0)); s1 = fmaxf(s1, fabsf(d1)); }
+                        const float d0 = q0[e] - ye, d1 = (NJ_ == 2 ? q1[e] : 0.f) - ye;
+                        if (OP == 0) { s0 = fmaf(d0, d0, s0); if (NJ_ == 2) s1 = fmaf(d1, d1, s1); }
+                        else if (OP == 1) { s0 += fabsf(d0); if (NJ_ == 2) s1 += fabsf(d1); }
+                        else { s0 = fmaxf(s0, fabsf(d0)); if (NJ_ == 2) s1 = fmaxf(s1, fabsf(d1)); }
                     }
                     acc0[rr] = s0;
-                    acc1[rr] = s1;
+                    acc1[rr] = NJ_ == 2 ? s1 : INFINITY;   // (one query per lane: the second accumulator never passes)
                 }
                 float mp0, mp1;
                 CM2_MIN16(acc0, mp0);

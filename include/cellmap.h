@@ -53,7 +53,7 @@ typedef enum {
  * sklearn's trees and brute force share.  Exact like the rest (float64 re-rank in sklearn's arithmetic -- for float32 data
  * brute force the coordinate difference is a float32 and the distance is rounded to float32 once, as DistanceMetric32
  * does -- certificate, fallback); the filter is the fp32 VALU direct-difference kernel, so they are VALU-bound, and the
- * row width is limited to d <= 64.  CM_E_UNSUPPORTED beyond that. */
+ * row width is limited to d <= 128 (two queries per lane up to 64 floats per row, one beyond).  CM_E_UNSUPPORTED beyond that. */
 #define CM_METRIC_MANHATTAN 2
 #define CM_METRIC_CHEBYSHEV 3
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):

@@ -10,6 +10,6 @@ $CXX -c knn_phase1_f16_inst.hip -o /tmp/cm_var_$name/f16.o &
 $CXX -c knn_kernels.hip -o /tmp/cm_var_$name/knn.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o ../../build_ab/lib_$name.so build/cm_api.o /tmp/cm_var_$name/knn.o \
-  build/graph_kernels.o build/jaccard_kernels.o build/grid_knn.o build/rank_kernels.o build/embed_kernels.o /tmp/cm_var_$name/f16.o build/knn_phase1_direct_inst.o build/knn_phase1_metric_inst.o \
+  build/graph_kernels.o build/jaccard_kernels.o build/grid_knn.o build/rank_kernels.o build/embed_kernels.o /tmp/cm_var_$name/f16.o build/knn_phase1_direct_inst.o build/knn_phase1_metric_inst.o build/knn_phase1_direct2_inst.o \
   build/p1_g0.o build/p1_g1.o build/p1_g2.o build/p1_g3.o
 echo built build_ab/lib_$name.so

@@ -741,7 +741,10 @@ def test_weights_and_vote_row_groupings(hip, oracle, monkeypatch, k):
     ("manhattan", np.float32, 50, 12000, 700, 30),      # brute force: float32 differences, distance rounded to float32
     ("manhattan", np.float64, 33, 9000, 500, 15),
     ("chebyshev", np.float32, 50, 12000, 700, 30),
-    ("chebyshev", np.float64, 64, 6000, 400, 10),       # the widest row the direct kernel takes
+    ("chebyshev", np.float64, 64, 6000, 400, 10),       # the widest row with two queries per lane
+    ("manhattan", np.float32, 100, 9000, 500, 15),      # one query per lane (65 <= d <= 128)
+    ("chebyshev", np.float32, 128, 6000, 300, 30),
+    ("manhattan", np.float64, 65, 5000, 300, 10),
     ("manhattan", np.float32, 3, 6000, 6000, 20),       # kd-tree arithmetic: float64 copies of the coordinates
     ("chebyshev", np.float32, 10, 12000, 800, 8),
 ])
@@ -767,11 +770,27 @@ def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, n
 
 def test_metric_passthrough_limits_and_names(hip):
     rng = np.random.default_rng(5)
-    x = rng.standard_normal((500, 65)).astype(np.float32)
-    with pytest.raises(NotImplementedError, match="64 dimensions"):
+    x = rng.standard_normal((500, 130)).astype(np.float32)
+    with pytest.raises(NotImplementedError, match="128 dimensions"):
         hip.knn(x, x[:10], 5, metric="manhattan")
     with pytest.raises(ValueError, match="not supported"):
         hip.knn(x, x[:10], 5, metric="braycurtis")
     d0, i0 = hip.knn(x, x[:10], 5, metric="minkowski")     # sklearn's default p = 2
     d1, i1 = hip.knn(x, x[:10], 5, metric="euclidean")
     assert np.array_equal(d0, d1) and np.array_equal(i0, i1)
+
+
+@pytest.mark.parametrize("d,sigma", [(100, 0.05), (128, 0.02), (70, 0.05)])
+def test_wide_rows_reach_the_direct_level_on_tight_clusters(hip, oracle, d, sigma):
+    """62 <= d <= 128 (K = 128 kernel family): near-duplicate clusters far from the origin defeat the split-fp16 filters; the
+    queries then go through the direct-difference level (one query per lane) instead of the exact scan -- and the result is
+    still the oracle's, bit for bit."""
+    rng = np.random.default_rng(400 + d)
+    cen = rng.standard_normal((12, d)) * 5.0
+    ref = (cen[rng.integers(0, 12, 30000)] + sigma * rng.standard_normal((30000, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 12, 3000)] + sigma * rng.standard_normal((3000, d))).astype(np.float32)
+    dist, idx = hip.knn(ref, qry, 15)
+    st = hip.knn_stats()
+    od, oi = oracle.knn_euclidean(ref, qry, 15)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert st["fallback_queries"] < 300, st      # (the exact scan is for the odd query, not for the set)
