@@ -171,7 +171,10 @@ cm_status cm_ws_reserve(cm_handle_t h, size_t bytes) {
 }
 void *cm_ws_alloc(cm_handle_t h, size_t bytes) {
     bytes = cm_align(bytes ? bytes : 1);
-    if (h->ws_off + bytes > h->ws_cap) return nullptr;
+    if (h->ws_off + bytes > h->ws_cap) {
+        if (getenv("CELLMAP_DBG_WS")) fprintf(stderr, "[cellmap dbg] workspace: request of %zu bytes at offset %zu exceeds the capacity %zu\n", bytes, h->ws_off, h->ws_cap);
+        return nullptr;
+    }
     void *p = h->ws + h->ws_off;
     h->ws_off += bytes;
     return p;

@@ -2234,7 +2234,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         b += cm_align((size_t)n_tiles * tileb + 65536) + cm_align((size_t)nq_pad * (KSTEPS > 4 ? cmk2::row_bytes(KSTEPS) : 256));
         b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * (Kc + 16)) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * 2 * cmk2::CL);
         // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
-        b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * Kc) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
+        b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * (Kc + 16)) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
              cm_align(4 * (nq + 1)) + 65536;
         {   // candidate rows of a split four-accumulator stage (cand_rows in knn_run_staged)
             const int64_t extra = std::min<int64_t>(3 * (nq_pad + 1024), 2000000 + 2048);
@@ -2262,7 +2262,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
         b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP);
     }
-    return b;
+    return b + (b >> 6) + (8u << 20);   // (+1.5 % and 8 MB: alignment of the many small allocations of the staged search)
 }
 
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,

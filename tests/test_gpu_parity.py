@@ -794,3 +794,20 @@ def test_wide_rows_reach_the_direct_level_on_tight_clusters(hip, oracle, d, sigm
     od, oi = oracle.knn_euclidean(ref, qry, 15)
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     assert st["fallback_queries"] < 300, st      # (the exact scan is for the odd query, not for the set)
+
+
+def test_workspace_covers_small_sets_with_many_neighbours(hip, oracle):
+    """Every (width, k) family on tiny query sets: the call's device workspace is sized from the shapes alone, and the fixed
+    parts (candidate rows of the staged search at k + slack + 16 per query) dominate here -- a shortfall showed up at d = 128,
+    k = 100, one query (scripts/fuzz_metrics.py).  Results against the oracle."""
+    rng = np.random.default_rng(77)
+    for d in (2, 16, 50, 61, 62, 100, 128, 200):
+        for k in (1, 30, 100, 180):
+            for nq, n_ref in ((1, 700), (600, 5000)):
+                if k > n_ref or (d > 128 and k > 64):   # (the f32-input kernel of 129 <= d <= 259 keeps its lists in LDS: k <= 64 or so)
+                    continue
+                ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+                qry = rng.standard_normal((nq, d)).astype(np.float32)
+                dist, idx = hip.knn(ref, qry, k)
+                od, oi = oracle.knn_euclidean(ref, qry, k)
+                assert np.array_equal(idx, oi) and np.array_equal(dist, od), (d, k, nq, n_ref)
