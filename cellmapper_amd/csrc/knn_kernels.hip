@@ -2227,7 +2227,9 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int64_t nq_pad = (nq + 511) / 512 * 512;
     size_t b = 512 * 1024 + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
-    if (use_f16_path(d, k)) {
+    // (d <= 128 always takes the staged sizing: the manhattan / chebyshev metrics run the staged search whatever k is, and
+    //  this function does not see the metric)
+    if (use_f16_path(d, k) || d <= 128) {
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
         size_t tileb = (size_t)cmk2::tile_bytes(KSTEPS > 4 ? KSTEPS : 4) + 1024;   // any tile image of the staged search: <= 256 B per row
@@ -2256,7 +2258,8 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
                  cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
             b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;   // bucket-sorted flag lists of the subset stages
         }
-    } else {
+    }
+    if (!use_f16_path(d, k)) {   // f32-input kernel: prepared rows of KP floats
         int KP = pick_kp(d);
         if (KP < 0) KP = 260;
         int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;

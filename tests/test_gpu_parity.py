@@ -811,3 +811,10 @@ def test_workspace_covers_small_sets_with_many_neighbours(hip, oracle):
                 dist, idx = hip.knn(ref, qry, k)
                 od, oi = oracle.knn_euclidean(ref, qry, k)
                 assert np.array_equal(idx, oi) and np.array_equal(dist, od), (d, k, nq, n_ref)
+    # the other metrics run the staged search whatever k is (the sizing does not see the metric)
+    for d, k in ((15, 191), (50, 191), (100, 150)):
+        ref = rng.standard_normal((6000, d)).astype(np.float32)
+        qry = rng.standard_normal((2, d)).astype(np.float32)
+        dist, idx = hip.knn(ref, qry, k, metric="manhattan")
+        od, oi = oracle.knn_minkowski_family(ref, qry, k, "manhattan")
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (d, k)
