@@ -1878,7 +1878,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                         tiles, full, hc[0], p2.nqb);
             // Pruning pays when little is left: every list starts its own threshold history (pass A from +inf) and the
             // re-rank ranks several lists per query, so at 15-25 % of the pairs the pruned stage measured SLOWER than the
-            // full scan (scripts/fuzz_paths.py); at an eighth and below it wins.
+            // full scan (tests/fuzz/fuzz_paths.py); at an eighth and below it wins.
             if (tiles * 8ull <= full) {
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;

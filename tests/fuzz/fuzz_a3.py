@@ -6,7 +6,7 @@ barrier kernel, single pass with the wave-sliced kernel (payload index), each wi
 offsets and completion order -- must give the same bytes, and those of the CPU oracle (csr_matmat's add order).  Prints one
 line per case; exits non-zero on the first mismatch."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import scipy.sparse as sp
 

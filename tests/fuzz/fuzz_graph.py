@@ -5,7 +5,7 @@ cm_mapping_matrix (K1-K3, every kernel), cm_label_vote (A0) and cm_spmm_dense (A
 1 .. 300 columns) against the CPU oracle: identical CSR structure, float32 weights to 2e-7, float64 connectivities to 1e-14,
 transfers to 1e-6.  Prints one line per case; exits non-zero on a mismatch."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 

@@ -3,7 +3,7 @@
 of the GPU search against the CPU oracle (sklearn's DistanceMetric arithmetic, pinned on goldens) over random widths 1..128,
 k, dtypes, scales, offsets and duplicated rows -- bit for bit.  Prints one line per case; exits non-zero on a mismatch."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 

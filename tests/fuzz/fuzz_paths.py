@@ -4,7 +4,7 @@ size thresholds, metrics, dtypes and cluster structures, the default search (buc
 must return bit-identical neighbours and distances to the search with all of it switched off
 (CELLMAP_NO_IVF / CELLMAP_NO_SEED / CELLMAP_NO_HINT / CELLMAP_Q4=0; even cases force the four-accumulator filter).  Prints one line per case; exits non-zero on the first mismatch."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 

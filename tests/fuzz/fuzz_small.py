@@ -4,7 +4,7 @@
 cm_knn against the CPU oracle, bit for bit (float32 cosine: sklearn's float32 arithmetic, compared at 4e-7 with tie sets).
 The large-shape fuzzers never visit these corners (k close to n_ref, one query, one reference row per tile ...)."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 

@@ -492,7 +492,7 @@ def test_four_accumulator_filter_is_exact(hip, oracle, monkeypatch, n_ref, nq, d
 def test_bucket_pruning_large_k_on_the_last_level(hip, oracle, monkeypatch):
     """k = 100 on very tight float64 clusters: the direct-difference level is the main stage and prunes; with K' = 125 the
     re-rank can rank 8 lists per query, so the plan must not hand out more -- a query dropped for holding too many
-    candidates on the last level would go to the exact scan with a loose bound (found by scripts/fuzz_paths.py)."""
+    candidates on the last level would go to the exact scan with a loose bound (found by tests/fuzz/fuzz_paths.py)."""
     rng = np.random.default_rng(65)
     d, k, n_ref, nq = 50, 100, 300000, 262144
     cen = rng.standard_normal((40, d)) * 5.0
@@ -799,7 +799,7 @@ def test_wide_rows_reach_the_direct_level_on_tight_clusters(hip, oracle, d, sigm
 def test_workspace_covers_small_sets_with_many_neighbours(hip, oracle):
     """Every (width, k) family on tiny query sets: the call's device workspace is sized from the shapes alone, and the fixed
     parts (candidate rows of the staged search at k + slack + 16 per query) dominate here -- a shortfall showed up at d = 128,
-    k = 100, one query (scripts/fuzz_metrics.py).  Results against the oracle."""
+    k = 100, one query (tests/fuzz/fuzz_metrics.py).  Results against the oracle."""
     rng = np.random.default_rng(77)
     for d in (2, 16, 50, 61, 62, 100, 128, 200):
         for k in (1, 30, 100, 180):
