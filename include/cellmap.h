@@ -220,7 +220,8 @@ cm_status cm_spmm_csr_dev(cm_handle_t h, const int64_t *d_indptr, const int32_t 
                           const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                           int64_t n_out, const int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
                           const int32_t *d_row_order);
-/* Single-pass form for callers that own a tile buffer with room for the worst case (n_out <= 32 768 columns, else
+/* (A3, `M @ reference.X` for a sparse layer: /root/reference/src/cellmapper/model/cellmapper.py:372-373, scipy csr_matmat.)
+ * Single-pass form for callers that own a tile buffer with room for the worst case (n_out <= 32 768 columns, else
  * CM_E_INVALID: use the pair above): counts, offsets and entries come from ONE gather of the payload rows -- the rows'
  * places in the output are found by a chained scan inside the kernel.  d_out_indptr [nq+1] is always written in full
  * (exact counts); the entries of rows that would end beyond `capacity` (entries available in d_out_cols / d_out_vals) are
