@@ -111,12 +111,35 @@ def pick_port(a) -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(a, argv) -> int:
-    """Parent of a self-launched multi-GPU run: never touches the GPU, only waits for the child."""
-    import torch  # device_count() does not initialise the GPU
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT loading the HIP runtime (the launching parent must never touch the GPU, and on ROCm
+    even `torch.cuda.device_count()` loads libamdhip64): the visible-devices variables if set, else the KFD topology nodes
+    that have SIMDs (CPU nodes report simd_count 0).  None when neither source is available (the caller then trusts --gpus)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
 
-    n_dev = torch.cuda.device_count()
-    if not a.share_gpu and n_dev < a.gpus:
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except OSError:
+            return None
+    return n
+
+
+def launch_ranks(a, argv) -> int:
+    """Parent of a self-launched multi-GPU run: never touches the GPU (no torch import, no HIP call), only waits for the
+    child."""
+    n_dev = visible_gpu_count()
+    if not a.share_gpu and n_dev is not None and n_dev < a.gpus:
         print(f"bench.py: --gpus {a.gpus} requested but only {n_dev} GPU(s) are visible", file=sys.stderr)
         return 2
     env = dict(os.environ)
@@ -128,28 +151,6 @@ def launch_ranks(a, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------- CPU legs -------------------
-def cpu_baseline(ref_np, qry_np, codes_np, k, ncat, kernel, n_sample):
-    """Time the CPU oracle (plain C restatement of the reference path: float64, query-blocked / cache-tiled scan, OpenMP
-    over the host cores) on a bounded sample: `n_sample` queries against the FULL reference; brute force is linear in the
-    number of queries.  The one-off re-layout of the reference (float64 upcast into tiles) is set-up: measured, stated,
-    and excluded from the rate -- at full size it is amortised over 1.5 M queries."""
-    # threads = the cores this process may actually use (cgroup CPU quota / affinity), not the host's core count: a GPU box
-    # gives a one-GPU job a share of its cores, and oversubscribing them only slows the scan down
-    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
-    from oracle import oracle as orc
-
-    orc.build()
-    q = qry_np[:n_sample]
-    t0 = time.perf_counter()
-    out = orc.run_path(ref_np, q, k, kernel=kernel, labels=codes_np, n_cat=ncat)
-    dt = time.perf_counter() - t0
-    setup = orc.last_setup_seconds()
-    return dict(value=n_sample / max(dt - setup, 1e-9), unit="query cells/s", cores=orc.num_threads(), kind="port",
-                sample=f"{n_sample} queries x {ref_np.shape[0]} reference rows, d={ref_np.shape[1]}, k={k}, "
-                       f"k-NN+kernel+label vote, {dt - setup:.2f} s of scan (+ {setup:.2f} s one-off reference re-layout, "
-                       f"excluded)"), out
-
-
 _SKLEARN_CHILD = r"""
 import json, sys, time
 import numpy as np
@@ -223,7 +224,7 @@ def host_inclusive_leg(a, ref_np, qry_np, codes_np):
     SURVEY.md 8d's definition of the metric; reported next to `value`, never as it."""
     from cellmapper_amd import _native
 
-    h = _native.default_handle()
+    h = _native.Handle(int(os.environ.get("LOCAL_RANK", "0")))   # ONE device (the process-wide default handle may span the node)
     best = None
     for _ in range(2):
         t0 = time.perf_counter()
@@ -249,9 +250,153 @@ def git_rev(path):
 
 
 # ------------------------------------------------------------------------------------- one rank -------------------
+class RunCtx:
+    """What one rank knows about the run: torch / torch.distributed, its place in the 2-D layout, the exchange state."""
+
+    def __init__(self, a, torch, dist, world, rank, dev, pipe, use_dist):
+        from cellmapper_amd.sharded import ExchangeState, HipOps, Layout, make_groups, shard_bounds
+
+        self.a, self.torch, self.dist, self.world, self.rank, self.dev, self.pipe, self.use_dist = a, torch, dist, world, rank, dev, pipe, use_dist
+        default_shards = world if a.config == 4 else None
+        self.lay = Layout(world, rank, a.nq, a.ref_shards or default_shards)
+        self.ops = HipOps(pipe)
+        self.pg = make_groups(dist, world, self.lay.n_groups, self.lay.ref_shards, a.exchange) if world > 1 else None
+        self.state = ExchangeState(a.exchange)
+        self.ref_lo, self.ref_hi = shard_bounds(a.nref, self.lay.ref_shards, self.lay.ref_rank)
+
+    def parallelism(self):
+        return f"q{self.lay.n_groups}xr{self.lay.ref_shards}"
+
+    def all_true(self, ok: bool) -> bool:
+        """Logical AND of a flag over all ranks (one small all-reduce)."""
+        if not self.use_dist or self.world == 1:
+            return bool(ok)
+        f = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(f, op=self.dist.ReduceOp.MIN)
+        return bool(int(f.item()))
+
+    def gather_rows(self, t):
+        """[n, w] int64 rows of every rank -> rank-major concatenation on every rank (equal n on all ranks)."""
+        if not self.use_dist or self.world == 1:
+            return t
+        out = self.torch.empty((self.world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1))
+        return out
+
+
+def full_reference_host(torch, bd, a, dev, chunk=1_000_000):
+    """The whole synthetic reference as one host array (the CPU oracle's input), drawn on the device in row chunks."""
+    out = np.empty((a.nref, a.d), np.float32)
+    for r0 in range(0, a.nref, chunk):
+        r1 = min(a.nref, r0 + chunk)
+        out[r0:r1] = bd.fill_rows(torch, "normal", bd.STREAM_REF, r0, r1, a.d, dev).cpu().numpy()
+    return out
+
+
+def sample_rows(lo: int, hi: int, n: int):
+    """n row numbers spread evenly over [lo, hi) (repeats when the slice is shorter than n)."""
+    if hi <= lo:
+        return np.zeros(n, np.int64)
+    return lo + (np.arange(n, dtype=np.int64) * (hi - lo)) // n
+
+
+def parity_gate(ctx, dist_t, idx_t, code_t, conf_t, my_lo, my_hi, want_cpu_baseline, ref_host_fn=None, qry_rows_fn=None,
+                what="k-NN+kernel+label vote"):
+    """Correctness gate of EVERY bench line (any N): each rank contributes an evenly spaced sample of the query rows it owns
+    -- merged indices, float64 distances, label, confidence, straight out of the timed configuration's outputs; rank 0
+    re-draws the whole reference and the sampled queries from the counter-based streams, runs the CPU oracle on them (the
+    timed run of it is also the `cpu_baseline`), and compares: indices and float64 distances bit for bit, labels and
+    confidences (1e-5) under the GLOBAL bandwidth, which is checked by an independent route (float64 mean of all nq*k
+    distances through torch + one all-reduce).  Returns (record, cpu_baseline | None); every rank learns `ok`."""
+    import bench_data as bd
+
+    a, torch, dist, dev = ctx.a, ctx.torch, ctx.dist, ctx.dev
+    k = a.k
+    ns_total = max(a.check, a.cpu_sample if want_cpu_baseline else 0)
+    scale = min(1.0, (1_500_000 * 50) / float(a.nref * a.d))       # bounded CPU leg: ~5-10 s of scan whatever the config
+    if a.metric != "euclidean":
+        ns_total = min(ns_total, 256 if a.metric == "cosine" else 32)   # numpy restatements of the oracle: small samples
+    elif ns_total > 256:
+        ns_total = max(256, int(ns_total * scale))
+    per = max(1, -(-ns_total // ctx.world))
+    rows = sample_rows(my_lo, my_hi, per)                          # global query ids of this rank's sample
+    sel = torch.from_numpy(rows - my_lo).to(dev)
+    pack = torch.empty((per, 2 * k + 3), dtype=torch.int64, device=dev)
+    pack[:, :k] = idx_t[sel]
+    pack[:, k:2 * k] = dist_t[sel].view(torch.int64)
+    pack[:, 2 * k] = code_t[sel].to(torch.int64) if code_t is not None else 0
+    pack[:, 2 * k + 1] = conf_t[sel].view(torch.int32).to(torch.int64) if conf_t is not None else 0
+    pack[:, 2 * k + 2] = torch.from_numpy(rows).to(dev)
+    allp = ctx.gather_rows(pack)
+    # the global bandwidth by an independent route: float64 sum of every distance of the run / their count
+    s = torch.stack([dist_t.sum(dtype=torch.float64), torch.tensor(float(dist_t.numel()), dtype=torch.float64, device=dev)])
+    if ctx.use_dist and ctx.world > 1:
+        dist.all_reduce(s)
+    sigma = float(s[0].item() / s[1].item())
+    rec, cb, ok = None, None, True
+    if ctx.rank == 0:
+        from oracle import oracle as orc
+
+        orc.build()
+        threads = orc.set_num_threads(usable_cores())
+        P = allp.cpu().numpy()
+        q_ids = P[:, 2 * k + 2]
+        g_idx, g_dist = P[:, :k], P[:, k:2 * k].copy().view(np.float64)
+        g_code, g_conf = P[:, 2 * k].astype(np.int32), P[:, 2 * k + 1].astype(np.int32).view(np.float32)
+        ref_np = ref_host_fn() if ref_host_fn else full_reference_host(torch, bd, a, dev)
+        q_np = (qry_rows_fn(q_ids) if qry_rows_fn else bd.rows_at(torch, "normal", bd.STREAM_QRY, q_ids, a.d, dev)).cpu().numpy()
+        codes_np = bd.integers(torch, bd.STREAM_LABEL, 0, a.nref, a.ncat, dev).cpu().numpy() if code_t is not None else None
+        t0 = time.perf_counter()
+        o = orc.run_path(ref_np, q_np, k, metric=a.metric, kernel=a.kernel, labels=codes_np, n_cat=a.ncat)
+        dt = time.perf_counter() - t0
+        setup = orc.last_setup_seconds() if a.metric == "euclidean" else 0.0
+        if want_cpu_baseline and a.metric == "euclidean":
+            cb = dict(value=len(q_ids) / max(dt - setup, 1e-9), unit="query cells/s", cores=threads, kind="port",
+                      sample=f"{len(q_ids)} queries (evenly spaced over all {a.nq}) x {a.nref} reference rows, d={a.d}, k={k}, "
+                             f"{what} on rank 0's host cores ({threads} OpenMP threads), {dt - setup:.2f} s of scan "
+                             f"(+ {setup:.2f} s one-off reference re-layout, excluded)")
+        idx_ok = bool(np.array_equal(g_idx, o["idx"]))
+        if a.metric == "cosine":   # float32 cosine: sklearn ranks float32 values, the device pipeline the float64 ones
+            dist_ok = bool(np.allclose(g_dist, o["dist"], rtol=0, atol=4e-7))
+            if not idx_ok:
+                idx_ok = bool((np.sort(g_idx, 1) == np.sort(o["idx"], 1)).mean() > 0.9999)
+        else:
+            dist_ok = bool(np.array_equal(g_dist, o["dist"]))
+        # labels / confidences under the run's GLOBAL bandwidth: the oracle's kernel + vote on ITS OWN lists with sigma
+        # injected (the oracle's own sigma is the sample's mean, a different number)
+        sig_ref = float(np.mean(o["dist"]))
+        if a.kernel == "gaussian":
+            w = np.exp(-(o["dist"].astype(np.float64) ** 2) / (2.0 * sigma * sigma))
+        elif a.kernel == "inverse_distance":
+            w = 1.0 / (o["dist"].astype(np.float64) + 1e-8)
+        elif a.kernel == "equal":
+            w = np.ones_like(o["dist"], dtype=np.float64)
+        else:
+            w = None   # scarches: the variance is not re-derived here; labels are compared on the lists only
+        lab, conf_ok = None, True
+        if w is not None and code_t is not None:
+            ip, cc, v32, _ = orc.mapping_matrix(w, o["dist"].astype(np.float64), o["idx"], a.nref)
+            c_code, c_conf = orc.label_vote(ip, cc, v32, codes_np, a.ncat)
+            lab = float((c_code == g_code).mean())
+            conf_ok = bool(np.allclose(g_conf, c_conf, rtol=1e-5, atol=1e-7))
+        ok = idx_ok and dist_ok and conf_ok and (lab is None or lab >= 0.9999)
+        rec = {"queries": int(len(q_ids)), "ranks_sampled": ctx.world, "rows": "evenly spaced over every rank's query slice",
+               "indices_bit_exact": idx_ok, "distances_bit_exact" if a.metric != "cosine" else "distances_within_4e-7": dist_ok,
+               "label_agreement": lab, "confidences_within_1e-5": conf_ok, "global_sigma": sigma,
+               "sigma_of_the_sample_alone": sig_ref, "ok": bool(ok)}
+    ok = ctx.all_true(ok)
+    if rec is not None:
+        rec["seconds_per_query_cpu"] = (dt - setup) / max(len(q_ids), 1)
+    return rec, cb, ok
+
+
 def main_rank(a):
+    import datetime
+
     import torch
     import torch.distributed as dist
+
+    import bench_data as bd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -259,81 +404,57 @@ def main_rank(a):
     a.gpus = world
     if a.share_gpu:
         local_rank = 0
-    if a.config in (3, 5) and world > 1:
-        print("bench.py: configs 3 and 5 are single-GPU workloads here (gene-column sharding needs no collective; "
-              "run one process per gene slab)", file=sys.stderr)
-        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        tmo = datetime.timedelta(minutes=8)   # a collective that never completes ends the run instead of hanging the box
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
 
     from cellmapper_amd.device import DevicePipeline
-    from cellmapper_amd.sharded import HipOps, grid_2d, make_groups, shard_bounds, sharded_map_labels
+    from cellmapper_amd.sharded import sharded_mapping_rows
 
     pipe = DevicePipeline(local_rank)
     pipe.h.set_profiling(True)
+    ctx = RunCtx(a, torch, dist, world, rank, dev, pipe, use_dist)
+    lay = ctx.lay
 
     if a.config in (3, 5):
-        import bench_wide   # configs 3 / 5: aggregation-heavy single-GPU workloads (scripts live next to bench.py)
+        import bench_wide   # configs 3 / 5: aggregation-heavy workloads (scripts live next to bench.py)
 
-        result = bench_wide.run(a, pipe, torch)
-        print(json.dumps(result), flush=True)
-        if result.get("parity_check", {}).get("ok") is False:
+        result, ok = bench_wide.run(ctx)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if not ok:
             sys.exit(4)
         return
 
-    # synthetic inputs: standard-normal float32 embeddings drawn separately for reference and query
-    g = torch.Generator(device=dev)
-    g.manual_seed(0)
-    ref_full_rows = a.nref
-    default_shards = world if a.config == 4 else None
-    n_groups, ref_shards = grid_2d(world, a.ref_shards or default_shards)
-    qgroup, ref_rank = rank // ref_shards, rank % ref_shards
-    pg = make_groups(dist, world, n_groups, ref_shards, a.exchange) if world > 1 else None
-    lo, hi = shard_bounds(ref_full_rows, ref_shards, ref_rank)
-    gq_lo, gq_hi = shard_bounds(a.nq, n_groups, qgroup)  # this query group's rows
-    # every rank draws the same stream and keeps its shard, so the global problem is independent of N; chunks that do
-    # not touch the rank's shard only advance the generator (same element count, no [chunk, d] buffer kept)
-    ref = torch.empty((hi - lo, a.d), dtype=torch.float32, device=dev)
-    chunk = 250_000
-    for c0 in range(0, ref_full_rows, chunk):
-        c1 = min(ref_full_rows, c0 + chunk)
-        blk = torch.randn((c1 - c0, a.d), generator=g, dtype=torch.float32, device=dev)
-        s0, s1 = max(c0, lo), min(c1, hi)
-        if s0 < s1:
-            ref[s0 - lo:s1 - lo] = blk[s0 - c0:s1 - c0]
-        del blk
-    qry = torch.empty((gq_hi - gq_lo, a.d), dtype=torch.float32, device=dev)
-    for c0 in range(0, a.nq, chunk):
-        c1 = min(a.nq, c0 + chunk)
-        blk = torch.randn((c1 - c0, a.d), generator=g, dtype=torch.float32, device=dev)
-        s0, s1 = max(c0, gq_lo), min(c1, gq_hi)
-        if s0 < s1:
-            qry[s0 - gq_lo:s1 - gq_lo] = blk[s0 - c0:s1 - c0]
-        del blk
-    codes = torch.randint(0, a.ncat, (ref_full_rows,), generator=g, device=dev, dtype=torch.int32)
+    # synthetic inputs: standard-normal float32 embeddings, reference and query from separate counter-based
+    # streams (bench_data.py): a rank draws ONLY its reference shard and its query group's rows; the problem is the same
+    # whatever N is
+    lo, hi = ctx.ref_lo, ctx.ref_hi
+    ref = bd.fill_rows(torch, "normal", bd.STREAM_REF, lo, hi, a.d, dev)
+    qry = bd.fill_rows(torch, "normal", bd.STREAM_QRY, lay.group_lo, lay.group_hi, a.d, dev)
+    codes = bd.integers(torch, bd.STREAM_LABEL, 0, a.nref, a.ncat, dev)
     torch.cuda.synchronize()
-
-    ops = HipOps(pipe)
     torch.cuda.set_stream(pipe.stream)  # library kernels, torch ops and RCCL collectives share one stream
+    ops = ctx.ops
 
-    q_bounds = [None]   # this rank's slice of its query group in the last sharded step
-
-    def step():
+    def step(want_graph=False):
         if not use_dist:
-            return pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel)
-        code, conf, qb, _, _ = sharded_map_labels(ops, dist, ref, lo, ref_full_rows, qry, a.k, codes, a.ncat,
-                                                  metric=a.metric, kernel=a.kernel, exchange=a.exchange, group=pg,
-                                                  ref_world=ref_shards, ref_rank=ref_rank)
-        q_bounds[0] = qb
-        return code, conf
+            return pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel, want_graph=want_graph)
+        r = sharded_mapping_rows(ops, dist, ref, lo, a.nref, qry, a.k, metric=a.metric, kernel=a.kernel, exchange=a.exchange,
+                                 group=ctx.pg, ref_world=lay.ref_shards, ref_rank=lay.ref_rank, state=ctx.state)
+        code, conf = ops.vote(r["cols"], r["vals"], r["cnt"], codes, a.ncat)
+        return code, conf, r["dist"], r["idx"]
 
     def check_overflow():
         ov = pipe.h.knn_stats().get("fallback_overflow", 0)
@@ -342,25 +463,34 @@ def main_rank(a):
                   f"would be truncated", file=sys.stderr, flush=True)
             sys.exit(5)
 
-    for _ in range(a.warmup):
+    # the FIRST call on the fresh handle pays what later calls skip: the pilot (~5 ms), the bucket-pruning gate (~1 ms), the
+    # workspace allocation, code-object loading -- and at N > 1 the exchange self-check; reported as `first_call_ms`
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - tf0) * 1e3
+    for _ in range(max(0, a.warmup - 1)):
         out = step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    p1_ms = []
+    p1_ms, stage_acc = [], {}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+        st = pipe.h.stage_times()       # HIP events of this step on the library's stream (synchronises it)
+        p1_ms.append(st["phase1_mfma"])
+        for kk, vv in st.items():
+            stage_acc[kk] = stage_acc.get(kk, 0.0) + vv
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     check_overflow()
-    # per-kernel time of the dominant kernel, from HIP events recorded on the launch stream (last step)
-    stages = pipe.h.stage_times()
-    p1_ms.append(stages["phase1_mfma"])
+    stages = {kk: vv / max(a.steps, 1) for kk, vv in stage_acc.items()}
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -398,7 +528,7 @@ def main_rank(a):
                 tj = json.load(open(tfile))
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = {"file": "profiles/phase1_hbm_traffic.json", "file_commit": git_rev(tfile),
-                               "kernel_source_commit": git_rev(os.path.join(ROOT, "cellmapper_amd", "csrc", "knn_phase1_f16.h")),
+                               "kernel_source_commit": git_rev(os.path.join(ROOT, "cellmapper_amd", "csrc", "knn_phase1_q4.h")),
                                "measured_on_commit": tj.get("measured_on_commit")}
             except Exception:
                 traffic = None
@@ -409,13 +539,18 @@ def main_rank(a):
             "dtype": "f16" if fb["lowd_path"] in (2, 4) else "f32",
             "data": "synthetic",
             "timed_region": "device-resident",   # inputs and outputs in HBM; host-in -> host-out is `host_inclusive`
+            # wall time of the first call on the fresh handle (pilot, pruning gate, workspace allocation, code loading and --
+            # at N > 1 -- the exchange self-check included): what a first CellMapper.map() pays and the timed steps do not
+            "first_call_ms": first_call_ms,
             "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.metric}, {a.kernel} kernel, "
-                                   f"{CONFIGS[a.config]['what']}; {world} GPU(s) = {n_groups} query "
-                                   f"group(s) x {ref_shards} reference shard(s), exchange="
-                                   f"{a.exchange if ref_shards > 1 else 'none'}",
+                                   f"{CONFIGS[a.config]['what']}; {world} GPU(s) = {lay.n_groups} query "
+                                   f"group(s) x {lay.ref_shards} reference shard(s), exchange="
+                                   f"{ctx.state.mode if lay.ref_shards > 1 else 'none'}",
                        "baseline_config": a.config,
-                       "parallelism": f"q{n_groups}xr{ref_shards}",
+                       "parallelism": ctx.parallelism(),
+                       "exchange": ctx.state.describe() if (use_dist and lay.ref_shards > 1) else None,
                        "nq": a.nq, "n_ref": a.nref, "d": a.d, "k": a.k, "kernel": a.kernel,
+                       "data_generator": "counter-based hash streams (bench_data.py): standard-normal float32, N-independent",
                        "fallback_queries_last_step": fb["fallback_queries"], "candidates_per_query": fb["candidates"],
                        "filter_products": fb.get("filter_products", 0),
                        # bucket pruning of the staged search: per cent of the (query block, reference tile) pairs the
@@ -425,90 +560,65 @@ def main_rank(a):
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": p1,
-                         # HIP events around the filter stage on the handle's stream
-                         "kernel_ms_covers": "all launches of the filter kernel in the step",
+                         # HIP events around the filter stage on the handle's stream, averaged over ALL timed steps
+                         "kernel_ms_covers": "all launches of the filter kernel in a step (seed scan + main scan), mean over the timed steps"
+                                             + (", rank 0's shard" if world > 1 else ""),
                          "flops_per_launch": flops, "executed_mfma_tflops": executed / (p1 * 1e-3) / 1e12,
                          "executed_frac_of_peak": executed / (p1 * 1e-3) / 1e12 / peak,
                          "f32_mfma_equivalent_frac": achieved / PEAK_F32_MFMA_TFLOPS},
-            "stage_ms_last_step": stages,
+            "stage_ms_mean": stages,
         }
-    # rehearsal of the N > 1 path on a one-GPU box (--share-gpu): every rank checks its slice of the sharded result against
-    # the same queries mapped onto the FULL reference by the single-GPU pipeline (identical labels, confidences to 1e-5)
+    # rehearsal of the N > 1 path on a one-GPU box (--share-gpu): every rank also checks its slice of the sharded result
+    # against the same queries mapped onto the FULL reference by the single-GPU pipeline (identical labels, confidences to 1e-5)
     if use_dist and (a.share_gpu or a.force_dist):
-        g2 = torch.Generator(device=dev)
-        g2.manual_seed(0)
-        ref_full = torch.cat([torch.randn((min(ref_full_rows, c0 + chunk) - c0, a.d), generator=g2, dtype=torch.float32, device=dev)
-                              for c0 in range(0, ref_full_rows, chunk)])
-        qry_full = torch.cat([torch.randn((min(a.nq, c0 + chunk) - c0, a.d), generator=g2, dtype=torch.float32, device=dev)
-                              for c0 in range(0, a.nq, chunk)])   # (same stream order as above)
-        ql, qh = q_bounds[0]
+        ref_full = bd.fill_rows(torch, "normal", bd.STREAM_REF, 0, a.nref, a.d, dev)
+        qry_full = bd.fill_rows(torch, "normal", bd.STREAM_QRY, 0, a.nq, a.d, dev)
+        ql, qh = lay.my_slice
         one = pipe.map_labels(ref_full, qry_full, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel)  # (global bandwidth)
         torch.cuda.synchronize()
-        sl = slice(gq_lo + ql, gq_lo + qh)
-        same = bool(torch.equal(one[0][sl], out[0])) and bool(torch.allclose(one[1][sl], out[1], rtol=1e-5, atol=1e-6))
-        print(f"[rehearsal] rank {rank}/{world} ({a.backend}, exchange={a.exchange}): sharded slice [{ql}, {qh}) of group "
-              f"{qgroup} vs single-GPU map of all queries: {'identical' if same else 'MISMATCH'}", file=sys.stderr, flush=True)
-        if not same:
+        same = bool(torch.equal(one[0][ql:qh], out[0])) and bool(torch.allclose(one[1][ql:qh], out[1], rtol=1e-5, atol=1e-6))
+        print(f"[rehearsal] rank {rank}/{world} ({a.backend}, exchange={ctx.state.mode}): sharded slice [{ql}, {qh}) "
+              f"vs single-GPU map of all queries: {'identical' if same else 'MISMATCH'}", file=sys.stderr, flush=True)
+        del ref_full, qry_full, one
+        if not ctx.all_true(same):
             sys.exit(3)
-    # parity spot check + CPU baseline + host-inclusive leg on rank 0 at N=1 only (bounded, outside the timed region)
+    # parity gate + CPU baseline (every N), sklearn and host-inclusive legs (rank 0; the latter at N = 1 only): bounded,
+    # outside the timed region
     parity_ok = True
-    if rank == 0 and world == 1 and not a.force_dist:
-        ref_np = qry_np = codes_np = None
-        if a.cpu_sample > 0 or a.check > 0 or not a.no_host_leg:
-            ref_np = ref.cpu().numpy()
-            qry_np = qry.cpu().numpy()
-            codes_np = codes.cpu().numpy()
-        if (a.cpu_sample > 0 or a.check > 0) and a.metric == "euclidean":
-            # bounded CPU leg: the sample shrinks with the cost of a query (n_ref x d) so that it stays ~5 s of scan
-            scale = min(1.0, (1_500_000 * 50) / float(a.nref * a.d))
-            ns = max(256, int(max(a.cpu_sample, a.check) * scale)) if max(a.cpu_sample, a.check) > 256 else max(a.cpu_sample, a.check)
-            cb, o = cpu_baseline(ref_np, qry_np, codes_np, a.k, a.ncat, a.kernel, ns)
-            if a.cpu_sample > 0:
-                result["cpu_baseline"] = cb
-                sk = sklearn_baseline(ref_np, qry_np, a.k, min(ns, 2048))
-                if sk is not None:
-                    result["cpu_baseline_sklearn"] = sk[0]
-                    # (not a parity gate: sklearn breaks exact ties by heap layout; on continuous synthetic data there are none)
-                    result["cpu_baseline_sklearn"]["indices_equal_oracle"] = bool(np.array_equal(sk[1], o["idx"][:sk[1].shape[0]]))
-            if a.check > 0:
-                # an evenly strided sample of the whole query set would need the oracle on other rows; the first `ns`
-                # rows are as random as any (i.i.d. synthetic data).  The kernel bandwidth is a global statistic, so
-                # labels / confidences are compared on a run over the same `ns` queries.
-                code, conf, d_gpu, i_gpu = pipe.map_labels(ref, qry[:ns].contiguous(), a.k, codes, a.ncat, kernel=a.kernel,
-                                                          want_graph=True)
-                torch.cuda.synchronize()
-                check_overflow()
-                idx_ok = bool(np.array_equal(i_gpu.cpu().numpy(), o["idx"]))
-                dist_ok = bool(np.array_equal(d_gpu.cpu().numpy(), o["dist"]))
-                lab = float((code.cpu().numpy() == o["pred_code"]).mean())
-                conf_ok = bool(np.allclose(conf.cpu().numpy(), o["conf"], rtol=1e-5, atol=1e-7))
-                parity_ok = idx_ok and dist_ok and conf_ok and lab >= 0.9999
-                result["parity_check"] = {"queries": ns, "indices_bit_exact": idx_ok, "distances_bit_exact": dist_ok,
-                                          "label_agreement": lab, "confidences_within_1e-5": conf_ok, "ok": parity_ok}
-        if a.check > 0 and a.metric != "euclidean":
-            # other metrics: a small sample through the numpy restatements of the oracle (no CPU throughput leg)
-            from oracle import oracle as orc
-            orc.build()
-            ns = min(a.check, 256 if a.metric == "cosine" else 16)
-            o = orc.run_path(ref_np, qry_np[:ns], a.k, metric=a.metric, kernel=a.kernel, labels=codes_np, n_cat=a.ncat)
-            code, conf, d_gpu, i_gpu = pipe.map_labels(ref, qry[:ns].contiguous(), a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel,
-                                                      want_graph=True)
+    if a.check > 0 or a.cpu_sample > 0:
+        if use_dist:
+            code_t, conf_t, dist_t, idx_t = out
+            my_lo, my_hi = lay.my_slice
+        else:
+            code_t, conf_t, dist_t, idx_t = step(want_graph=True)   # the fused call returns the lists only when asked
             torch.cuda.synchronize()
             check_overflow()
-            i_np, d_np = i_gpu.cpu().numpy(), d_gpu.cpu().numpy()
-            idx_ok = bool(np.array_equal(i_np, o["idx"]))
-            # (float32 cosine: sklearn ranks float32 values, the fused pipeline the float64 ones -- tie order at rounding level)
-            dist_ok = bool(np.array_equal(d_np, o["dist"])) if a.metric != "cosine" else bool(np.allclose(d_np, o["dist"], rtol=0, atol=4e-7))
-            if a.metric == "cosine" and not idx_ok:
-                idx_ok = bool((np.sort(i_np, 1) == np.sort(o["idx"], 1)).mean() > 0.9999)
-            conf_ok = bool(np.allclose(conf.cpu().numpy(), o["conf"], rtol=1e-5, atol=1e-7))
-            lab = float((code.cpu().numpy() == o["pred_code"]).mean())
-            parity_ok = idx_ok and dist_ok and conf_ok and lab >= 0.999
-            result["parity_check"] = {"queries": ns, "indices_exact": idx_ok, "distances_exact": dist_ok, "label_agreement": lab,
-                                      "confidences_within_1e-5": conf_ok, "ok": parity_ok}
-        if not a.no_host_leg and a.config == 2:
+            my_lo, my_hi = 0, a.nq
+        rec, cb, parity_ok = parity_gate(ctx, dist_t, idx_t, code_t, conf_t, my_lo, my_hi, a.cpu_sample > 0)
+        if rank == 0:
+            if a.check > 0:
+                result["parity_check"] = rec
+            else:
+                parity_ok = True
+            if cb is not None:
+                result["cpu_baseline"] = cb
+        if a.check <= 0:
+            parity_ok = True
+    if rank == 0 and a.cpu_sample > 0 and a.metric == "euclidean":
+        from oracle import oracle as orc
+
+        ns = min(2048, max(256, int(2048 * min(1.0, (1_500_000 * 50) / float(a.nref * a.d)))))
+        ref_np = full_reference_host(torch, bd, a, dev)
+        q_np = bd.fill_rows(torch, "normal", bd.STREAM_QRY, 0, ns, a.d, dev).cpu().numpy()
+        sk = sklearn_baseline(ref_np, q_np, a.k, ns)
+        if sk is not None:
+            result["cpu_baseline_sklearn"] = sk[0]
+            # (not a parity gate: sklearn breaks exact ties by heap layout; on continuous synthetic data there are none)
+            oi = orc.knn_euclidean(ref_np, q_np, a.k)[1]
+            result["cpu_baseline_sklearn"]["indices_equal_oracle"] = bool(np.array_equal(sk[1], oi))
+        if not a.no_host_leg and a.config == 2 and world == 1:
             pipe.h.set_profiling(False)
-            result["host_inclusive"] = host_inclusive_leg(a, ref_np, qry_np, codes_np)
+            result["host_inclusive"] = host_inclusive_leg(a, ref_np, qry.cpu().numpy(), codes.cpu().numpy())
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

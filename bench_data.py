@@ -1,0 +1,130 @@
+"""Counter-based synthetic inputs for bench.py: every element is a pure function of (stream, row, column).
+
+Why not ``torch.randn(generator=...)``: the benchmark problem must not depend on the number of GPUs, and a rank must be able
+to draw ITS shard (reference rows, query rows, gene columns) without drawing everybody else's -- and, for the parity gate,
+any rank must be able to re-draw any row.  A sequential generator gives neither (round 2 drew the whole 12 M x 128 stream on
+every rank to keep an eighth of it).  Here element (row, col) of stream ``s`` is a 32-bit integer hash of the three numbers
+(two rounds of the "lowbias32" finaliser, int32 wrap-around arithmetic in torch ops on the device), turned into
+
+  * ``uniform``  [0, 1) float32 with 24 random bits,
+  * ``normal``   standard normal float32 by Box-Muller from two such uniforms (embeddings: SURVEY.md 8d's
+                 ``standard_normal((n, d)).astype(float32)``),
+  * ``integers`` in [0, m).
+
+The same function on CPU tensors gives the gloo tests their inputs.  Nothing here is on the product path.
+"""
+from __future__ import annotations
+
+import math
+
+_C1 = 0x7FEB352D
+_C2 = 0x846CA68B - (1 << 32)     # as a wrapped int32
+_GOLD = 0x9E3779B1 - (1 << 32)
+
+STREAM_REF, STREAM_QRY, STREAM_LABEL, STREAM_OBSM, STREAM_X, STREAM_XY, STREAM_SPCOL, STREAM_SPVAL = range(1, 9)
+
+
+def _lsr(x, s: int):
+    """logical shift right of an int32 tensor (torch's >> is arithmetic)."""
+    return (x >> s) & ((1 << (32 - s)) - 1)
+
+
+def _mix(x):
+    x = x ^ _lsr(x, 16)
+    x = x * _C1
+    x = x ^ _lsr(x, 15)
+    x = x * _C2
+    return x ^ _lsr(x, 16)
+
+
+def hash_grid(torch, stream: int, rows, cols):
+    """int32 hash of every (row, col) pair: ``rows`` int32 [n] and ``cols`` int32 [m] -> [n, m]."""
+    r = _mix(rows ^ ((stream * 0x632BE5AB) & 0x7FFFFFFF))
+    return _mix(r[:, None] + cols[None, :] * _GOLD + stream)
+
+
+def uniform_block(torch, stream: int, r0: int, r1: int, c0: int, c1: int, device):
+    """[r1-r0, c1-c0] float32 uniform on [0, 1): element (i, j) depends on (stream, r0 + i, c0 + j) only."""
+    rows = torch.arange(r0, r1, dtype=torch.int32, device=device)
+    cols = torch.arange(c0, c1, dtype=torch.int32, device=device)
+    h = hash_grid(torch, stream, rows, cols)
+    return (h & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
+
+
+def normal_block(torch, stream: int, r0: int, r1: int, c0: int, c1: int, device):
+    """[r1-r0, c1-c0] float32 standard normal (Box-Muller on two hashed uniforms)."""
+    rows = torch.arange(r0, r1, dtype=torch.int32, device=device)
+    cols = torch.arange(c0, c1, dtype=torch.int32, device=device)
+    h1 = hash_grid(torch, stream, rows, cols)
+    h2 = _mix(h1 ^ 0x5BD1E995)
+    u1 = ((h1 & 0xFFFFFF).to(torch.float32) + 0.5) * (1.0 / 16777216.0)     # (0, 1)
+    u2 = (h2 & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+
+
+def fill_rows(torch, kind: str, stream: int, r0: int, r1: int, width: int, device, c0: int = 0, scale: float = 1.0,
+              chunk_elems: int = 1 << 25, out=None):
+    """Rows [r0, r1) x columns [c0, c0 + width) of a stream as one float32 tensor, generated in row chunks (the int32
+    temporaries of a chunk stay below ~1 GB)."""
+    fn = normal_block if kind == "normal" else uniform_block
+    n = r1 - r0
+    if out is None:
+        out = torch.empty((n, width), dtype=torch.float32, device=device)
+    step = max(1, chunk_elems // max(width, 1))
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        blk = fn(torch, stream, r0 + a, r0 + b, c0, c0 + width, device)
+        out[a:b] = blk * scale if scale != 1.0 else blk
+    return out
+
+
+def rows_at(torch, kind: str, stream: int, row_ids, width: int, device, c0: int = 0, scale: float = 1.0):
+    """The same stream at an arbitrary list of rows (the parity gate re-draws its sample)."""
+    fn_rows = torch.as_tensor(row_ids, dtype=torch.int32, device=device)
+    cols = torch.arange(c0, c0 + width, dtype=torch.int32, device=device)
+    h1 = hash_grid(torch, stream, fn_rows, cols)
+    if kind == "normal":
+        h2 = _mix(h1 ^ 0x5BD1E995)
+        u1 = ((h1 & 0xFFFFFF).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+        u2 = (h2 & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
+        out = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+    else:
+        out = (h1 & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
+    return out * scale if scale != 1.0 else out
+
+
+def integers(torch, stream: int, r0: int, r1: int, m: int, device):
+    """int32 [r1 - r0] in [0, m): label codes of reference rows [r0, r1)."""
+    rows = torch.arange(r0, r1, dtype=torch.int32, device=device)
+    cols = torch.zeros(1, dtype=torch.int32, device=device)
+    h = hash_grid(torch, stream, rows, cols)[:, 0]
+    return (_lsr(h, 8) % m).to(torch.int32)
+
+
+def sparse_rows(torch, r0: int, r1: int, n_genes: int, density: float, device, s0: int = 0, s1: int | None = None,
+                chunk_rows: int = 500_000):
+    """CSR float32 payload rows [r0, r1) of SURVEY.md 8d's sparse reference.X: ``per = round(density * n_genes)`` entries per
+    row, one per stratum of ``width = n_genes // per`` columns (ascending, distinct), values exp(N(0,1)).  ``[s0, s1)``
+    restricts to a range of STRATA = a gene-column slab [s0 * width, s1 * width) with columns renumbered from 0 (gene-column
+    sharding across GPUs): entry t of a row is the same number whatever the slab.
+    Returns (indptr int64 [n+1], cols int32, vals float32, entries per row, first gene column of the slab)."""
+    per = max(1, int(round(density * n_genes)))
+    width = n_genes // per
+    s1 = per if s1 is None else s1
+    n, m = r1 - r0, s1 - s0
+    cols = torch.empty((n, m), dtype=torch.int32, device=device)
+    vals = torch.empty((n, m), dtype=torch.float32, device=device)
+    base = (torch.arange(0, m, device=device, dtype=torch.int32) * width)[None, :]
+    strata = torch.arange(s0, s1, dtype=torch.int32, device=device)
+    for a in range(0, n, chunk_rows):
+        b = min(n, a + chunk_rows)
+        rows = torch.arange(r0 + a, r0 + b, dtype=torch.int32, device=device)
+        h = hash_grid(torch, STREAM_SPCOL, rows, strata)
+        cols[a:b] = base + (_lsr(h, 8) % width).to(torch.int32)
+        h1 = hash_grid(torch, STREAM_SPVAL, rows, strata)
+        h2 = _mix(h1 ^ 0x5BD1E995)
+        u1 = ((h1 & 0xFFFFFF).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+        u2 = (h2 & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
+        vals[a:b] = torch.exp(torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2))
+    indptr = torch.arange(n + 1, device=device, dtype=torch.int64) * m
+    return indptr, cols.view(-1), vals.view(-1), m, s0 * width

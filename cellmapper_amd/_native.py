@@ -34,7 +34,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = [
-    "cm_version", "cm_device_count", "cm_create", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
+    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
@@ -62,6 +62,7 @@ def load_library():
         lib.cm_version.restype = C.c_int
         lib.cm_device_count.restype = C.c_int
         lib.cm_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.cm_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         lib.cm_destroy.argtypes = [vp]
         lib.cm_last_error.argtypes = [vp]
         lib.cm_last_error.restype = C.c_char_p
@@ -133,17 +134,30 @@ def _ptr(a):
 
 
 class Handle:
-    """One backend context = one GPU + stream + workspace (``cm_create`` / ``cm_destroy``)."""
+    """One backend context (``cm_create`` / ``cm_create_multi`` / ``cm_destroy``): one GPU + stream + workspace, or -- with
+    ``devices=[...]`` -- several GPUs of one node behind ONE handle: the graph tier (what the drop-in classes call) then
+    shards the reference rows over them, exchanges the per-shard lists with peer copies and merges exactly, all inside the
+    library (one host thread per device; ctypes releases the GIL)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None):
         self.lib = load_library()
         h = C.c_void_p()
-        rc = self.lib.cm_create(int(device), C.byref(h))
+        if devices is not None:
+            devices = [int(x) for x in devices]
+            if not devices:
+                raise ValueError("Handle(devices=...): empty device list")
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.cm_create_multi(arr, len(devices), C.byref(h))
+            device = devices[0]
+        else:
+            rc = self.lib.cm_create(int(device), C.byref(h))
+            devices = [int(device)]
         if rc != 0:
             msg = self.lib.cm_last_error(None).decode()
-            raise RuntimeError(f"Could not initialise the HIP backend on device {device}: {msg}. {BUILD_HINT}")
+            raise RuntimeError(f"Could not initialise the HIP backend on device(s) {devices}: {msg}. {BUILD_HINT}")
         self._h = h
         self.device = device
+        self.devices = devices
 
     def close(self):
         if getattr(self, "_h", None):
@@ -449,6 +463,13 @@ class DeviceGraph:
         except Exception:
             pass
 
+    @property
+    def n_devices(self) -> int:
+        """GPUs the graph is spread over (query slices; > 1 only on a multi-device handle)."""
+        out = np.zeros(8, np.int64)
+        self.h.call("cm_graph_info", self._g, _ptr(out))
+        return int(out[7])
+
     def fetch_knn(self):
         dist = np.empty((self.nq, self.k), self.dist_dtype)
         idx = np.empty((self.nq, self.k), np.int64)
@@ -516,11 +537,24 @@ _default = None
 _default_lock = threading.Lock()
 
 
+def default_devices():
+    """Which GPUs the process-wide handle uses: ``CELLMAP_DEVICES`` ("all" or a comma-separated list) if set; the rank's own
+    GPU under a ``torch.distributed`` / MPI launch (``LOCAL_RANK`` or ``CELLMAP_DEVICE`` set: one process per GPU); otherwise
+    EVERY visible GPU -- ``CellMapper(query, reference).map(...)`` uses the whole node from one call."""
+    env = os.environ.get("CELLMAP_DEVICES", "").strip()
+    if env and env.lower() != "all":
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    if not env and ("CELLMAP_DEVICE" in os.environ or "LOCAL_RANK" in os.environ):
+        return [int(os.environ.get("CELLMAP_DEVICE", os.environ.get("LOCAL_RANK", "0")))]
+    n = int(load_library().cm_device_count())
+    return list(range(max(n, 1)))
+
+
 def default_handle() -> Handle:
-    """Process-wide handle on ``CELLMAP_DEVICE`` (default: LOCAL_RANK or 0), created on first use."""
+    """Process-wide handle on :func:`default_devices`, created on first use."""
     global _default
     with _default_lock:
         if _default is None:
-            dev = int(os.environ.get("CELLMAP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            _default = Handle(dev)
+            devs = default_devices()
+            _default = Handle(devs[0]) if len(devs) == 1 else Handle(devices=devs)
         return _default

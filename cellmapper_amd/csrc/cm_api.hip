@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <mutex>
+#include <thread>
 
 namespace {
 std::mutex g_err_mu;
@@ -54,6 +56,7 @@ struct DevBuf {  // RAII device allocation used by the host tier (pooled per han
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), owner(o.owner) { o.p = nullptr; }
     ~DevBuf() { release(); }
     void release() {
         if (p) {
@@ -216,6 +219,8 @@ cm_status cm_create(int device, cm_handle_t *out) {
 
 cm_status cm_destroy(cm_handle_t h) {
     if (!h) return CM_OK;
+    for (auto *p : h->peers) (void)cm_destroy(p);
+    h->peers.clear();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->ws) (void)hipFree(h->ws);
@@ -442,6 +447,20 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     if (n_ref < 1 || d < 1 || nq < 0) CM_FAIL(h, CM_E_INVALID, "k-NN: bad shape");
     if (k < 1 || k > n_ref)
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
+    if (!h->peers.empty()) {   // multi-device handle: the graph tier shards the reference rows over the devices (falls back to one by itself)
+        cm_rep_t r = nullptr, q = nullptr;
+        cm_graph_t g = nullptr;
+        cm_status rc = cm_rep_create(h, ref, n_ref, d, dtype, &r);
+        if (rc == CM_OK) rc = cm_rep_create(h, qry, nq, d, dtype, &q);
+        if (rc == CM_OK) rc = cm_graph_knn(h, r, q, k, metric, form, &g);
+        if (rc == CM_OK) rc = cm_graph_knn_fetch(h, g, out_dist, out_idx);
+        const std::string keep = h->err;
+        if (g) (void)cm_graph_destroy(h, g);
+        if (q) (void)cm_rep_destroy(h, q);
+        if (r) (void)cm_rep_destroy(h, r);
+        if (rc != CM_OK) h->err = keep;
+        return rc;
+    }
     const size_t es = dtype == CM_F64 ? 8 : 4;
     const size_t des = (metric == CM_METRIC_COSINE) ? es : 8;  // element size of the returned distances
     const int64_t QCH = 1 << 21;
@@ -749,31 +768,116 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
 // What the drop-in Python classes hold between compute_neighbors -> compute_mapping_matrix -> map_obs / map_obsm /
 // map_layers (one in-process flow upstream, cellmapper.py:465-484): the embeddings, the k-NN result and the mapping matrix
 // stay on the device; host arrays are produced only when the caller asks for them (the *_fetch calls).
+//
+// Multi-device (cm_create_multi, SURVEY.md 8e behind the C ABI): a representation is uploaded to EVERY device of the handle;
+// a graph is a list of PARTS, part p = the query rows [q_lo, q_lo + nq) whose merged lists, mapping-matrix rows and transfers
+// device p owns.  A single-device graph is one part on the handle itself and runs exactly the code it always ran.
 struct cm_rep_s {
-    DevBuf buf;
+    std::vector<DevBuf> bufs;   // one copy per device of the handle (index 0: the handle's own device)
     int64_t n = 0;
     int32_t d = 0, dtype = 0;
+};
+struct GraphPart {
+    cm_handle_t h = nullptr;
+    int64_t q_lo = 0, nq = 0;
+    DevBuf dist, idx;              // k-NN result as the reference returns it: float64 (float32: cosine on float32 input), int64
+    DevBuf indptr, cols, vals;     // row-normalised mapping matrix rows of the part, canonical CSR (indptr starts at 0)
+    int64_t nnz = 0;
 };
 struct cm_graph_s {
     int64_t nq = 0, n_ref = 0;
     int32_t k = 0, metric = 0, dist_is_f32 = 0;
-    DevBuf dist, idx;              // k-NN result as the reference returns it: float64 (float32: cosine on float32 input), int64
-    DevBuf indptr, cols, vals;     // row-normalised mapping matrix, canonical CSR on the device
+    std::vector<GraphPart> parts;
     bool has_map = false;
     int64_t nnz = 0;
 };
 
+}  // extern "C"
+
+namespace {
+std::vector<cm_handle_t> handle_devices(cm_handle_t h) {
+    std::vector<cm_handle_t> v{h};
+    for (auto *p : h->peers) v.push_back(p);
+    return v;
+}
+// f(i) for every part, one host thread per part beyond the first (every HIP call of a part is issued by its own thread,
+// which binds that part's device first); the first failure is reported through the caller's handle.
+template <class F>
+cm_status for_parts(cm_handle_t h, size_t n, const std::vector<cm_handle_t> &hs, F f) {
+    if (n <= 1) return f((size_t)0);
+    std::vector<cm_status> rc(n, CM_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < n; ++i) th.emplace_back([&, i] { rc[i] = f(i); });
+    rc[0] = f((size_t)0);
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(h->device);
+    for (size_t i = 0; i < n; ++i)
+        if (rc[i] != CM_OK) {
+            if (hs[i] != h) h->err = "device " + std::to_string(hs[i]->device) + ": " + hs[i]->err;
+            return rc[i];
+        }
+    return CM_OK;
+}
+std::vector<cm_handle_t> part_handles(const cm_graph_s *g) {
+    std::vector<cm_handle_t> v;
+    for (auto &p : g->parts) v.push_back(p.h);
+    return v;
+}
+// the part's distances as float64 on its device (float32 graphs: widened into the part's workspace)
+cm_status part_dist64(GraphPart &p, const cm_graph_s *g, const double **out) {
+    if (!g->dist_is_f32) { *out = p.dist.as<double>(); return CM_OK; }
+    const size_t nk = (size_t)p.nq * g->k;
+    double *w = (double *)cm_ws_alloc(p.h, 8 * nk);
+    if (!w) CM_FAIL(p.h, CM_E_NOMEM, "graph: device workspace exhausted");
+    CM_TRY(cm_widen_f32_run(p.h, p.dist.as<float>(), (int64_t)nk, w));
+    *out = w;
+    return CM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+cm_status cm_create_multi(const int *devices, int n, cm_handle_t *out) {
+    if (!out) return CM_E_INVALID;
+    *out = nullptr;
+    if (!devices || n < 1) { std::lock_guard<std::mutex> g(g_err_mu); g_create_err = "cm_create_multi: empty device list"; return CM_E_INVALID; }
+    cm_handle_t h0 = nullptr;
+    cm_status rc = cm_create(devices[0], &h0);
+    if (rc != CM_OK) return rc;
+    for (int i = 1; i < n; ++i) {
+        cm_handle_t hp = nullptr;
+        rc = cm_create(devices[i], &hp);
+        if (rc != CM_OK) { (void)cm_destroy(h0); return rc; }
+        h0->peers.push_back(hp);
+    }
+    // direct peer copies (xGMI) where the platform allows them; hipMemcpyPeerAsync works (staged) without
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            int can = 0;
+            if (devices[i] == devices[j] || hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) continue;
+            if (hipSetDevice(devices[i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+        }
+    (void)hipGetLastError();   // ("peer access already enabled" is not an error)
+    (void)hipSetDevice(devices[0]);
+    *out = h0;
+    return CM_OK;
+}
+
 cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, cm_rep_t *out) {
     if (!h) return CM_E_INVALID;
     if (!out || !X || n < 1 || d < 1 || (dtype != CM_F32 && dtype != CM_F64)) CM_FAIL(h, CM_E_INVALID, "rep: bad arguments");
-    CM_TRY(begin_call(h, 0));
     cm_rep_s *r = new (std::nothrow) cm_rep_s();
     if (!r) CM_FAIL(h, CM_E_NOMEM, "rep: out of host memory");
     r->n = n; r->d = d; r->dtype = dtype;
+    const auto hs = handle_devices(h);
+    r->bufs = std::vector<DevBuf>(hs.size());
     const size_t bytes = (size_t)n * d * (dtype == CM_F64 ? 8 : 4);
-    cm_status rc = r->buf.alloc(h, bytes);
-    if (rc == CM_OK) rc = h2d(h, r->buf.p, X, bytes);
-    if (rc == CM_OK) rc = sync(h);
+    cm_status rc = for_parts(h, hs.size(), hs, [&](size_t i) -> cm_status {   // every device over its own PCIe link
+        CM_TRY(begin_call(hs[i], 0));
+        CM_TRY(r->bufs[i].alloc(hs[i], bytes));
+        CM_TRY(h2d(hs[i], r->bufs[i].p, X, bytes));
+        return sync(hs[i]);
+    });
     if (rc != CM_OK) { delete r; return rc; }
     *out = r;
     return CM_OK;
@@ -781,8 +885,30 @@ cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int3
 
 cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r) {
     if (!h) return CM_E_INVALID;
+    if (r)
+        for (auto &b : r->bufs) { if (b.owner) (void)hipSetDevice(b.owner->device); b.release(); }
     (void)hipSetDevice(h->device);
     delete r;
+    return CM_OK;
+}
+
+// one device's search of the queries [0, nq) against reference rows [r_lo, r_lo + n_rows) of its copy of the representation
+static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const DevBuf &refbuf, const cm_rep_s *qry, const DevBuf &qbuf, int64_t r_lo,
+                          int64_t n_rows, int32_t k, int32_t metric, int32_t form, int32_t flags, void *d_dist, size_t des, int64_t *d_idx,
+                          int64_t *nflag_out) {
+    const int64_t QCH = 1 << 21;   // queries in chunks of 2^21 rows like the host tier (bounds the workspace)
+    const size_t es = ref->dtype == CM_F64 ? 8 : 4;
+    int64_t nflag = 0;
+    for (int64_t q0 = 0; q0 < qry->n; q0 += QCH) {
+        const int64_t nqc = std::min<int64_t>(QCH, qry->n - q0);
+        CM_TRY(begin_call(hp, cm_knn_ws_bytes(n_rows, nqc, ref->d, k, ref->dtype)));
+        CM_TRY(cm_knn_run(hp, (const char *)refbuf.p + es * r_lo * ref->d, n_rows, (const char *)qbuf.p + es * q0 * ref->d, nqc, ref->d,
+                          ref->dtype, k, metric, form, r_lo, flags, (char *)d_dist + des * q0 * k, d_idx + q0 * k));
+        CM_TRY(sync(hp));
+        CM_TRY(check_fallback_overflow(hp));
+        nflag += hp->knn_stats[0];
+    }
+    *nflag_out = nflag;
     return CM_OK;
 }
 
@@ -796,33 +922,84 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
     if (!g) CM_FAIL(h, CM_E_NOMEM, "graph: out of host memory");
     g->nq = qry->n; g->n_ref = ref->n; g->k = k; g->metric = metric;
     g->dist_is_f32 = (metric == CM_METRIC_COSINE && ref->dtype == CM_F32) ? 1 : 0;
-    const size_t nk = (size_t)g->nq * k;
-    cm_status rc = g->dist.alloc(h, (g->dist_is_f32 ? 4 : 8) * nk);
-    if (rc == CM_OK) rc = g->idx.alloc(h, 8 * nk);
-    // queries in chunks of 2^21 rows like the host tier (bounds the workspace)
-    const int64_t QCH = 1 << 21;
-    const size_t es = ref->dtype == CM_F64 ? 8 : 4, des = g->dist_is_f32 ? 4 : 8;
-    int64_t nflag = 0;
-    for (int64_t q0 = 0; q0 < g->nq && rc == CM_OK; q0 += QCH) {
-        const int64_t nqc = std::min<int64_t>(QCH, g->nq - q0);
-        rc = begin_call(h, cm_knn_ws_bytes(ref->n, nqc, ref->d, k, ref->dtype));
+    const auto hs = handle_devices(h);
+    size_t P = std::min(hs.size(), std::min(ref->bufs.size(), qry->bufs.size()));
+    // reference shards need room for k neighbours and enough rows to be worth a launch; float32 cosine keeps the one-device
+    // arithmetic (sklearn's float32 distances)
+    if (g->dist_is_f32 || ref->n < (int64_t)P * 4096 || ref->n < (int64_t)P * k || qry->n < 1024) P = 1;
+    cm_status rc = CM_OK;
+    if (P == 1) {
+        g->parts.resize(1);
+        GraphPart &p = g->parts[0];
+        p.h = h; p.q_lo = 0; p.nq = g->nq;
+        const size_t nk = (size_t)g->nq * k, des = g->dist_is_f32 ? 4 : 8;
+        rc = p.dist.alloc(h, des * nk);
+        if (rc == CM_OK) rc = p.idx.alloc(h, 8 * nk);
+        int64_t nflag = 0;
+        if (rc == CM_OK) rc = part_knn(h, ref, ref->bufs[0], qry, qry->bufs[0], 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag);
+        h->knn_stats[0] = nflag;
+    } else {
+        // 1. every device: all queries against its reference shard, GLOBAL indices, float64 ranking values (squared for
+        //    euclidean) into a packed buffer [2][nq][k] of 8-byte words -- the layout of the RCCL path's exchange buffer
+        g->parts.resize(P);
+        std::vector<DevBuf> packed(P);
+        std::vector<int64_t> nflag(P, 0);
+        const size_t nk = (size_t)g->nq * k;
+        const std::vector<cm_handle_t> hp(hs.begin(), hs.begin() + P);
+        rc = for_parts(h, P, hp, [&](size_t i) -> cm_status {
+            const int64_t base = ref->n / (int64_t)P, extra = ref->n % (int64_t)P;
+            const int64_t lo = (int64_t)i * base + std::min<int64_t>((int64_t)i, extra), rows = base + ((int64_t)i < extra ? 1 : 0);
+            CM_TRY(begin_call(hp[i], 0));
+            CM_TRY(packed[i].alloc(hp[i], 16 * nk));
+            return part_knn(hp[i], ref, ref->bufs[i], qry, qry->bufs[i], lo, rows, k, metric, form, CM_KNN_SQUARED | CM_KNN_F64_OUT,
+                            packed[i].p, 8, packed[i].as<int64_t>() + nk, &nflag[i]);
+        });
+        // 2. + 3. device p owns query slice p: it pulls that slice of every device's two planes with peer copies (xGMI) and
+        //    merges the P lists per query by (value, global index) -- the rule of a single search, so the result is exact
         if (rc == CM_OK)
-            rc = cm_knn_run(h, ref->buf.p, ref->n, (const char *)qry->buf.p + es * q0 * ref->d, nqc, ref->d, ref->dtype, k, metric, form, 0, 0,
-                            (char *)g->dist.p + des * q0 * k, g->idx.as<int64_t>() + q0 * k);
-        if (rc == CM_OK) rc = sync(h);
-        if (rc == CM_OK) rc = check_fallback_overflow(h);
-        nflag += h->knn_stats[0];
+            rc = for_parts(h, P, hp, [&](size_t i) -> cm_status {
+                GraphPart &p = g->parts[i];
+                const int64_t base = g->nq / (int64_t)P, extra = g->nq % (int64_t)P;
+                p.h = hp[i];
+                p.q_lo = (int64_t)i * base + std::min<int64_t>((int64_t)i, extra);
+                p.nq = base + ((int64_t)i < extra ? 1 : 0);
+                const size_t pk = (size_t)p.nq * k;
+                CM_TRY(begin_call(hp[i], 0));
+                DevBuf recv;
+                CM_TRY(recv.alloc(hp[i], 16 * pk * P));
+                CM_TRY(p.dist.alloc(hp[i], 8 * pk));
+                CM_TRY(p.idx.alloc(hp[i], 8 * pk));
+                for (size_t r = 0; r < P; ++r) {
+                    char *dst = (char *)recv.p + 16 * pk * r;
+                    const char *src = (const char *)packed[r].p + 8 * (size_t)p.q_lo * k;
+                    CM_HIP(hp[i], hipMemcpyPeerAsync(dst, hp[i]->device, src, hp[r]->device, 8 * pk, hp[i]->stream));
+                    CM_HIP(hp[i], hipMemcpyPeerAsync(dst + 8 * pk, hp[i]->device, src + 8 * nk, hp[r]->device, 8 * pk, hp[i]->stream));
+                }
+                CM_TRY(cm_knn_merge_run(hp[i], recv.as<double>(), recv.as<int64_t>() + pk, (int)P, (int64_t)(2 * pk), p.nq, k,
+                                        metric == CM_METRIC_EUCLIDEAN ? 1 : 0, p.dist.as<double>(), p.idx.as<int64_t>()));
+                return sync(hp[i]);
+            });
+        for (size_t i = 0; i < P; ++i) { (void)hipSetDevice(hp[i]->device); packed[i].release(); }
+        (void)hipSetDevice(h->device);
+        int64_t tot = 0;
+        for (auto v : nflag) tot += v;
+        h->knn_stats[0] = tot;
     }
-    h->knn_stats[0] = nflag;
-    if (rc != CM_OK) { delete g; return rc; }
+    if (rc != CM_OK) { (void)cm_graph_destroy(h, g); return rc; }
     *out = g;
     return CM_OK;
 }
 
 cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g) {
     if (!h) return CM_E_INVALID;
+    if (g)
+        for (auto &p : g->parts) {
+            if (!p.h) continue;
+            (void)hipSetDevice(p.h->device);
+            if (p.h->a3_session && static_cast<A3Session *>(p.h->a3_session)->mp == p.indptr.as<int64_t>()) a3_session_drop(p.h);
+            p.dist.release(); p.idx.release(); p.indptr.release(); p.cols.release(); p.vals.release();
+        }
     (void)hipSetDevice(h->device);
-    if (g && h->a3_session && static_cast<A3Session *>(h->a3_session)->mp == g->indptr.as<int64_t>()) a3_session_drop(h);
     delete g;
     return CM_OK;
 }
@@ -830,56 +1007,98 @@ cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g) {
 cm_status cm_graph_knn_fetch(cm_handle_t h, cm_graph_t g, void *out_dist, int64_t *out_idx) {
     if (!h) return CM_E_INVALID;
     if (!g || !out_dist || !out_idx) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
-    CM_TRY(begin_call(h, 0));
-    const size_t nk = (size_t)g->nq * g->k;
-    CM_TRY(d2h(h, out_dist, g->dist.p, (g->dist_is_f32 ? 4 : 8) * nk));
-    CM_TRY(d2h(h, out_idx, g->idx.p, 8 * nk));
-    return sync(h);
+    const size_t des = g->dist_is_f32 ? 4 : 8;
+    return for_parts(h, g->parts.size(), part_handles(g), [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        CM_TRY(begin_call(p.h, 0));
+        const size_t nk = (size_t)p.nq * g->k, off = (size_t)p.q_lo * g->k;
+        CM_TRY(d2h(p.h, (char *)out_dist + des * off, p.dist.p, des * nk));
+        CM_TRY(d2h(p.h, out_idx + off, p.idx.p, 8 * nk));
+        return sync(p.h);
+    });
 }
 
 cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double epsilon, int64_t *out_nnz, double *out_param) {
     if (!h) return CM_E_INVALID;
     if (!g) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
-    const size_t nk = (size_t)g->nq * g->k;
-    CM_TRY(begin_call(h, 64 * 1024 + cm_scan_ws_bytes(g->nq) + cm_align(8 * nk) + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)g->nq)));
     g->has_map = false;
-    // float32 distances (cosine on float32 input) are widened on the device: the graph kernels read float64
-    const double *dd = g->dist.as<double>();
-    if (g->dist_is_f32) {
-        double *w = (double *)cm_ws_alloc(h, 8 * nk);
-        if (!w) CM_FAIL(h, CM_E_NOMEM, "graph: device workspace exhausted");
-        CM_TRY(cm_widen_f32_run(h, g->dist.as<float>(), (int64_t)nk, w));
-        dd = w;
+    const size_t P = g->parts.size();
+    const auto hs = part_handles(g);
+    auto ws_need = [&](const GraphPart &p) {
+        const size_t nk = (size_t)p.nq * g->k;
+        return 64 * 1024 + cm_scan_ws_bytes(p.nq) + cm_align(8 * nk) + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)p.nq);
+    };
+    // the GLOBAL bandwidth (knn.py:194-209): moments of every part, summed on the host in part order, handed back to every
+    // device, which then computes the parameter with the kernel a single device uses
+    std::vector<std::array<double, 3>> mom(P);
+    std::vector<double *> d_m3(P, nullptr);
+    std::vector<const double *> dd(P, nullptr);
+    auto moments_pass = [&](bool centred) {
+        return for_parts(h, P, hs, [&](size_t i) -> cm_status {
+            GraphPart &p = g->parts[i];
+            if (!centred) {
+                CM_TRY(begin_call(p.h, ws_need(p)));
+                CM_TRY(part_dist64(p, g, &dd[i]));
+                d_m3[i] = (double *)cm_ws_alloc(p.h, 64);
+                if (!d_m3[i]) CM_FAIL(p.h, CM_E_NOMEM, "graph: device workspace exhausted");
+            } else {
+                CM_HIP(p.h, hipSetDevice(p.h->device));
+            }
+            CM_HIP(p.h, hipMemsetAsync(d_m3[i], 0, 24, p.h->stream));
+            CM_TRY(cm_moments_run(p.h, dd[i], p.idx.as<int64_t>(), (int64_t)p.nq * g->k, centred ? d_m3[i] + 5 : nullptr, d_m3[i]));
+            CM_TRY(d2h(p.h, mom[i].data(), d_m3[i], 24));
+            return sync(p.h);
+        });
+    };
+    auto param_pass = [&](int which) {   // total moments -> every device -> param (d_m3 + 5)
+        double tot[3] = {0, 0, 0};
+        for (size_t i = 0; i < P; ++i) for (int j = 0; j < 3; ++j) tot[j] += mom[i][j];
+        return for_parts(h, P, hs, [&](size_t i) -> cm_status {
+            GraphPart &p = g->parts[i];
+            CM_HIP(p.h, hipSetDevice(p.h->device));
+            CM_TRY(h2d(p.h, d_m3[i], tot, 24));
+            CM_TRY(cm_param_run(p.h, d_m3[i], which, d_m3[i] + 5));
+            return sync(p.h);   // (tot lives on this stack frame)
+        });
+    };
+    CM_TRY(moments_pass(false));
+    double cnt = 0;
+    for (size_t i = 0; i < P; ++i) cnt += mom[i][2];
+    if (!(cnt > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
+    if (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) {
+        CM_TRY(param_pass(CM_KERNEL_GAUSSIAN));   // = mean
+        if (kernel == CM_KERNEL_SCARCHES) {
+            CM_TRY(moments_pass(true));
+            CM_TRY(param_pass(CM_KERNEL_SCARCHES));
+        }
     }
-    int32_t *ecols = (int32_t *)cm_ws_alloc(h, 4 * nk);
-    float *evals = (float *)cm_ws_alloc(h, 4 * nk);
-    int32_t *cnt = (int32_t *)cm_ws_alloc(h, 4 * (size_t)g->nq);
-    double *m3 = (double *)cm_ws_alloc(h, 64);
-    if (!ecols || !evals || !cnt || !m3) CM_FAIL(h, CM_E_NOMEM, "graph: device workspace exhausted");
-    double *param = m3 + 5;
-    CM_HIP(h, hipMemsetAsync(m3, 0, 64, h->stream));
-    CM_TRY(cm_moments_run(h, dd, g->idx.as<int64_t>(), (int64_t)nk, nullptr, m3));
-    double hm[3] = {0, 0, 0};
-    CM_TRY(d2h(h, hm, m3, 24));
-    CM_TRY(sync(h));
-    if (!(hm[2] > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
-    CM_TRY(kernel_param_dev(h, dd, g->idx.as<int64_t>(), (int64_t)nk, kernel, m3, param));
-    CM_TRY(cm_weights_run(h, dd, g->idx.as<int64_t>(), g->nq, g->k, g->n_ref, kernel, param, epsilon, ecols, evals, cnt, nullptr));
-    CM_TRY(g->indptr.alloc(h, 8 * ((size_t)g->nq + 1)));
-    CM_TRY(g->cols.alloc(h, 4 * nk));
-    CM_TRY(g->vals.alloc(h, 4 * nk));
-    CM_TRY(cm_ell_to_csr_run(h, ecols, evals, nullptr, cnt, g->nq, g->k, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(),
-                             nullptr));
+    std::vector<double> hp_(P, 0.0);
+    CM_TRY(for_parts(h, P, hs, [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        CM_HIP(p.h, hipSetDevice(p.h->device));
+        const size_t nk = (size_t)p.nq * g->k;
+        int32_t *ecols = (int32_t *)cm_ws_alloc(p.h, 4 * nk);
+        float *evals = (float *)cm_ws_alloc(p.h, 4 * nk);
+        int32_t *ecnt = (int32_t *)cm_ws_alloc(p.h, 4 * (size_t)p.nq);
+        if (!ecols || !evals || !ecnt) CM_FAIL(p.h, CM_E_NOMEM, "graph: device workspace exhausted");
+        double *param = d_m3[i] + 5;
+        CM_TRY(cm_weights_run(p.h, dd[i], p.idx.as<int64_t>(), p.nq, g->k, g->n_ref, kernel, param, epsilon, ecols, evals, ecnt, nullptr));
+        CM_TRY(p.indptr.alloc(p.h, 8 * ((size_t)p.nq + 1)));
+        CM_TRY(p.cols.alloc(p.h, 4 * nk));
+        CM_TRY(p.vals.alloc(p.h, 4 * nk));
+        CM_TRY(cm_ell_to_csr_run(p.h, ecols, evals, nullptr, ecnt, p.nq, g->k, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(),
+                                 nullptr));
+        CM_TRY(d2h(p.h, &p.nnz, p.indptr.as<int64_t>() + p.nq, 8));
+        CM_TRY(d2h(p.h, &hp_[i], param, 8));
+        return sync(p.h);
+    }));
     int64_t nnz = 0;
-    double hp = 0.0;
-    CM_TRY(d2h(h, &nnz, g->indptr.as<int64_t>() + g->nq, 8));
-    CM_TRY(d2h(h, &hp, param, 8));
-    CM_TRY(sync(h));
+    for (auto &p : g->parts) nnz += p.nnz;
     g->nnz = nnz;
     g->has_map = true;
     if (out_nnz) *out_nnz = nnz;
-    if (out_param) *out_param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? hp : 0.0;
+    if (out_param) *out_param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? hp_[0] : 0.0;
     return CM_OK;
 }
 
@@ -889,11 +1108,24 @@ cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double e
 cm_status cm_graph_mapping_fetch(cm_handle_t h, cm_graph_t g, int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
     if (!h) return CM_E_INVALID;
     CM_NEED_MAP(h, g);
-    CM_TRY(begin_call(h, 0));
-    CM_TRY(d2h(h, out_indptr, g->indptr.p, 8 * ((size_t)g->nq + 1)));
-    CM_TRY(d2h(h, out_cols, g->cols.p, 4 * (size_t)g->nnz));
-    CM_TRY(d2h(h, out_vals, g->vals.p, 4 * (size_t)g->nnz));
-    return sync(h);
+    std::vector<int64_t> base(g->parts.size() + 1, 0);
+    for (size_t i = 0; i < g->parts.size(); ++i) base[i + 1] = base[i] + g->parts[i].nnz;
+    CM_TRY(for_parts(h, g->parts.size(), part_handles(g), [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        CM_TRY(begin_call(p.h, 0));
+        // (the row pointer of a part starts at 0; entry nq of part i and entry 0 of part i + 1 are the same output slot:
+        // every part writes its rows' START offsets only, the last one also the end)
+        CM_TRY(d2h(p.h, out_indptr + p.q_lo, p.indptr.p, 8 * ((size_t)p.nq + (i + 1 == g->parts.size() ? 1 : 0))));
+        CM_TRY(d2h(p.h, out_cols + base[i], p.cols.p, 4 * (size_t)p.nnz));
+        CM_TRY(d2h(p.h, out_vals + base[i], p.vals.p, 4 * (size_t)p.nnz));
+        return sync(p.h);
+    }));
+    for (size_t i = 1; i < g->parts.size(); ++i) {
+        const GraphPart &p = g->parts[i];
+        const int64_t n = p.nq + (i + 1 == g->parts.size() ? 1 : 0);
+        for (int64_t r = 0; r < n; ++r) out_indptr[p.q_lo + r] += base[i];
+    }
+    return CM_OK;
 }
 
 cm_status cm_graph_label_vote(cm_handle_t h, cm_graph_t g, const int32_t *codes, int64_t n_ref, int32_t n_cat, int32_t *out_code,
@@ -901,46 +1133,87 @@ cm_status cm_graph_label_vote(cm_handle_t h, cm_graph_t g, const int32_t *codes,
     if (!h) return CM_E_INVALID;
     CM_NEED_MAP(h, g);
     if (n_ref != g->n_ref) CM_FAIL(h, CM_E_INVALID, "graph: %lld label codes for %lld reference cells", (long long)n_ref, (long long)g->n_ref);
-    CM_TRY(begin_call(h, 0));
-    DevBuf dcodes, ocode, oconf;
-    CM_TRY(dcodes.alloc(h, 4 * (size_t)n_ref)); CM_TRY(ocode.alloc(h, 4 * (size_t)g->nq)); CM_TRY(oconf.alloc(h, 4 * (size_t)g->nq));
-    CM_TRY(h2d(h, dcodes.p, codes, 4 * (size_t)n_ref));
-    CM_TRY(cm_vote_run(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, g->k, nullptr, dcodes.as<int32_t>(), n_cat,
-                       ocode.as<int32_t>(), oconf.as<float>()));
-    CM_TRY(d2h(h, out_code, ocode.p, 4 * (size_t)g->nq));
-    CM_TRY(d2h(h, out_conf, oconf.p, 4 * (size_t)g->nq));
-    return sync(h);
+    return for_parts(h, g->parts.size(), part_handles(g), [&](size_t i) -> cm_status {   // label codes replicated, votes by query slice
+        GraphPart &p = g->parts[i];
+        CM_TRY(begin_call(p.h, 0));
+        DevBuf dcodes, ocode, oconf;
+        CM_TRY(dcodes.alloc(p.h, 4 * (size_t)n_ref)); CM_TRY(ocode.alloc(p.h, 4 * (size_t)p.nq)); CM_TRY(oconf.alloc(p.h, 4 * (size_t)p.nq));
+        CM_TRY(h2d(p.h, dcodes.p, codes, 4 * (size_t)n_ref));
+        CM_TRY(cm_vote_run(p.h, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, g->k, nullptr, dcodes.as<int32_t>(), n_cat,
+                           ocode.as<int32_t>(), oconf.as<float>()));
+        CM_TRY(d2h(p.h, out_code + p.q_lo, ocode.p, 4 * (size_t)p.nq));
+        CM_TRY(d2h(p.h, out_conf + p.q_lo, oconf.p, 4 * (size_t)p.nq));
+        return sync(p.h);
+    });
 }
 
 cm_status cm_graph_spmm_dense(cm_handle_t h, cm_graph_t g, const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
     if (!h) return CM_E_INVALID;
     CM_NEED_MAP(h, g);
     if (n_ref != g->n_ref) CM_FAIL(h, CM_E_INVALID, "graph: payload with %lld rows for %lld reference cells", (long long)n_ref, (long long)g->n_ref);
-    CM_TRY(begin_call(h, 0));
-    return spmm_dense_stream(h, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq, B, n_ref, n_out, b_dtype, out);
+    const size_t es = b_dtype == CM_F64 ? 8 : 4;
+    return for_parts(h, g->parts.size(), part_handles(g), [&](size_t i) -> cm_status {   // payload streamed to every device, rows by slice
+        GraphPart &p = g->parts[i];
+        CM_TRY(begin_call(p.h, 0));
+        return spmm_dense_stream(p.h, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, B, n_ref, n_out, b_dtype,
+                                 (char *)out + es * (size_t)p.q_lo * (size_t)n_out);
+    });
 }
 
 cm_status cm_graph_spmm_csr_nnz(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
                                 int64_t n_ref, int64_t n_out, int64_t *out_indptr) {
     if (!h) return CM_E_INVALID;
     CM_NEED_MAP(h, g);
-    return spmm_csr_nnz_impl(h, nullptr, nullptr, nullptr, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq,
-                             b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr);
+    const size_t P = g->parts.size();
+    if (P == 1) {
+        GraphPart &p = g->parts[0];
+        return spmm_csr_nnz_impl(h, nullptr, nullptr, nullptr, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), g->nq, b_indptr,
+                                 b_cols, b_vals, n_ref, n_out, out_indptr);
+    }
+    if (!out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    std::vector<std::vector<int64_t>> loc(P);
+    CM_TRY(for_parts(h, P, part_handles(g), [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        loc[i].resize((size_t)p.nq + 1);
+        return spmm_csr_nnz_impl(p.h, nullptr, nullptr, nullptr, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, b_indptr,
+                                 b_cols, b_vals, n_ref, n_out, loc[i].data());
+    }));
+    int64_t base = 0;
+    for (size_t i = 0; i < P; ++i) {
+        const GraphPart &p = g->parts[i];
+        for (int64_t r = 0; r < p.nq; ++r) out_indptr[p.q_lo + r] = base + loc[i][(size_t)r];
+        base += loc[i][(size_t)p.nq];
+    }
+    out_indptr[g->nq] = base;
+    return CM_OK;
 }
 
 cm_status cm_graph_spmm_csr(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals,
                             int64_t n_ref, int64_t n_out, const int64_t *out_indptr, int32_t *out_cols, float *out_vals) {
     if (!h) return CM_E_INVALID;
     CM_NEED_MAP(h, g);
-    return spmm_csr_fill_impl(h, nullptr, nullptr, nullptr, g->indptr.as<int64_t>(), g->cols.as<int32_t>(), g->vals.as<float>(), g->nq,
-                              b_indptr, b_cols, b_vals, n_ref, n_out, out_indptr, out_cols, out_vals);
+    const size_t P = g->parts.size();
+    if (P == 1) {
+        GraphPart &p = g->parts[0];
+        return spmm_csr_fill_impl(h, nullptr, nullptr, nullptr, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), g->nq, b_indptr,
+                                  b_cols, b_vals, n_ref, n_out, out_indptr, out_cols, out_vals);
+    }
+    if (!out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
+    return for_parts(h, P, part_handles(g), [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        const int64_t base = out_indptr[p.q_lo];
+        std::vector<int64_t> loc((size_t)p.nq + 1);   // the part's row pointer, relative to its first entry
+        for (int64_t r = 0; r <= p.nq; ++r) loc[(size_t)r] = out_indptr[p.q_lo + r] - base;
+        return spmm_csr_fill_impl(p.h, nullptr, nullptr, nullptr, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, b_indptr,
+                                  b_cols, b_vals, n_ref, n_out, loc.data(), out_cols + base, out_vals + base);
+    });
 }
 
 cm_status cm_graph_info(cm_handle_t h, cm_graph_t g, int64_t out[8]) {
     if (!h) return CM_E_INVALID;
     if (!g || !out) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
     out[0] = g->nq; out[1] = g->n_ref; out[2] = g->k; out[3] = g->metric; out[4] = g->dist_is_f32; out[5] = g->has_map ? 1 : 0;
-    out[6] = g->nnz; out[7] = 0;
+    out[6] = g->nnz; out[7] = (int64_t)g->parts.size();   // [7]: devices the graph is spread over
     return CM_OK;
 }
 

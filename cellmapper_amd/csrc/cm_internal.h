@@ -37,6 +37,10 @@ struct cm_handle_s {
     size_t pool_bytes = 0;
     hipStream_t copy_stream = nullptr;   // D2H of finished output tiles while the next tile is computed (host tier)
     hipEvent_t tile_ev[2] = {nullptr, nullptr};
+    // multi-device handle (cm_create_multi): the OTHER GPUs' contexts, owned by this handle.  The handle itself is the
+    // first device's context, so every single-device entry point keeps working on it unchanged; the graph tier
+    // (cm_rep_* / cm_graph_*) and cm_knn spread over all of them (cm_api.hip, "multi-device").
+    std::vector<cm_handle_s *> peers;
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;
     hipEvent_t ev[CM_N_STAGE_EVENTS] = {};

@@ -849,7 +849,9 @@ cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_i
     if (k < 1 || k > W_KMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "mapping matrix: %d neighbours per row exceeds the supported %d", k, W_KMAX);
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     if (nq == 0) return CM_OK;
-    const bool reg_ok = n_ref > 0 && n_ref <= (1LL << 25) && !getenv("CELLMAP_WEIGHTS_LDS");   // (n_ref <= 0: unknown column range)
+    // (n_ref <= 0: unknown column range.  STRICTLY below 2^25: the sorted kernel's key is (column << 7) | position with 0xffffffff as
+    // the invalid sentinel, which column 2^25 - 1 at position 127 would collide with)
+    const bool reg_ok = n_ref > 0 && n_ref < (1LL << 25) && !getenv("CELLMAP_WEIGHTS_LDS");
     if (reg_ok && k <= 128) {   // register-resident sort: one row per 32 lanes, per wave, or per wave with two entries per lane
         if (k <= 32)
             hipLaunchKernelGGL((weights_rows_sorted<32, 1>), dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,

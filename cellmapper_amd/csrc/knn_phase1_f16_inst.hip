@@ -1,7 +1,6 @@
 // Instantiations + launcher of the split-fp16 phase-1 kernel (knn_phase1_f16.h).
 #include "cm_internal.h"
 #include "knn_phase1_f16.h"
-#include "knn_phase1_q4.h"
 
 template <int KSTEPS, int NP, bool CEN = false, int SEEDL = 0>
 static cm_status launch_f16(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
@@ -36,17 +35,6 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
         break;
     }
     CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d with %d products", KSTEPS, a.nprod);
-}
-
-// four accumulators per wave (knn_phase1_q4.h): hi*hi level, K = 64, full-set scans without a work list
-cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
-    if ((KSTEPS != 4 && KSTEPS != 2) || a.nprod != 1 || a.side || a.wlist || a.seed_len)
-        CM_FAIL(h, CM_E_INTERNAL, "phase1/f16q: instantiated for the hi*hi level at K <= 64 without work lists");
-    auto kern = KSTEPS == 4 ? cmk2::knn_cand_f16q<4> : cmk2::knn_cand_f16q<2>;
-    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
-    CM_HIP(h, hipGetLastError());
-    return CM_OK;
 }
 
 cm_status cm_p1direct_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);

@@ -19,6 +19,10 @@
 namespace cmk2 {
 
 constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumulator kernel
+#ifndef CM2Q_EXP
+#define CM2Q_EXP 0   // timing experiments only (scripts/ablate_q4.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads,
+                     // 8 no min trees, 16 no threshold test, 64 thresholds at -inf (never append)
+#endif
 #ifndef CM2Q_PRIO
 #define CM2Q_PRIO 0   // wave priority while an append event is handled (s_setprio; 0 = leave it alone)
 #endif
@@ -28,7 +32,7 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
     {                                                                                                          \
         unsigned long long te0_ = 0;                                                                           \
         if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(CM2Q_PRIO);   /* the event is on the path to the tile barrier */ \
-        if (a.dbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                        \
+        if (adbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                        \
         const float tj_ = thr[J];                                                                              \
         int cj_ = cnt[J];                                                                                      \
         const unsigned loff_ = (unsigned)((((J) * 32 + c) * 2 + hh) * CL * 8);                                 \
@@ -36,12 +40,16 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
         CM2_GROUP_B(ACC, T3, 3, RB, loff_) CM2_GROUP_B(ACC, T4, 4, RB, loff_)                                  \
         if (__ballot((ACC)[15] < tj_) != 0ull) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                          \
         cnt[J] = cj_;                                                                                          \
-        if (a.dbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                         \
+        if (adbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                         \
         if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(0);                                                          \
     }
 
-template <int KSTEPS>
+// DBG = false is the production body: the CELLMAP_DBG modes (adbg: 1 never append, 2 skip the filter, 4 in-kernel
+// counters) are compiled out -- they cost two vector and a dozen scalar instructions per accumulator and sub-tile, and
+// the counters' SGPRs spilled (round 3).  The host launches DBG = true only when CELLMAP_DBG is set.
+template <int KSTEPS, bool DBG>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
+    const int adbg = DBG ? a.dbg : 0;
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = img_row_bytes(KSTEPS, true);
     constexpr int GTILEB = img_tile_bytes(KSTEPS, true);
@@ -83,14 +91,14 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
 
     unsigned long long c_br = 0, c_app = 0, c_pr = 0, c_prcyc = 0, c_evcyc = 0, c_barcyc = 0, c_dmacyc = 0;
     unsigned long long c_procyc = 0, c_loopcyc = 0, c_fincyc = 0;
-    const unsigned long long c_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c_t0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n_work = a.nqb * a.S;
     for (int work = blockIdx.x; work < n_work; work += (int)gridDim.x) {
         const int qb = work / a.S, split = work - qb * a.S;
         const int t0 = split * a.tiles_per_split;
         const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
         const int64_t qbase = (int64_t)qb * QBQ + wave * 128;
-        const unsigned long long tw0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tw0_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
 
         // ---- query fragments (B operand) of the wave's 128 queries: hi halves only (hi*hi level)
         half8 qh[NJ][KSTEPS];
@@ -104,9 +112,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[j][s]));
-        const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
+        const float thr_init = (((adbg & 1) | (CM2Q_EXP & 64)) != 0) ? -INFINITY : INFINITY;
         float thr[NJ] = {thr_init, thr_init, thr_init, thr_init};
-        if (a.thr0) {
+        if (a.thr0 && !(CM2Q_EXP & 64)) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) thr[j] = a.thr0[qbase + j * 32 + c];
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]));
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
 #define CM2Q_PUT(ARR, J, V) { if ((J) == 0) ARR[0] = (V); else if ((J) == 1) ARR[1] = (V); else if ((J) == 2) ARR[2] = (V); else ARR[3] = (V); }
 #define CM2Q_MERGE_PASS(LIM_)                                                                                  \
     {                                                                                                          \
-        unsigned long long tp0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                           \
+        unsigned long long tp0_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
         _Pragma("unroll 1") for (int j = 0; j < NJ; ++j) {                                                     \
             int cj_ = CM2Q_SEL(cnt, j), kj_ = CM2Q_SEL(keptn, j);                                              \
@@ -136,11 +144,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
                 int nn = wave_merge_prune(nullptr, kq, nk, wlbuf + (size_t)(wq * 2) * CL, n0,                  \
                                           wlbuf + (size_t)(wq * 2 + 1) * CL, n1, a.Kc, kq, nullptr, &tq, lane); \
                 if (c == ql_) { cj_ = 0; kj_ = nn; tj_ = tq; }                                                 \
-                if (a.dbg & 4) { ++c_pr; c_app += n0 + n1; }                                                   \
+                if (adbg & 4) { ++c_pr; c_app += n0 + n1; }                                                   \
             }                                                                                                  \
             CM2Q_PUT(cnt, j, cj_) CM2Q_PUT(keptn, j, kj_) CM2Q_PUT(thr, j, tj_)                                \
         }                                                                                                      \
-        if (a.dbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                         \
+        if (adbg & 4) c_prcyc += __builtin_amdgcn_s_memtime() - tp0_;                                         \
     }
 
         __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         }
         int ptile = CM2Q_PT(t0), ptile_a = CM2Q_PT(t0 + AHEAD);
         const int pstep = a.perm_mul > 1u ? (int)(a.perm_mul % (unsigned)a.n_tiles) : 1;
-        const unsigned long long tw1_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tw1_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
 
         // min tree of accumulator P in 8 steps: T0..T4 = minima of registers 3g..3g+2, U0 / U1 / TOT above them
 #define CM2Q_TREE_STEP(I, P, T, U, TOT)                                                                        \
@@ -196,13 +204,15 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s) {                                               \
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CUR[s], qh[j][s], s == 0 ? zero_ : acc[j], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
-                if (j == 0) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \
-                _Pragma("unroll") for (int q_ = 0; q_ < 8 / KSTEPS; ++q_)                                      \
-                    CM2Q_TREE_STEP(s * (8 / KSTEPS) + q_, acc[jp], T_, U_, tot_)                               \
-                if (j == 1 && s == 0 && (ST) < NPIECE && t + AHEAD < t1) CM2Q_DMA_PIECE(ptile_a, (t + AHEAD) % RING, (ST)); \
+                if (j == 0 && !(CM2Q_EXP & 4)) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \
+                if (!(CM2Q_EXP & 8)) { _Pragma("unroll") for (int q_ = 0; q_ < 8 / KSTEPS; ++q_)                 \
+                    CM2Q_TREE_STEP(s * (8 / KSTEPS) + q_, acc[jp], T_, U_, tot_) }                               \
+                if (!(CM2Q_EXP & 1) && j == 1 && s == 0 && (ST) < NPIECE && t + AHEAD < t1) CM2Q_DMA_PIECE(ptile_a, (t + AHEAD) % RING, (ST)); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                                  \
-            if (!(a.dbg & 2)) {                                                                                \
+            if (CM2Q_EXP & 8) asm volatile("" ::"v"(acc[jp][0]), "v"(acc[jp][7]), "v"(acc[jp][15]));                \
+            else if (CM2Q_EXP & 16) asm volatile("" ::"v"(tot_));                                              \
+            if (!(adbg & 2) && !(CM2Q_EXP & 16)) {                                                            \
                 const bool pass_ = tot_ < thr[jp];                                                             \
                 if (__ballot(pass_) != 0ull) {                                                                 \
                     const int rbj_ = jp >= 2 ? rb_prev : rb_cur;                                               \
@@ -213,13 +223,13 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
     }
 
         for (int t = t0; t < t1; ++t) {
-            unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+            unsigned long long tb0_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0 && (BT == 1 || (t - t0) % BT == 0)) {
                 if (t + AHEAD - 1 >= t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * NPIECE) : "memory");
-                if (a.dbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
-                __builtin_amdgcn_s_barrier();
-                if (a.dbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
+                if (adbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
+                if (!(CM2Q_EXP & 2)) __builtin_amdgcn_s_barrier();
+                if (adbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
             }
             const unsigned tile = ldsbase + (t % RING) * TILEB;
             const unsigned tile_n = ldsbase + ((t + 1) % RING) * TILEB;
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f_) : "v"(fl_ + 4 * (t & 1)) : "memory");
                 if (__builtin_amdgcn_readfirstlane(f_) == t) next_refresh = t;
             }
-            if (!(a.dbg & 3)) {   // end of tile: scheduled refresh, or logs that could overflow during the next tile
+            if (!(adbg & 3)) {   // end of tile: scheduled refresh, or logs that could overflow during the next tile
                 constexpr int FULL_ = CL - 16 * NST;
                 const bool sched_ = t == next_refresh;
                 if (sched_ || __ballot(cnt[0] > FULL_ || cnt[1] > FULL_ || cnt[2] > FULL_ || cnt[3] > FULL_) != 0ull) {
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             ptile_a += pstep; if (ptile_a >= a.n_tiles) ptile_a -= a.n_tiles;
         }
         // drain: accumulators 2 and 3 of the last sub-tile have not been filtered yet
-        if (!(a.dbg & 2)) {
+        if (!(adbg & 2)) {
 #pragma unroll
             for (int jp = 2; jp < 4; ++jp) {
                 float T_[5], U_[2], tot_ = INFINITY;
@@ -263,11 +273,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
                 if (__ballot(tot_ < thr[jp]) != 0ull) CM2Q_EVENT(acc[jp], T_[0], T_[1], T_[2], T_[3], T_[4], jp, rb_cur)
             }
         }
-        if (a.dbg & 2) asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][15]), "v"(acc[3][15]));
+        if (adbg & 2) asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][15]), "v"(acc[3][15]));
 #undef CM2Q_SUBTILE
 #undef CM2Q_TREE_STEP
 
-        const unsigned long long tw2_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tw2_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
         // final merge: K' candidate rows (-1 padded) and the threshold of every query of the wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
                 if (lane == 0) a.cthr[qg * a.S + split] = tq;
             }
         }
-        if (a.dbg & 4) {
+        if (adbg & 4) {
             const unsigned long long tw3_ = __builtin_amdgcn_s_memtime();
             c_procyc += tw1_ - tw0_; c_loopcyc += tw2_ - tw1_; c_fincyc += tw3_ - tw2_;
         }
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
 #undef CM2Q_DMA_TILE
 #undef CM2Q_DMA_PIECE
 #undef CM2Q_PT
-    if ((a.dbg & 4) && lane == 0) {
+    if (DBG && (adbg & 4) && lane == 0) {
         atomicAdd(&a.ctr[0], c_br);
         atomicAdd(&a.ctr[1], c_app);
         atomicAdd(&a.ctr[2], c_pr);

@@ -1,24 +1,36 @@
-"""Reference-sharded k-NN -> kernel -> label transfer across the GPUs of one node.
+"""Reference-sharded k-NN -> kernel -> transfer across the GPUs of one node.
 
 Layout (2-D): ``world = query groups x reference shards``, rank = group * shards + shard.  A rank holds the reference
-rows ``[lo, hi)`` of its shard (contiguous split), the full label-code vector, and the query rows of its group
-(pure reference sharding = one group = every rank holds ALL queries).  Per step, inside a reference-shard group:
+rows ``[lo, hi)`` of its shard (contiguous split), the query rows of its group (pure reference sharding = one group =
+every rank holds ALL queries) and the small reference-side payloads in full (label codes, ``.obsm`` columns).  Per step,
+inside a reference-shard group:
 
 1. local exact top-k of every query against the rank's shard, with GLOBAL reference indices (``idx_offset``)
    and squared float64 distances;
 2. ONE collective over RCCL/xGMI on a packed buffer (distances and indices travel together): an all-to-all by
    query slice -- rank j receives, from every rank, the local top-k of query slice j -- ``[world, 2, nq/world, k]``
-   (8x less traffic than an all-gather of the full lists; ``exchange="allgather"`` is the all-gather variant of the
+   (shards x less traffic than an all-gather of the full lists; ``exchange="allgather"`` is the all-gather variant of the
    north-star wording);
 3. k-way merge by (distance, global index): the same tie rule as the single-GPU search, so indices stay exact;
 4. the global kernel bandwidth needs the mean (and for scarches the variance) of ALL nq*k distances: a
-   3-double all-reduce;
-5. weights / normalisation / label vote on the rank's query slice (label codes replicated).
+   3-double all-reduce over the whole world;
+5. weights / normalisation on the rank's query slice -> its rows of the mapping matrix ("ELL": k columns per row).
+
+Aggregation (second half of 8e; reference: ``cellmapper.py:338,373,595-605`` do all of it on one CPU thread):
+
+* labels and ``.obsm`` (tens of MB): the payload is REPLICATED, every rank transfers onto its own query slice -- no
+  communication (:func:`sharded_map_labels`, :func:`sharded_map_obsm`); outputs are query-sliced;
+* wide ``.X`` / layers, dense or CSR: GENE COLUMNS are sharded -- rank r holds ``X[:, g_lo:g_hi]`` -- and the mapping matrix
+  is replicated by ONE all-gather of its ELL rows (366 MB at 1.5 M x 30); every rank then multiplies ALL query rows with
+  its slab (:func:`gather_mapping_rows` + :func:`sharded_map_layer_dense` / ``_csr``): no further communication, outputs
+  are column-sliced, and a column's sum is the same sequence of multiply-adds as on one GPU (bit-identical).
 
 The compute calls are injected (``ops``) so that the choreography can be unit-tested on CPU with gloo; in
 production ``ops`` is :class:`HipOps` (device tensors through the C ABI).
 """
 from __future__ import annotations
+
+import sys
 
 import numpy as np
 
@@ -67,13 +79,42 @@ class HipOps:
     def param(self, m3, kernel):
         return self.p.kernel_param(m3, kernel)
 
-    def weights_vote(self, dist, idx, n_ref, kernel, param, codes, n_cat, epsilon):
-        cols, vals, cnt = self.p.weights(dist, idx, n_ref, kernel, param, epsilon)
+    def weights(self, dist, idx, n_ref, kernel, param, epsilon):
+        """K1-K3 on the rank's rows: ELL mapping-matrix rows ``(cols int32 [n,k], vals float32 [n,k], cnt int32 [n])``."""
+        return self.p.weights(dist, idx, n_ref, kernel, param, epsilon)
+
+    def vote(self, cols, vals, cnt, codes, n_cat):
         indptr, oc, ov = self.p.to_csr(cols, vals, cnt)
         return self.p.label_vote(indptr, oc, ov, codes, n_cat)
 
+    def weights_vote(self, dist, idx, n_ref, kernel, param, codes, n_cat, epsilon):
+        cols, vals, cnt = self.weights(dist, idx, n_ref, kernel, param, epsilon)
+        return self.vote(cols, vals, cnt, codes, n_cat)
+
+    def to_csr(self, cols, vals, cnt):
+        return self.p.to_csr(cols, vals, cnt)
+
+    def spmm_dense(self, csr, B, out=None):
+        return self.p.spmm_dense(csr[0], csr[1], csr[2], B, out=out)
+
+    def spmm_csr(self, csr, b_csr, n_out):
+        """``M @ B`` for a CSR payload (two-pass form: exact allocation) -> ``(out_indptr, out_cols, out_vals)``."""
+        return self.p.spmm_csr(csr[0], csr[1], csr[2], b_csr[0], b_csr[1], b_csr[2], n_out)
+
     def empty_words(self, n, like):
         return self.t.empty((n,), dtype=self.t.int64, device=like.device)
+
+    def empty_i32(self, n, like):
+        return self.t.empty((n,), dtype=self.t.int32, device=like.device)
+
+    def cat(self, parts):
+        return self.t.cat(parts)
+
+    def equal(self, a, b):
+        return bool(self.t.equal(a, b))
+
+    def flag(self, ok: bool, like):
+        return self.t.tensor([1 if ok else 0], dtype=self.t.int32, device=like.device)
 
 
 def grid_2d(world: int, ref_shards: int | None = None):
@@ -90,6 +131,30 @@ def grid_2d(world: int, ref_shards: int | None = None):
     while world % ref_shards:
         ref_shards -= 1
     return world // ref_shards, ref_shards
+
+
+class Layout:
+    """Who owns what in the 2-D layout: ``rank = group * ref_shards + ref_rank``.  All row numbers are GLOBAL query rows."""
+
+    def __init__(self, world: int, rank: int, nq_total: int, ref_shards: int | None = None):
+        self.world, self.rank, self.nq_total = int(world), int(rank), int(nq_total)
+        self.n_groups, self.ref_shards = grid_2d(world, ref_shards)
+        self.group, self.ref_rank = rank // self.ref_shards, rank % self.ref_shards
+        self.group_lo, self.group_hi = shard_bounds(nq_total, self.n_groups, self.group)   # the queries this rank searches
+
+    def slice_of(self, r: int):
+        """Global query rows [lo, hi) whose merged lists (and mapping-matrix rows) rank ``r`` owns after the exchange."""
+        g, s = r // self.ref_shards, r % self.ref_shards
+        g_lo, g_hi = shard_bounds(self.nq_total, self.n_groups, g)
+        lo, hi = slice_bounds(g_hi - g_lo, self.ref_shards, s)
+        return g_lo + lo, g_lo + hi
+
+    def all_slices(self):
+        return [self.slice_of(r) for r in range(self.world)]
+
+    @property
+    def my_slice(self):
+        return self.slice_of(self.rank)
 
 
 class WorldSlice:
@@ -125,8 +190,151 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int, exchange: 
 SUPPORTED_METRICS = ("euclidean", "cosine", "manhattan", "chebyshev")
 
 
+class ExchangeState:
+    """Which exchange a run uses, decided on its FIRST step.  The default all-to-all of the 2-D layout (split sizes that are
+    zero outside the rank's reference-shard group) could never be exercised between two real GPUs before the first hardware
+    run, so that step runs it NEXT TO the plain world-wide all-gather -- every rank receives every rank's lists through the
+    default communicator, the least exotic collective there is -- and compares the two merged results bit for bit.  If the
+    all-to-all raises, or the results differ on any rank (one all-reduce of a flag), the run continues on the all-gather
+    in the same process group: nothing is re-executed, and the bench line says which exchange ran and why."""
+
+    def __init__(self, requested: str = "alltoall", selfcheck: bool = True):
+        self.requested = requested
+        self.mode = requested            # "alltoall" | "allgather" | "allgather_world"
+        self.selfcheck = selfcheck and requested == "alltoall"
+        self.checked = False
+        self.note = None                 # why the run left the requested exchange (None = it did not)
+        self.pad_words = None            # world all-gather: words per rank (max over the query groups)
+
+    def describe(self):
+        return {"requested": self.requested, "used": self.mode, "self_check": ("passed" if self.checked and self.note is None
+                else ("not run" if not self.checked else "FAILED: " + str(self.note)))}
+
+
+def _world_allgather_merge(ops, dist_mod, send, group, world, rank, nq_pad, k, n_mine, metric, state):
+    """The exchange through ONE all-gather of the whole world (default communicator): rank r's packed buffer lands at
+    ``r * pad`` words; the lists of this rank's query slice are merged out of its group's parts."""
+    n_all = dist_mod.get_world_size()
+    words = 2 * nq_pad * k
+    if state.pad_words is None:   # groups of a ragged split differ by one query: pad every rank's buffer to the largest
+        w = ops.flag(True, send).to(dtype=send.dtype) * words
+        dist_mod.all_reduce(w, op=dist_mod.ReduceOp.MAX)
+        state.pad_words = int(w.item())
+    pad = state.pad_words
+    flat = send.view(-1)
+    if pad != words:
+        padded = ops.empty_words(pad, send)
+        padded[:words] = flat
+        flat = padded
+    recv = ops.empty_words(n_all * pad, send)
+    dist_mod.all_gather_into_tensor(recv, flat)
+    first = group.first if isinstance(group, WorldSlice) else 0
+    pk = (nq_pad // world) * k
+    return ops.merge_packed(recv, world, pad, first * pad + rank * pk, first * pad + nq_pad * k + rank * pk, n_mine, k, metric)
+
+
+def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", exchange="alltoall", group=None,
+                ref_world=None, ref_rank=None, state: ExchangeState | None = None):
+    """Steps 1-3 of the module docstring.  Returns ``(dist, idx, (q_lo, q_hi))``: the merged exact lists of this rank's query
+    slice (``(q_lo, q_hi)`` relative to ``qry``).  ``exchange`` may be an :class:`ExchangeState` (first-step self-check and
+    fall-back, see there) passed as ``state``; a plain string runs that exchange unchecked."""
+    if metric not in SUPPORTED_METRICS:
+        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, cosine, manhattan, chebyshev).")
+    n_all = dist_mod.get_world_size()
+    world = n_all if ref_world is None else ref_world
+    rank = dist_mod.get_rank() if ref_rank is None else ref_rank
+    mode = state.mode if state is not None else exchange
+    nq = qry.shape[0]
+    per = (nq + world - 1) // world
+    nq_pad = per * world
+    send = ops.local_knn_packed(ref_shard, qry, k, metric, shard_lo, nq_pad)   # [2, nq_pad, k] 8-byte words
+    pk = per * k
+    if world == 1:
+        dist, idx = ops.merge_packed(send, 1, 2 * nq_pad * k, 0, nq_pad * k, nq, k, metric)
+        return dist, idx, (0, nq)
+    q_lo, q_hi = slice_bounds(nq, world, rank)
+    n_mine = max(q_hi - q_lo, 0)
+
+    def run_alltoall():
+        # chunk j of the send buffer = what rank j merges: [2][per][k] of query slice j
+        packed = send.view(2, world, pk).transpose(0, 1).contiguous().view(-1)
+        recv = ops.empty_words(world * 2 * pk, send)
+        if isinstance(group, WorldSlice):   # the group's all-to-all inside the world's: empty chunks for everybody else
+            splits = [2 * pk if group.first <= r < group.first + group.count else 0 for r in range(n_all)]
+            dist_mod.all_to_all_single(recv, packed, output_split_sizes=splits, input_split_sizes=splits)
+        else:
+            dist_mod.all_to_all_single(recv, packed, group=group)
+        return ops.merge_packed(recv, world, 2 * pk, 0, pk, n_mine, k, metric)
+
+    def run_allgather():
+        if isinstance(group, WorldSlice):
+            raise ValueError("the all-gather exchange of a 2-D layout needs a process group (make_groups(..., exchange='allgather'))")
+        recv = ops.empty_words(world * 2 * nq_pad * k, send)
+        dist_mod.all_gather_into_tensor(recv, send.view(-1), group=group)
+        return ops.merge_packed(recv, world, 2 * nq_pad * k, rank * pk, nq_pad * k + rank * pk, n_mine, k, metric)
+
+    if mode == "alltoall":
+        if state is not None and state.selfcheck and not state.checked:
+            ok, err, got = True, None, None
+            try:
+                got = run_alltoall()
+            except Exception as e:   # (RCCL rejects the call on every rank alike: the arguments are symmetric)
+                ok, err = False, f"{type(e).__name__}: {e}"
+            want = _world_allgather_merge(ops, dist_mod, send, group, world, rank, nq_pad, k, n_mine, metric, state)
+            if ok:
+                ok = ops.equal(got[0], want[0]) and ops.equal(got[1], want[1])
+                if not ok:
+                    err = "merged lists differ from the world all-gather route"
+            f = ops.flag(ok, send)
+            dist_mod.all_reduce(f, op=dist_mod.ReduceOp.MIN)
+            state.checked = True
+            if int(f.item()) == 0:
+                state.mode, state.note = "allgather_world", err or "another rank reported a mismatch"
+                print(f"[sharded] rank {dist_mod.get_rank()}: all-to-all exchange failed its self-check ({state.note}); "
+                      f"continuing on the world all-gather", file=sys.stderr, flush=True)
+            dist, idx = want
+        else:
+            dist, idx = run_alltoall()
+    elif mode == "allgather":
+        dist, idx = run_allgather()
+    elif mode == "allgather_world":
+        st = state if state is not None else ExchangeState("allgather_world", selfcheck=False)
+        dist, idx = _world_allgather_merge(ops, dist_mod, send, group, world, rank, nq_pad, k, n_mine, metric, st)
+    else:
+        raise ValueError(f"unknown exchange '{mode}'")
+    return dist, idx, (q_lo, q_hi)
+
+
+def global_kernel_param(ops, dist_mod, dist, idx, kernel):
+    """Step 4: the reference's GLOBAL bandwidth (``knn.py:194-209``) from moments all-reduced over the whole world."""
+    if kernel not in ("gaussian", "scarches"):
+        return None
+    n_all = dist_mod.get_world_size()
+    m = ops.moments(dist, idx)
+    if n_all > 1:
+        dist_mod.all_reduce(m)
+    param = ops.param(m, "gaussian")  # mean distance
+    if kernel == "scarches":
+        m2 = ops.moments(dist, idx, center=param)
+        if n_all > 1:
+            dist_mod.all_reduce(m2)
+        param = ops.param(m2, "scarches")
+    return param
+
+
+def sharded_mapping_rows(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, metric="euclidean", kernel="gaussian",
+                         epsilon=1e-8, exchange="alltoall", group=None, ref_world=None, ref_rank=None, state=None):
+    """Steps 1-5: this rank's rows of the row-normalised mapping matrix.  Returns a dict: ``cols / vals / cnt`` (ELL),
+    ``dist / idx`` (merged lists), ``bounds`` (slice relative to ``qry``), ``param``."""
+    dist, idx, qb = sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric, exchange, group, ref_world, ref_rank, state)
+    param = global_kernel_param(ops, dist_mod, dist, idx, kernel)
+    cols, vals, cnt = ops.weights(dist, idx, n_ref_total, kernel, param, epsilon)
+    return dict(cols=cols, vals=vals, cnt=cnt, dist=dist, idx=idx, bounds=qb, param=param)
+
+
 def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, codes, n_cat, metric="euclidean",
-                       kernel="gaussian", epsilon=1e-8, exchange="alltoall", group=None, ref_world=None, ref_rank=None):
+                       kernel="gaussian", epsilon=1e-8, exchange="alltoall", group=None, ref_world=None, ref_rank=None,
+                       state=None):
     """Run one sharded step.  Returns ``(code, conf, (q_lo, q_hi), dist, idx)`` for this rank's query slice.
 
     ``dist_mod`` is ``torch.distributed`` (already initialised); ``ops`` supplies compute (HipOps in production).
@@ -138,52 +346,64 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
     words): ``all_to_all_single`` of ``[world][2][per][k]`` (default), or ``all_gather_into_tensor`` of ``[2][nq_pad][k]``.
     Shard-local lists carry the float64 values the single-GPU search ranks by (squared euclidean; float64 cosine even
     for float32 input), so the merged order -- and therefore every index -- equals the unsharded result.
+    Label codes are replicated (A0, ``cellmapper.py:589-623``): the vote needs no communication.
     """
     if metric not in SUPPORTED_METRICS:
         raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, cosine, manhattan, chebyshev).")
-    n_all = dist_mod.get_world_size()
-    world = n_all if ref_world is None else ref_world
-    rank = dist_mod.get_rank() if ref_rank is None else ref_rank
-    nq = qry.shape[0]
-    per = (nq + world - 1) // world
-    nq_pad = per * world
-    send = ops.local_knn_packed(ref_shard, qry, k, metric, shard_lo, nq_pad)   # [2, nq_pad, k] 8-byte words
-    pk = per * k
-    if world == 1:
-        q_lo, q_hi = 0, nq
-        dist, idx = ops.merge_packed(send, 1, 2 * nq_pad * k, 0, nq_pad * k, nq, k, metric)
-    else:
-        q_lo, q_hi = slice_bounds(nq, world, rank)
-        n_mine = max(q_hi - q_lo, 0)
-        if exchange == "alltoall":
-            # chunk j of the send buffer = what rank j merges: [2][per][k] of query slice j
-            packed = send.view(2, world, pk).transpose(0, 1).contiguous().view(-1)
-            recv = ops.empty_words(world * 2 * pk, send)
-            if isinstance(group, WorldSlice):   # the group's all-to-all inside the world's: empty chunks for everybody else
-                splits = [2 * pk if group.first <= r < group.first + group.count else 0 for r in range(n_all)]
-                dist_mod.all_to_all_single(recv, packed, output_split_sizes=splits, input_split_sizes=splits)
-            else:
-                dist_mod.all_to_all_single(recv, packed, group=group)
-            dist, idx = ops.merge_packed(recv, world, 2 * pk, 0, pk, n_mine, k, metric)
-        elif exchange == "allgather":
-            recv = ops.empty_words(world * 2 * nq_pad * k, send)
-            if isinstance(group, WorldSlice):
-                raise ValueError("the all-gather exchange of a 2-D layout needs a process group (make_groups(..., exchange='allgather'))")
-            dist_mod.all_gather_into_tensor(recv, send.view(-1), group=group)
-            dist, idx = ops.merge_packed(recv, world, 2 * nq_pad * k, rank * pk, nq_pad * k + rank * pk, n_mine, k, metric)
-        else:
-            raise ValueError(f"unknown exchange '{exchange}'")
-    # global bandwidth: all-reduce the moments of the merged distances
-    param = None
-    if kernel in ("gaussian", "scarches"):
-        m = ops.moments(dist, idx)
-        if n_all > 1:
-            dist_mod.all_reduce(m)
-        param = ops.param(m, "gaussian")  # mean distance
-        if kernel == "scarches":
-            m2 = ops.moments(dist, idx, center=param)
-            if n_all > 1:
-                dist_mod.all_reduce(m2)
-            param = ops.param(m2, "scarches")
-    code, conf = ops.weights_vote(dist, idx, n_ref_total, kernel, param, codes, n_cat, epsilon)
-    return code, conf, (q_lo, q_hi), dist, idx
+    r = sharded_mapping_rows(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, metric, kernel, epsilon, exchange, group,
+                             ref_world, ref_rank, state)
+    code, conf = ops.vote(r["cols"], r["vals"], r["cnt"], codes, n_cat)
+    return code, conf, r["bounds"], r["dist"], r["idx"]
+
+
+def sharded_map_obsm(ops, rows, payload):
+    """A1 / A0n on this rank's query slice with a REPLICATED dense payload ``[n_ref, d_out]`` (``cellmapper.py:338,628``):
+    no communication; the output rows are those of ``rows['bounds']``."""
+    return ops.spmm_dense(ops.to_csr(rows["cols"], rows["vals"], rows["cnt"]), payload)
+
+
+def gather_mapping_rows(ops, dist_mod, rows, layout: Layout):
+    """Replicate the mapping matrix: ONE all-gather (whole world, default communicator) of every rank's ELL rows, packed as
+    int32 words ``[per_max][k] columns | [per_max][k] value bits | [per_max] counts``.  Returns ``(cols [nq, k], vals [nq, k],
+    cnt [nq])`` in GLOBAL query order (8 bytes per entry: 366 MB at 1.5 M x 30)."""
+    cols, vals, cnt = rows["cols"], rows["vals"], rows["cnt"]
+    k = cols.shape[1]
+    if layout.world == 1:
+        return cols, vals, cnt
+    slices = layout.all_slices()
+    per_max = max(hi - lo for lo, hi in slices)
+    n_mine = cols.shape[0]
+    if n_mine != slices[layout.rank][1] - slices[layout.rank][0]:
+        raise ValueError("gather_mapping_rows: this rank's rows do not match its slice of the layout")
+    words = per_max * (2 * k + 1)
+    send = ops.empty_i32(words, cols)
+    if n_mine < per_max:
+        send.zero_()
+    send[:per_max * k].view(per_max, k)[:n_mine] = cols
+    send[per_max * k:2 * per_max * k].view(per_max, k)[:n_mine] = vals.view(cols.dtype)
+    send[2 * per_max * k:][:n_mine] = cnt
+    recv = ops.empty_i32(layout.world * words, cols)
+    dist_mod.all_gather_into_tensor(recv, send)
+    parts_c, parts_v, parts_n = [], [], []
+    for r, (lo, hi) in enumerate(slices):
+        base = r * words
+        n = hi - lo
+        parts_c.append(recv[base:base + per_max * k].view(per_max, k)[:n])
+        parts_v.append(recv[base + per_max * k:base + 2 * per_max * k].view(per_max, k)[:n])
+        parts_n.append(recv[base + 2 * per_max * k:base + words][:n])
+    return ops.cat(parts_c), ops.cat(parts_v).view(vals.dtype), ops.cat(parts_n)
+
+
+def sharded_map_layer_dense(ops, full_rows, payload_slab, out=None):
+    """A2 with gene-column sharding (``cellmapper.py:372-373``): ``M @ X[:, g_lo:g_hi]`` for ALL query rows; ``full_rows`` is
+    :func:`gather_mapping_rows`' result (or its CSR form), ``payload_slab`` the rank's columns ``[n_ref, g_hi - g_lo]``."""
+    csr = full_rows if len(full_rows) == 3 and full_rows[0].dim() == 1 else ops.to_csr(*full_rows)
+    return ops.spmm_dense(csr, payload_slab, out=out)
+
+
+def sharded_map_layer_csr(ops, full_rows, payload_slab_csr, n_out_slab):
+    """A3 with gene-column sharding (``cellmapper.py:372-373``, scipy ``csr_matmat``): ``M @ X[:, g_lo:g_hi]`` for a CSR payload
+    slab ``(indptr, cols - g_lo, vals)`` with ``n_out_slab`` columns -> the slab of the product as CSR (columns relative to the
+    slab).  Exact zeros are dropped per output entry, so the slab equals the same columns of the one-GPU product."""
+    csr = full_rows if len(full_rows) == 3 and full_rows[0].dim() == 1 else ops.to_csr(*full_rows)
+    return ops.spmm_csr(csr, payload_slab_csr, n_out_slab)

@@ -81,6 +81,20 @@ int cm_device_count(void);
 /* Create / destroy a backend context bound to one GPU (replaces faiss.StandardGpuResources /
  * index_cpu_to_gpu(res, 0, ...) bookkeeping of knn.py:410-413). */
 cm_status cm_create(int device, cm_handle_t *out);
+/* The same over SEVERAL GPUs of one node (SURVEY.md 8b `cm_create(devices[], n)`; the reference is pinned to one device,
+ * knn.py:412,420): one stream + workspace per listed device, owned by the handle.  The graph tier (cm_rep_create,
+ * cm_graph_knn, cm_graph_mapping, cm_graph_label_vote, cm_graph_spmm_dense, cm_graph_spmm_csr*) and cm_knn then use all of
+ * them from ONE call of ONE caller thread: the representations are uploaded to every device, the REFERENCE ROWS are
+ * partitioned (device p searches all queries against rows [lo_p, hi_p) with global indices), the per-shard lists are
+ * exchanged by query slice with peer copies (hipMemcpyPeerAsync: xGMI between GPUs) and merged by (distance, index) with the
+ * kernel of cm_knn_merge_strided_dev -- exact, bit-identical to one device -- after which device p owns query slice p of the
+ * graph, of the mapping matrix (global bandwidth from per-device moments summed on the host) and of every transfer
+ * (payloads replicated, outputs written to the caller's arrays by row range).  The library runs one host thread per device
+ * inside the call.  Everything else (host tier, device tier) runs on devices[0].  n = 1 is cm_create(devices[0]).  A device
+ * may be listed more than once (tests of the choreography on a one-GPU box).  Small problems (fewer than 4 096 reference
+ * rows per device or fewer than 1 024 queries) and cosine on float32 input (whose float32 distances are a property of the
+ * one-device arithmetic) run on devices[0] alone. */
+cm_status cm_create_multi(const int *devices, int n, cm_handle_t *out);
 cm_status cm_destroy(cm_handle_t h);
 const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
 cm_status cm_set_stream(cm_handle_t h, void *hip_stream); /* NULL = the handle's own stream */

@@ -45,6 +45,17 @@ int cmo_num_threads(void) {
 #endif
 }
 
+/* Thread count of every later parallel region.  OMP_NUM_THREADS is read when libgomp is loaded -- in a process that has
+ * already imported torch (which loads libgomp) the environment variable comes too late, and omp_get_max_threads() stays at
+ * the host's core count while the process may run on a 16-core share: bench.py calls this with the cores it may use. */
+void cmo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 static inline double ld(const void *p, int is_f64, int64_t i) {
     return is_f64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
 }

@@ -40,9 +40,7 @@ def test_parent_spawns_child_and_returns_its_code(monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     ran = []
     monkeypatch.setattr(bench, "main_rank", lambda a: ran.append(a))
-    import torch
-
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 8)
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2", "--steps", "1", "--master-port", "29444"])
     assert e.value.code == 7, "the parent exits with the child's status"
@@ -52,9 +50,7 @@ def test_parent_spawns_child_and_returns_its_code(monkeypatch):
 
 
 def test_too_few_gpus_is_an_error(monkeypatch):
-    import torch
-
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: 1)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("must not launch"))
     with pytest.raises(SystemExit) as e:
@@ -69,3 +65,19 @@ def test_config_defaults():
     assert (a.nq, a.nref, a.d, a.k, a.genes) == (1000, 4_000_000, 2, 90, 30_000)
     a = bench.parse([])
     assert (a.config, a.nq, a.nref, a.d, a.k) == (2, 1_500_000, 1_500_000, 50, 30)
+
+
+def test_gpu_count_never_loads_hip(monkeypatch, tmp_path):
+    """The launching parent counts GPUs from the environment / the KFD topology files: it must not import torch or call HIP
+    (a parent that has initialised the GPU and then spawns ranks is what the pool forbids)."""
+    import subprocess
+
+    code = ("import sys, bench; bench.visible_gpu_count(); "
+            "assert 'torch' not in sys.modules, 'visible_gpu_count imported torch'; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3,5")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count() == 1

@@ -1,0 +1,108 @@
+"""Multi-device handle of the C ABI (cm_create_multi) on a ONE-GPU box: the same device listed two or three
+times runs the whole choreography -- representations uploaded per device, reference rows sharded with global indices, packed
+per-shard lists, peer copies by query slice, strided exact merge, per-part mapping-matrix rows under the GLOBAL bandwidth,
+transfers by query slice into the caller's arrays -- and must reproduce the single-device results: indices and float64
+distances bit for bit (the merge rule is the search's own order), everything downstream to rounding of the bandwidth's sum."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def problem():
+    rng = np.random.default_rng(11)
+    n_ref, nq, d = 20000, 3001, 24
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    ref[17] = ref[15000]                       # an exact tie across the shard boundary: the lower global index must win
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    qry[5] = ref[17]
+    return ref, qry
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+@pytest.mark.parametrize("kernel", ["gaussian", "scarches"])
+def test_multi_device_graph_equals_single_device(problem, ndev, kernel, oracle):
+    import scipy.sparse as sp
+    from cellmapper_amd import _native
+
+    ref, qry = problem
+    k, n_cat, G = 15, 9, 37
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, n_cat, ref.shape[0]).astype(np.int32)
+    X = rng.random((ref.shape[0], G), dtype=np.float32)
+    Xs = sp.csr_matrix((X * (rng.random(X.shape) < 0.15)).astype(np.float32))
+    Xs.sort_indices()
+    outs = []
+    for devs in (None, [0] * ndev):
+        h = _native.Handle(0) if devs is None else _native.Handle(devices=devs)
+        xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
+        g = _native.DeviceGraph(h, xr, yr, k)
+        assert g.n_devices == (1 if devs is None else ndev)
+        xr.close(); yr.close()
+        dist, idx = g.fetch_knn()
+        nnz, param = g.mapping(kernel)
+        ip, cc, vv = g.fetch_mapping()
+        code, conf = g.label_vote(codes, n_cat)
+        dense = g.spmm_dense(X)
+        cp, ccols, cvals = g.spmm_csr(Xs.indptr, Xs.indices, Xs.data, G)
+        outs.append(dict(dist=dist, idx=idx, nnz=nnz, param=param, ip=ip, cc=cc, vv=vv, code=code, conf=conf, dense=dense,
+                         csr=sp.csr_matrix((cvals, ccols, cp), shape=(qry.shape[0], G)).toarray()))
+        g.close()
+        h.close()
+    one, many = outs
+    assert np.array_equal(many["idx"], one["idx"]) and np.array_equal(many["dist"], one["dist"])
+    assert many["idx"][5, 0] == 17 and many["idx"][5, 1] == 15000
+    o = oracle.run_path(ref, qry, k, kernel=kernel, labels=codes, n_cat=n_cat)
+    assert np.array_equal(many["idx"], o["idx"]) and np.array_equal(many["dist"], o["dist"])
+    assert many["nnz"] == one["nnz"] and np.array_equal(many["ip"], one["ip"]) and np.array_equal(many["cc"], one["cc"])
+    np.testing.assert_allclose(many["param"], one["param"], rtol=1e-13)
+    np.testing.assert_allclose(many["vv"], one["vv"], rtol=2e-7)
+    np.testing.assert_allclose(many["vv"], o["vals"], rtol=1e-6)
+    assert (many["code"] == one["code"]).mean() > 0.9995
+    np.testing.assert_allclose(many["conf"], one["conf"], rtol=1e-6)
+    np.testing.assert_allclose(many["dense"], one["dense"], rtol=1e-6)
+    np.testing.assert_allclose(many["csr"], one["csr"], rtol=1e-6)
+
+
+def test_multi_device_host_knn_and_small_problem_fall_back(problem):
+    from cellmapper_amd import _native
+
+    ref, qry = problem
+    h2, h1 = _native.Handle(devices=[0, 0]), _native.Handle(0)
+    d2, i2 = h2.knn(ref, qry, 10)                       # host tier on a multi handle: sharded inside the library
+    d1, i1 = h1.knn(ref, qry, 10)
+    assert np.array_equal(i2, i1) and np.array_equal(d2, d1)
+    # fewer than 4096 reference rows per device, or float32 cosine: one part on devices[0]
+    xr, yr = _native.DeviceRep(h2, ref[:5000]), _native.DeviceRep(h2, qry)
+    g = _native.DeviceGraph(h2, xr, yr, 5)
+    assert g.n_devices == 1
+    g.close()
+    g = _native.DeviceGraph(h2, _native.DeviceRep(h2, ref), yr, 5, metric="cosine")
+    assert g.n_devices == 1
+    g.close()
+    h2.close(); h1.close()
+
+
+def test_drop_in_class_on_a_multi_device_handle(problem, monkeypatch):
+    """CELLMAP_DEVICES selects the devices of the process-wide handle the drop-in classes use."""
+    import pandas as pd
+
+    from cellmapper_amd import CellMapper, MiniAnnData, _native
+
+    ref, qry = problem
+    rng = np.random.default_rng(2)
+    labels = pd.Categorical([f"t{c}" for c in rng.integers(0, 6, ref.shape[0])])
+    res = []
+    for env in ("0", "0,0"):
+        monkeypatch.setenv("CELLMAP_DEVICES", env)
+        monkeypatch.setattr(_native, "_default", None)
+        reference = MiniAnnData(X=np.zeros((ref.shape[0], 2), np.float32), obs=pd.DataFrame({"label": labels}), obsm={"X_emb": ref})
+        query = MiniAnnData(X=np.zeros((qry.shape[0], 2), np.float32), obsm={"X_emb": qry})
+        cm = CellMapper(query, reference).map(obs_keys="label", use_rep="X_emb", n_neighbors=12, only_yx=True)
+        assert cm.knn.yx._graph_dev.n_devices == (1 if env == "0" else 2)
+        res.append((cm.knn.yx.indices.copy(), query.obs["label_pred"].astype(str).to_numpy(), query.obs["label_conf"].to_numpy()))
+    monkeypatch.setattr(_native, "_default", None)
+    assert np.array_equal(res[0][0], res[1][0])
+    assert (res[0][1] == res[1][1]).mean() > 0.9995
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6)

@@ -58,17 +58,61 @@ class OracleOps:
             return self.t.tensor([m[0] / m[2]], dtype=self.t.float64)
         return self.t.tensor([(2.0 / np.sqrt(m[1] / m[2])) ** 2], dtype=self.t.float64)
 
-    def weights_vote(self, dist, idx, n_ref, kernel, param, codes, n_cat, epsilon):
+    def weights(self, dist, idx, n_ref, kernel, param, epsilon):
         d, i = dist.numpy(), idx.numpy()
         p = float(param[0]) if param is not None else 0.0
         w = {"gaussian": lambda: np.exp(-(d * d) / (2 * p * p)), "scarches": lambda: np.exp(-d / p),
              "inverse_distance": lambda: 1.0 / (d + epsilon), "equal": lambda: np.ones_like(d)}[kernel]()
         indptr, cols, v32, _ = self.o.mapping_matrix(w, d, i, n_ref)
-        code, conf = self.o.label_vote(indptr, cols, v32, codes.numpy(), n_cat)
+        n, k = d.shape
+        cnt = np.diff(indptr).astype(np.int32)
+        ec, ev = np.zeros((n, k), np.int32), np.zeros((n, k), np.float32)
+        for r in range(n):   # CSR -> ELL (valid entries first, columns ascending)
+            ec[r, :cnt[r]] = cols[indptr[r]:indptr[r + 1]]
+            ev[r, :cnt[r]] = v32[indptr[r]:indptr[r + 1]]
+        return self.t.from_numpy(ec), self.t.from_numpy(ev), self.t.from_numpy(cnt)
+
+    def to_csr(self, cols, vals, cnt):
+        c, v, n = cols.numpy(), vals.numpy(), cnt.numpy()
+        indptr = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        keep = np.arange(c.shape[1])[None, :] < n[:, None]
+        return self.t.from_numpy(indptr), self.t.from_numpy(c[keep]), self.t.from_numpy(v[keep])
+
+    def vote(self, cols, vals, cnt, codes, n_cat):
+        ip, c, v = self.to_csr(cols, vals, cnt)
+        code, conf = self.o.label_vote(ip.numpy(), c.numpy(), v.numpy(), codes.numpy(), n_cat)
         return self.t.from_numpy(code), self.t.from_numpy(conf)
+
+    def spmm_dense(self, csr, B, out=None):
+        r = self.t.from_numpy(self.o.spmm_dense(csr[0].numpy(), csr[1].numpy(), csr[2].numpy(), B.numpy()))
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def spmm_csr(self, csr, b_csr, n_out):
+        import scipy.sparse as sp
+
+        B = sp.csr_matrix((b_csr[2].numpy(), b_csr[1].numpy(), b_csr[0].numpy()), shape=(len(b_csr[0]) - 1, n_out))
+        dense = self.o.spmm_csr(csr[0].numpy(), csr[1].numpy(), csr[2].numpy(), B)
+        nz = dense != 0   # (csr_matmat drops exact zeros)
+        indptr = np.concatenate([[0], np.cumsum(nz.sum(1))]).astype(np.int64)
+        return (self.t.from_numpy(indptr), self.t.from_numpy(np.nonzero(nz)[1].astype(np.int32)), self.t.from_numpy(dense[nz]))
 
     def empty_words(self, n, like):
         return self.t.empty((n,), dtype=self.t.int64)
+
+    def empty_i32(self, n, like):
+        return self.t.empty((n,), dtype=self.t.int32)
+
+    def cat(self, parts):
+        return self.t.cat(parts)
+
+    def equal(self, a, b):
+        return bool(self.t.equal(a, b))
+
+    def flag(self, ok, like):
+        return self.t.tensor([1 if ok else 0], dtype=self.t.int32)
 
 
 def _worker(rank, world, port, exchange, kernel, out_dir, ref_shards=None, metric="euclidean"):
@@ -148,3 +192,99 @@ def test_sharded_choreography(world, ref_shards, exchange, kernel, metric, tmp_p
         assert idx[0, 0] == 10 and idx[0, 1] == 2500  # lower global index wins the cross-shard tie
     np.testing.assert_array_equal(np.concatenate([p["code"] for p in parts]), full["pred_code"])
     np.testing.assert_allclose(np.concatenate([p["conf"] for p in parts]), full["conf"], rtol=1e-6)
+
+
+# ---- aggregation half of SURVEY.md 8e: replicated small payloads, gene-column-sharded layers -------------------------
+def _problem():
+    rng = np.random.default_rng(5)
+    n_ref, nq, d, k, G = 1501, 157, 16, 9, 40
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    obsm = rng.standard_normal((n_ref, 2)).astype(np.float32)
+    X = rng.random((n_ref, G), dtype=np.float32)
+    Xs = X * (rng.random((n_ref, G)) < 0.2)     # sparse layer, 20 % density
+    return ref, qry, obsm, X, Xs.astype(np.float32), k, G
+
+
+def _worker_layers(rank, world, port, out_dir, ref_shards, break_alltoall):
+    sys.path.insert(0, ROOT)
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+
+    from cellmapper_amd import sharded as sh
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref, qry, obsm, X, Xs, k, G = _problem()
+    lay = sh.Layout(world, rank, qry.shape[0], ref_shards)
+    pg = sh.make_groups(dist, world, lay.n_groups, lay.ref_shards, "alltoall")
+    lo, hi = sh.shard_bounds(ref.shape[0], lay.ref_shards, lay.ref_rank)
+    state = sh.ExchangeState("alltoall")
+    dist_mod = dist
+    if break_alltoall:   # an all-to-all that raises (what an unsupported split-size call would do): the run must fall back
+        class Broken:
+            def __getattr__(self, name):
+                return getattr(dist, name)
+
+            def all_to_all_single(self, *a, **kw):
+                raise RuntimeError("all_to_all_single with split sizes is not supported here")
+        dist_mod = Broken()
+    ops = OracleOps()
+    outs = []
+    for _ in range(2):   # step 1 self-checks the exchange, step 2 runs what step 1 decided
+        rows = sh.sharded_mapping_rows(ops, dist_mod, torch.from_numpy(ref[lo:hi].copy()), lo, ref.shape[0],
+                                       torch.from_numpy(qry[lay.group_lo:lay.group_hi].copy()), k, exchange="alltoall", group=pg,
+                                       ref_world=lay.ref_shards, ref_rank=lay.ref_rank, state=state)
+        outs.append(rows)
+    assert torch.equal(outs[0]["idx"], outs[1]["idx"]) and torch.equal(outs[0]["vals"], outs[1]["vals"])
+    rows = outs[1]
+    my_lo, my_hi = lay.my_slice
+    assert (lay.group_lo + rows["bounds"][0], lay.group_lo + rows["bounds"][1]) == (my_lo, my_hi)
+    o_obsm = sh.sharded_map_obsm(ops, rows, torch.from_numpy(obsm))                       # query-sliced
+    full = sh.gather_mapping_rows(ops, dist, rows, lay)                                   # ONE all-gather
+    g_lo, g_hi = sh.shard_bounds(G, world, rank)                                          # this rank's gene columns
+    o_dense = sh.sharded_map_layer_dense(ops, full, torch.from_numpy(np.ascontiguousarray(X[:, g_lo:g_hi])))
+    slab = sp.csr_matrix(Xs[:, g_lo:g_hi])
+    slab.sort_indices()
+    o_csr = sh.sharded_map_layer_csr(ops, full, (torch.from_numpy(slab.indptr.astype(np.int64)),
+                                                 torch.from_numpy(slab.indices.astype(np.int32)),
+                                                 torch.from_numpy(slab.data.astype(np.float32))), g_hi - g_lo)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), q_lo=my_lo, q_hi=my_hi, g_lo=g_lo, g_hi=g_hi, obsm=o_obsm.numpy(),
+             dense=o_dense.numpy(), c_ptr=o_csr[0].numpy(), c_cols=o_csr[1].numpy(), c_vals=o_csr[2].numpy(),
+             mode=state.mode, note=str(state.note), full_cols=full[0].numpy(), full_vals=full[1].numpy(), full_cnt=full[2].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ref_shards,break_alltoall", [
+    (2, None, False),    # 1 query group x 2 reference shards
+    (4, 2, False),       # 2 x 2: ragged query groups (157 rows), world-wide all-gather of the mapping-matrix rows
+    (3, 3, False),       # odd world, ragged slices and gene slabs
+    (4, 2, True),        # the all-to-all raises on the first step -> world all-gather fall-back, same results
+])
+def test_sharded_obsm_and_layers(world, ref_shards, break_alltoall, tmp_path, oracle):
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 1500) + world * 11 + (5 if break_alltoall else 0)
+    mp.spawn(_worker_layers, args=(world, port, str(tmp_path), ref_shards, break_alltoall), nprocs=world, join=True)
+    ref, qry, obsm, X, Xs, k, G = _problem()
+    full = oracle.run_path(ref, qry, k, obsm=obsm, layer=X)
+    want_csr = oracle.spmm_csr(full["indptr"], full["cols"], full["vals"], sp.csr_matrix(Xs))
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert all(str(p["mode"]) == ("allgather_world" if break_alltoall else "alltoall") for p in parts)
+    if break_alltoall:
+        assert "not supported" in str(parts[0]["note"])
+    # query-sliced outputs tile the query rows; column-sliced outputs tile the genes
+    assert int(parts[0]["q_lo"]) == 0 and int(parts[-1]["q_hi"]) == qry.shape[0]
+    np.testing.assert_array_equal(np.concatenate([p["obsm"] for p in parts]), full["obsm_pred"])
+    np.testing.assert_array_equal(np.concatenate([p["dense"] for p in parts], axis=1), full["layer_pred"])
+    for p in parts:   # every rank holds the SAME replicated mapping matrix = the unsharded one
+        cnt = p["full_cnt"]
+        keep = np.arange(k)[None, :] < cnt[:, None]
+        np.testing.assert_array_equal(p["full_cols"][keep], full["cols"])
+        np.testing.assert_array_equal(p["full_vals"][keep], full["vals"])
+        got = sp.csr_matrix((p["c_vals"], p["c_cols"], p["c_ptr"]), shape=(qry.shape[0], int(p["g_hi"]) - int(p["g_lo"]))).toarray()
+        np.testing.assert_array_equal(got, want_csr[:, int(p["g_lo"]):int(p["g_hi"])])
