@@ -34,7 +34,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = [
-    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_last_error", "cm_set_stream", "cm_synchronize",
+    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_pool_trim", "cm_reload_knobs", "cm_last_error", "cm_set_stream", "cm_synchronize",
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
@@ -64,6 +64,8 @@ def load_library():
         lib.cm_create.argtypes = [C.c_int, C.POINTER(vp)]
         lib.cm_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         lib.cm_destroy.argtypes = [vp]
+        lib.cm_pool_trim.argtypes = [vp]
+        lib.cm_reload_knobs.argtypes = []
         lib.cm_last_error.argtypes = [vp]
         lib.cm_last_error.restype = C.c_char_p
         lib.cm_set_stream.argtypes = [vp, vp]
@@ -125,6 +127,11 @@ def load_library():
         return lib
 
 
+def reload_knobs():
+    """Re-read the ``CELLMAP_*`` diagnostics / test variables (the library reads them in ``cm_create`` only)."""
+    load_library().cm_reload_knobs()
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -177,6 +184,10 @@ class Handle:
 
     def call(self, name: str, *args):
         self.check(getattr(self.lib, name)(self._h, *args))
+
+    def trim(self):
+        """Return the handle's cached device blocks to the HIP allocator (``cm_pool_trim``)."""
+        self.call("cm_pool_trim")
 
     def set_stream(self, stream_ptr):
         self.call("cm_set_stream", C.c_void_p(int(stream_ptr) if stream_ptr else 0))

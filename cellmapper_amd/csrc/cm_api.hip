@@ -11,12 +11,35 @@
 #include <thread>
 
 namespace {
+cm_knobs g_knobs;
+void latch_knobs() {
+    cm_knobs k;
+    auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return (e && *e) ? atoll(e) : dflt; };
+    auto on = [](const char *n) { return getenv(n) != nullptr; };
+    k.dbg = (int)num("CELLMAP_DBG", 0);
+    k.filter_products = (int)num("CELLMAP_FILTER_PRODUCTS", 0);
+    k.q4 = (int)num("CELLMAP_Q4", 1);
+    k.slack = (int)num("CELLMAP_SLACK", -1);
+    if (const char *e = getenv("CELLMAP_PHASE1")) k.phase1 = !strcmp(e, "f32") ? 1 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "direct") ? 3 : 0));
+    k.spgemm_ct = (int)num("CELLMAP_SPGEMM_CT", 0);
+    k.spgemm_dbg = (int)num("CELLMAP_SPGEMM_DBG", 0);
+    k.spmm_budget_mb = num("CELLMAP_SPMM_BUDGET_MB", -1);
+    k.spgemm_budget_mb = num("CELLMAP_SPGEMM_BUDGET_MB", -1);
+    k.pool_mb = num("CELLMAP_POOL_MB", -1);
+    k.dbg_ws = on("CELLMAP_DBG_WS"); k.weights_lds = on("CELLMAP_WEIGHTS_LDS");
+    if (const char *e = getenv("CELLMAP_LOWD")) k.lowd_brute = !strcmp(e, "brute");
+    k.no_sort = on("CELLMAP_NO_SORT"); k.no_chain = on("CELLMAP_NO_CHAIN"); k.no_centre = on("CELLMAP_NO_CENTRE");
+    k.no_ivf = on("CELLMAP_NO_IVF"); k.no_hint = on("CELLMAP_NO_HINT"); k.no_perm = on("CELLMAP_NO_PERM");
+    k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
+    g_knobs = k;
+}
 std::mutex g_err_mu;
 std::string g_create_err;
 void a3_session_drop(cm_handle_t h);
 
 // Device allocation pool of the host tier.  A released block is kept on the handle and handed to the next request it
-// fits (no more than twice the requested size); the pool is capped at a quarter of the device memory.
+// fits (no more than twice the requested size); the pool is capped per handle (pool_cap, set by cm_create from the handle's
+// own device) and can be returned to the allocator at any time with cm_pool_trim.
 void *pool_take(cm_handle_t h, size_t bytes, size_t *got) {
     int best = -1;
     for (int i = 0; i < (int)h->pool.size(); ++i)
@@ -29,11 +52,7 @@ void *pool_take(cm_handle_t h, size_t bytes, size_t *got) {
     return p;
 }
 void pool_release(cm_handle_t h, void *p, size_t bytes) {
-    static size_t cap = 0;
-    if (!cap) {
-        size_t free_b = 0, total_b = 0;
-        cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? total_b / 4 : ((size_t)16 << 30);
-    }
+    const size_t cap = h ? h->pool_cap : 0;
     if (!h || bytes > cap / 2) { (void)hipFree(p); return; }
     h->pool.emplace_back(bytes, p);
     h->pool_bytes += bytes;
@@ -113,6 +132,8 @@ cm_status check_fallback_overflow(cm_handle_t h) {
 struct A3Session {
     const void *key[6] = {};
     int64_t nq = 0, n_ref = 0, n_out = 0;
+    int64_t token = 0;   // fingerprint of the output row pointer the count call produced (pointer identity alone is not
+                         // enough: numpy / the pool hand out recycled addresses)
     DevBuf dp, dc, dv, bp, bc, bv, op;
     // the mapping matrix on the device: the session's own upload (dp / dc / dv) or a cm_graph's arrays
     const int64_t *mp = nullptr;
@@ -129,11 +150,11 @@ cm_status tile_streams(cm_handle_t h) {
         if (!h->tile_ev[i]) CM_HIP(h, hipEventCreateWithFlags(&h->tile_ev[i], hipEventDisableTiming));
     return CM_OK;
 }
-size_t device_budget(cm_handle_t h, const char *env_mb) {
+size_t device_budget(cm_handle_t h, long long knob_mb) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
     size_t budget = free_b / 2;
-    if (const char *e = getenv(env_mb)) budget = (size_t)atoll(e) << 20;   // testing: force tiling
+    if (knob_mb >= 0) budget = (size_t)knob_mb << 20;   // testing: force tiling
     (void)h;
     return budget;
 }
@@ -156,6 +177,8 @@ cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d
 }
 }  // namespace
 
+const cm_knobs &cm_get_knobs() { return g_knobs; }
+
 void cm_mark(cm_handle_t h, int which) {
     if (!h->profiling || which < 0 || which >= CM_N_STAGE_EVENTS) return;
     if (!h->ev[which] && hipEventCreate(&h->ev[which]) != hipSuccess) return;
@@ -175,7 +198,7 @@ cm_status cm_ws_reserve(cm_handle_t h, size_t bytes) {
 void *cm_ws_alloc(cm_handle_t h, size_t bytes) {
     bytes = cm_align(bytes ? bytes : 1);
     if (h->ws_off + bytes > h->ws_cap) {
-        if (getenv("CELLMAP_DBG_WS")) fprintf(stderr, "[cellmap dbg] workspace: request of %zu bytes at offset %zu exceeds the capacity %zu\n", bytes, h->ws_off, h->ws_cap);
+        if (cm_get_knobs().dbg_ws) fprintf(stderr, "[cellmap dbg] workspace: request of %zu bytes at offset %zu exceeds the capacity %zu\n", bytes, h->ws_off, h->ws_cap);
         return nullptr;
     }
     void *p = h->ws + h->ws_off;
@@ -193,9 +216,15 @@ int cm_device_count(void) {
     return n;
 }
 
+cm_status cm_reload_knobs(void) {
+    latch_knobs();
+    return CM_OK;
+}
+
 cm_status cm_create(int device, cm_handle_t *out) {
     if (!out) return CM_E_INVALID;
     *out = nullptr;
+    latch_knobs();   // the CELLMAP_* knobs are read here, never on a call path
     auto fail = [&](const char *what, hipError_t e) {
         std::lock_guard<std::mutex> g(g_err_mu);
         g_create_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -213,7 +242,22 @@ cm_status cm_create(int device, cm_handle_t *out) {
     h->stream = h->own_stream;
     if ((e = hipHostMalloc((void **)&h->d_nflag_pinned, 64, hipHostMallocDefault)) != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail("hipHostMalloc", e); }
     memset(h->d_nflag_pinned, 0, 64);
+    {   // pool cap from THIS device's memory (not from whichever device happens to be current later)
+        size_t free_b = 0, total_b = 0;
+        h->pool_cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? std::min<size_t>(total_b / 8, (size_t)32 << 30) : ((size_t)8 << 30);
+        if (cm_get_knobs().pool_mb >= 0) h->pool_cap = (size_t)cm_get_knobs().pool_mb << 20;
+    }
     *out = h;
+    return CM_OK;
+}
+
+cm_status cm_pool_trim(cm_handle_t h) {
+    if (!h) return CM_E_INVALID;
+    for (auto *p : h->peers) (void)cm_pool_trim(p);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    a3_session_drop(h);
+    pool_drop(h);
     return CM_OK;
 }
 
@@ -606,7 +650,7 @@ static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const
     // Streaming ("wide aggregation outputs"): the payload is cut into column slabs that fit HBM next
     // to two output tiles, the output into query tiles; tile i is copied to the caller's buffer on a second stream while
     // tile i+1 is computed.  Nothing of size nq x n_out is ever resident.
-    const size_t budget = device_budget(h, "CELLMAP_SPMM_BUDGET_MB");
+    const size_t budget = device_budget(h, cm_get_knobs().spmm_budget_mb);
     int64_t cw = n_out;
     int64_t qt = std::max<int64_t>(1, std::min<int64_t>(nq, 1 << 16));           // query rows per output tile
     auto need = [&](int64_t w, int64_t t) { return es * ((size_t)n_ref * w + 2 * (size_t)t * w); };
@@ -650,6 +694,14 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
 }
 
 // shared by the host tier (mapping matrix in host arrays) and the graph tier (mapping matrix already on the device: d_m*)
+// fingerprint of a host row pointer: its end and 64 evenly spaced entries
+static int64_t indptr_token(const int64_t *p, int64_t nq) {
+    uint64_t t = 0x9E3779B97F4A7C15ull ^ (uint64_t)p[nq];
+    const int64_t step = std::max<int64_t>(1, nq / 64);
+    for (int64_t i = 0; i <= nq; i += step) t = (t ^ (uint64_t)p[i]) * 0x100000001B3ull;
+    return (int64_t)t;
+}
+
 static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const int32_t *cols, const float *vals,
                                    const int64_t *d_mp, const int32_t *d_mc, const float *d_mv, int64_t nq,
                                    const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
@@ -680,6 +732,7 @@ static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const i
     if (rc == CM_OK) rc = cm_exclusive_scan_i32_to_i64(h, rn.as<int32_t>(), nq, ss->op.as<int64_t>());
     if (rc == CM_OK) rc = d2h(h, out_indptr, ss->op.p, 8 * ((size_t)nq + 1));
     if (rc == CM_OK) rc = sync(h);
+    if (rc == CM_OK) ss->token = indptr_token(out_indptr, nq);
     if (rc != CM_OK) a3_session_drop(h);
     return rc;
 }
@@ -695,7 +748,8 @@ static cm_status spmm_csr_fill_impl(cm_handle_t h, const int64_t *indptr, const 
                           d_mp ? (const void *)d_mv : (const void *)vals, b_indptr, b_cols, b_vals};
     A3Session *ss = static_cast<A3Session *>(h->a3_session);
     A3Session local;
-    if (!(ss && !memcmp(ss->key, key, sizeof(key)) && ss->nq == nq && ss->n_ref == n_ref && ss->n_out == n_out)) {
+    if (!(ss && !memcmp(ss->key, key, sizeof(key)) && ss->nq == nq && ss->n_ref == n_ref && ss->n_out == n_out &&
+          ss->token == indptr_token(out_indptr, nq))) {
         // no matching count call on this handle: upload here
         a3_session_drop(h);
         ss = &local;
@@ -710,7 +764,7 @@ static cm_status spmm_csr_fill_impl(cm_handle_t h, const int64_t *indptr, const 
     }
     // Query tiles: the output (which approaches nq x n_out for dense neighbourhoods) is produced in tiles of at most `cap`
     // entries, copied to the caller's arrays on a second stream while the next tile is computed.
-    const size_t budget = device_budget(h, "CELLMAP_SPGEMM_BUDGET_MB");
+    const size_t budget = device_budget(h, cm_get_knobs().spgemm_budget_mb);
     const int64_t nnz = out_indptr[nq];
     int64_t cap = std::max<int64_t>((int64_t)(budget / 16), 1);   // two buffers of (int32 column + float32 value) per entry
     int64_t longest = 0;
@@ -1023,6 +1077,9 @@ cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double e
     if (!g) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     g->has_map = false;
+    for (auto &p : g->parts)   // a pending sparse-product session holds the OLD mapping-matrix arrays of this graph
+        if (p.h->a3_session) { (void)hipSetDevice(p.h->device); a3_session_drop(p.h); }
+    (void)hipSetDevice(h->device);
     const size_t P = g->parts.size();
     const auto hs = part_handles(g);
     auto ws_need = [&](const GraphPart &p) {

@@ -7,6 +7,23 @@
 
 #include "cellmap.h"
 
+// Diagnostics / test knobs (CELLMAP_* environment variables): read ONCE per cm_create (and by
+// cm_reload_knobs) into this process-wide record -- nothing on a call path reads the environment.
+struct cm_knobs {
+    int dbg = 0;                 // CELLMAP_DBG: in-kernel timing modes / counters of the filter kernels
+    int filter_products = 0;     // CELLMAP_FILTER_PRODUCTS: pin the filter level (no escalation)
+    int q4 = 1;                  // CELLMAP_Q4: 0 never / 1 by size / 2 wherever instantiated: the four-accumulator filter
+    int slack = -1;              // CELLMAP_SLACK: candidate slack override
+    int phase1 = 0;              // CELLMAP_PHASE1: 1 f32, 2 f16, 3 direct
+    int spgemm_ct = 0;           // CELLMAP_SPGEMM_CT: columns per accumulator pass of the sparse product (tests)
+    int spgemm_dbg = 0;          // CELLMAP_SPGEMM_DBG: timing experiments
+    long long spmm_budget_mb = -1, spgemm_budget_mb = -1;   // CELLMAP_SPMM_BUDGET_MB / CELLMAP_SPGEMM_BUDGET_MB: device budget of the streaming host tiers
+    long long pool_mb = -1;      // CELLMAP_POOL_MB: cap of the per-handle device allocation pool
+    bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,
+         no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false;
+};
+const cm_knobs &cm_get_knobs();
+
 #define CM_N_STAGE_EVENTS 8
 struct cm_handle_s {
     int device = 0;
@@ -35,6 +52,7 @@ struct cm_handle_s {
     // through hipMalloc / hipFree every time (freed by cm_destroy; bounded, see pool_release in cm_api.hip)
     std::vector<std::pair<size_t, void *>> pool;
     size_t pool_bytes = 0;
+    size_t pool_cap = 0;   // bytes the pool may keep: min(an eighth of THIS device's memory, 32 GB), or CELLMAP_POOL_MB (cm_create)
     hipStream_t copy_stream = nullptr;   // D2H of finished output tiles while the next tile is computed (host tier)
     hipEvent_t tile_ev[2] = {nullptr, nullptr};
     // multi-device handle (cm_create_multi): the OTHER GPUs' contexts, owned by this handle.  The handle itself is the

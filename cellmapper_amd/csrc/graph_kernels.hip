@@ -851,7 +851,7 @@ cm_status cm_weights_run(cm_handle_t h, const double *d_dist, const int64_t *d_i
     if (nq == 0) return CM_OK;
     // (n_ref <= 0: unknown column range.  STRICTLY below 2^25: the sorted kernel's key is (column << 7) | position with 0xffffffff as
     // the invalid sentinel, which column 2^25 - 1 at position 127 would collide with)
-    const bool reg_ok = n_ref > 0 && n_ref < (1LL << 25) && !getenv("CELLMAP_WEIGHTS_LDS");
+    const bool reg_ok = n_ref > 0 && n_ref < (1LL << 25) && !cm_get_knobs().weights_lds;
     if (reg_ok && k <= 128) {   // register-resident sort: one row per 32 lanes, per wave, or per wave with two entries per lane
         if (k <= 32)
             hipLaunchKernelGGL((weights_rows_sorted<32, 1>), dim3((unsigned)((nq + 7) / 8)), dim3(256), 0, h->stream, d_dist, d_idx, nq, k,
@@ -980,9 +980,9 @@ static cm_status spgemm_launch(cm_handle_t h, int mode, const int64_t *d_indptr,
     if (n_out > 0x7fffffffLL) CM_FAIL(h, CM_E_UNSUPPORTED, "spmm_csr: more than 2^31 output columns");
     if (nq == 0) return CM_OK;
     int ct = SPG_CT;
-    if (const char *e = getenv("CELLMAP_SPGEMM_CT")) { int v = atoi(e); if (v >= 4 && v <= SPG_CT) ct = v & ~3; }   // testing: force column passes
+    { const int v = cm_get_knobs().spgemm_ct; if (v >= 4 && v <= SPG_CT) ct = v & ~3; }   // testing: force column passes
     if (n_out < ct) ct = (int)((n_out + 3) & ~3LL);
-    const int dbg = getenv("CELLMAP_SPGEMM_DBG") ? atoi(getenv("CELLMAP_SPGEMM_DBG")) : 0;   // timing experiments only (wrong results)
+    const int dbg = cm_get_knobs().spgemm_dbg;   // timing experiments only (wrong results)
     size_t lds = (size_t)ct * 4 + (size_t)SPG_MK * 16 + 128 + 512;
     if (h->n_cu <= 0) {
         hipDeviceProp_t pr;
@@ -1034,7 +1034,7 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
 // Single pass (n_out <= SPG_CT): counts, output offsets (chained scan, or completion order with d_out_rows) and entries from
 // ONE gather.  d_chain: nq + 2 words of scratch.  d_out_indptr[0..nq] is written in full; entries of rows that end beyond
 // `capacity` are not.
-bool cm_spmm_csr_single_pass_ok(int64_t n_out) { return n_out >= 1 && n_out <= SPG_CT && !getenv("CELLMAP_SPGEMM_CT"); }
+bool cm_spmm_csr_single_pass_ok(int64_t n_out) { return n_out >= 1 && n_out <= SPG_CT && cm_get_knobs().spgemm_ct == 0; }
 cm_status cm_spmm_csr_fused_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals,
                                 int64_t nq, const int64_t *d_bptr, const int32_t *d_bcols, const float *d_bvals,
                                 int64_t n_out, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals, int64_t capacity,

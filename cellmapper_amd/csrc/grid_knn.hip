@@ -304,7 +304,7 @@ cm_status cm_grid_query(cm_handle_t h, const T *d_qry, int64_t nq, int d, const 
     if (nq > 0)
         hipLaunchKernelGGL(grid_query<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, d_qry, nq, d, rowmap,
                            (const GridInfo *)gi, cell_start, sxyz, sidx, k, Kc, gmax, sizeof(T) == 8 ? 1 : 0, cand, cthr,
-                           getenv("CELLMAP_DBG") ? const_cast<unsigned *>(gmax) + 12 : (unsigned *)nullptr);
+                           cm_get_knobs().dbg ? const_cast<unsigned *>(gmax) + 12 : (unsigned *)nullptr);
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }

@@ -857,7 +857,7 @@ int knn_slack(int k) { return k / 4 > 8 ? k / 4 : 8; }
 int lowd_dpad(int d) { return d <= 15 ? d : (d + 3) / 4 * 4; }
 // candidate slack of the split-fp16 kernels by number of products evaluated (coarser filter -> wider safety margin)
 int knn_slack_level(int k, int nprod) {
-    if (const char *e = getenv("CELLMAP_SLACK")) { const int v = atoi(e); if (v >= 0 && v <= 256) return v; }  // tuning only
+    { const int v = cm_get_knobs().slack; if (v >= 0 && v <= 256) return v; }  // tuning only
     if (nprod >= 3) return knn_slack(k);
     if (nprod == 2) return k / 3 > 12 ? k / 3 : 12;
     return k / 2 > 16 ? k / 2 : 16;
@@ -866,11 +866,11 @@ int knn_slack_level(int k, int nprod) {
 // phase-1 kernel choice: 2 = low-d VALU direct form (d <= 15), 1 = split-fp16 MFMA K <= 64 (d <= 61),
 // 3 = split-fp16 MFMA K = 128 (d <= 125), 0 = f32-input MFMA
 int phase1_path(int d, int k) {
-    const char *e = getenv("CELLMAP_PHASE1");
-    if (e && !strcmp(e, "f32")) return 0;
-    if (e && !strcmp(e, "direct") && d <= 64) return 2;   // diagnostics: the VALU direct-difference kernel for any d <= 64
+    const int e = cm_get_knobs().phase1;   // CELLMAP_PHASE1: 1 f32, 2 f16, 3 direct
+    if (e == 1) return 0;
+    if (e == 3 && d <= 64) return 2;   // diagnostics: the VALU direct-difference kernel for any d <= 64
     if (k + knn_slack_level(k, 1) + 2 * cmk2::CL > 512) return 0;  // the in-register merge handles 512 entries per query
-    if (d <= 15 && !(e && !strcmp(e, "f16"))) return 2;
+    if (d <= 15 && e != 2) return 2;
     if (d + cmk2::NORM_SLOTS <= 64) return 1;             // needs three spare feature slots for the norm digits
     return d <= 128 ? 3 : 0;  // the K = 128 kernel carries |y|^2 in a side block, all 128 slots hold features
 }
@@ -1479,9 +1479,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const bool have_direct = dl <= 128;   // (rows of up to 64 floats: two queries per lane; up to 128: one)
     // level 0: uniform-grid search (grid_knn.hip) for spatial coordinates; worth its set-up from a few thousand rows on
     const bool have_grid = lowp && d <= 3 && metric == CM_METRIC_EUCLIDEAN && n_ref >= 4096 &&
-                           !(getenv("CELLMAP_LOWD") && !strcmp(getenv("CELLMAP_LOWD"), "brute"));
-    const int dbg = getenv("CELLMAP_DBG") ? atoi(getenv("CELLMAP_DBG")) : 0;
-    int forced = getenv("CELLMAP_FILTER_PRODUCTS") ? atoi(getenv("CELLMAP_FILTER_PRODUCTS")) : 0;
+                           !cm_get_knobs().lowd_brute;
+    const int dbg = cm_get_knobs().dbg;
+    int forced = cm_get_knobs().filter_products;
     if (forced < 1 || forced > 5 || (forced == 4 && !have_direct) || lowp) forced = 0;   // (5 = bucket-centred hi*hi level)
     if (wide && forced == 2) forced = 3;   // the K = 128 family has no two-product kernel
 
@@ -1544,7 +1544,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // in which full-set stages pack them into waves
     int *rperm = nullptr, *qperm = nullptr, *q_bstart = nullptr, *q_bcount = nullptr, *r_bstart = nullptr;
     int *q_lab = nullptr, *flag_s = nullptr, *fl_tmp = nullptr, *fl_cnt = nullptr;   // bucket of every query; sorted flag list
-    if (!lowp && n_ref >= 65536 && nq >= 4096 && !getenv("CELLMAP_NO_SORT")) {
+    if (!lowp && n_ref >= 65536 && nq >= 4096 && !cm_get_knobs().no_sort) {
         const int C = LS_CMAX;
         int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
         int *cnt_c = (int *)cm_ws_alloc(h, sizeof(int) * 2 * LS_CMAX);
@@ -1563,7 +1563,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         int *b_order = (int *)cm_ws_alloc(h, sizeof(int) * LS_CMAX);
         if (!b_order) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         hipLaunchKernelGGL(ls_chain<T>, dim3(1), dim3(64), 0, st, d_ref, n_ref / C, d, C, b_order);
-        if (getenv("CELLMAP_NO_CHAIN")) hipLaunchKernelGGL(strided_rows, dim3(1), dim3(256), 0, st, b_order, C, (int64_t)1);   // (experiments)
+        if (cm_get_knobs().no_chain) hipLaunchKernelGGL(strided_rows, dim3(1), dim3(256), 0, st, b_order, C, (int64_t)1);   // (experiments)
         for (int side = 0; side < 2; ++side) {
             const T *X = side ? d_qry : d_ref;
             const int64_t nn = side ? nq : n_ref;
@@ -1583,7 +1583,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     }
     // bucket-centred hi*hi level (level 5): state built on first use
     // (worth it from ~131k queries on: every bucket is padded to whole 512-query blocks; smaller sets only when forced)
-    const bool have_cen = rperm && !wide && !lowp && !getenv("CELLMAP_NO_CENTRE") && (nq >= 131072 || forced == 5);
+    const bool have_cen = rperm && !wide && !lowp && !cm_get_knobs().no_centre && (nq >= 131072 || forced == 5);
     int *qpack = nullptr, *blk_bucket = nullptr;
     double *cen = nullptr;
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
@@ -1593,8 +1593,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
     if (!hint_same || h->staged_ivf_nref != n_ref || h->staged_ivf_nq != nq) h->staged_ivf_skip = 0;
-    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !getenv("CELLMAP_NO_IVF");
-    if (ivf_try && h->staged_ivf_skip > 0 && !getenv("CELLMAP_NO_HINT")) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
+    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !cm_get_knobs().no_ivf;
+    if (ivf_try && h->staged_ivf_skip > 0 && !cm_get_knobs().no_hint) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
     int *ivf_rcnt = nullptr, *ivf_bcnt = nullptr, *ivf_jstar = nullptr, *ivf_ctr = nullptr, *ivf_cand = nullptr;
@@ -1672,7 +1672,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // kernels of the same stage (seed scan) see an even number of blocks.
         // CELLMAP_Q4: 0 = never, 2 = whenever the kernel exists for the stage (tests), default = large sets only (a block is
         // 1 024 queries: below two blocks per CU the 512-query kernel fills the chip better).
-        const int q4_env = getenv("CELLMAP_Q4") ? atoi(getenv("CELLMAP_Q4")) : 1;
+        const int q4_env = cm_get_knobs().q4;
         bool q4 = level == 1 && !cenl && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
                   (q4_env == 2 || nsub >= 32768);
         if (q4) {
@@ -1740,7 +1740,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.dbg = dbg; a.ctr = d_ctr;
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
-        if (level != 4 && !w3 && p2.n_tiles > 8 && !getenv("CELLMAP_NO_PERM")) {   // knn_cand_f16: scattered tile order
+        if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
             unsigned long long pm = (unsigned long long)((double)p2.n_tiles * 0.6180339887498949) | 1ull;
             auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
             while (gcd(pm, (unsigned long long)p2.n_tiles) != 1ull) pm += 2;
@@ -1845,7 +1845,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             const bool seed_a = !marks && !pilot && rerank && qmap && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !w3 && !cenl &&
                                 seeds_from_level >= 1 && (level == 4 ? (sizeof(T) == 4 && seeds_from_level != 4)
                                                                      : (seeds_from_level <= 3 && seeds_from_level <= level)) &&
-                                !getenv("CELLMAP_NO_SUBSEED") && !getenv("CELLMAP_NO_SEED");
+                                !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
             if (seed_a) {
                 hipLaunchKernelGGL(seed_scatter_slot0, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, st, (const float *)seedb,
                                    (const double *)bound, qmap, nsub, ivf_S, level == 4 ? 1 : 0, metric == CM_METRIC_COSINE ? 1 : 0,
@@ -1910,7 +1910,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // was too tight simply ends with fewer than k candidates below it and moves on to the next level.
             const bool seed = marks && !pilot && rerank && !cenl && level != 4 && !w3 && p2.n_tiles >= 1024 &&
                               !forced && !(flags & CM_KNN_FORCE_FALLBACK) &&   // (pinned levels do not escalate: a seed failure would have nowhere to go)
-                              !getenv("CELLMAP_NO_SEED");
+                              !cm_get_knobs().no_seed;
             if (seed) {
                 // Seed = a value with at least m = 8 rows of a 1/R row sample at or below it (knn_cand_f16 in seeding mode:
                 // two lanes per query, each keeping its 4 smallest sub-tile minima in registers -- no lists, no merges).
@@ -1959,7 +1959,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             //  error on tight clusters is far below the plain levels')
             const bool sub_seed = !seed && !marks && !pilot && rerank && qmap && !cenl && level != 4 && !w3 && !forced &&
                                   seeds_from_level >= 1 && seeds_from_level <= 3 && seeds_from_level <= level &&
-                                  !(flags & CM_KNN_FORCE_FALLBACK) && !getenv("CELLMAP_NO_SUBSEED") && !getenv("CELLMAP_NO_SEED");
+                                  !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
             if (sub_seed) {
                 hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
                                    (int64_t)p2.nq_pad, seed_sub);
@@ -2023,7 +2023,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // ---- choose the level the whole set starts at
     int start = lowp ? (have_grid ? 0 : 4) : 1;
     const bool hint_ok = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
-                         !getenv("CELLMAP_NO_HINT");
+                         !cm_get_knobs().no_hint;
     const bool hinted = hint_ok && (h->staged_hint_level == 1 || (h->staged_hint_level == 5 && have_cen));
     const bool cen_bad = hint_ok && h->staged_hint_level == -5;   // the centred level failed for most queries last time
     if (lowp) {}   // grid or direct kernel: nothing to choose
@@ -2068,7 +2068,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // for most of them as well (40 clusters, sigma 0.1: 69 % again): go straight to the direct-difference filter.
         // A small remainder is cheaper on the three-product level (sigma 0.2: 6 ms against 36).
         int next_level = next;
-        if (level == 5 && next == 3 && have_direct && nf * 5 > nsub && !getenv("CELLMAP_NO_SKIP3")) next_level = 4;
+        if (level == 5 && next == 3 && have_direct && nf * 5 > nsub && !cm_get_knobs().no_skip3) next_level = 4;
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
             const bool good = (level == 1 || level == 5) && nf * 2 <= nq;
             h->staged_hint_level = good ? level : (level == 5 ? -5 : 0);

@@ -96,6 +96,13 @@ cm_status cm_create(int device, cm_handle_t *out);
  * one-device arithmetic) run on devices[0] alone. */
 cm_status cm_create_multi(const int *devices, int n, cm_handle_t *out);
 cm_status cm_destroy(cm_handle_t h);
+/* Housekeeping (no reference counterpart).  cm_pool_trim returns the handle's cached device blocks (the allocation pool of
+ * the host / graph tiers, capped at min(1/8 of the device memory, 32 GB) or CELLMAP_POOL_MB) to the HIP allocator, so that
+ * other users of the GPU (torch, another handle) see the memory again; it also drops a pending cm_spmm_csr_nnz session.
+ * cm_reload_knobs re-reads the CELLMAP_* diagnostics / test variables: the library reads them in cm_create only, never on
+ * a call path. */
+cm_status cm_pool_trim(cm_handle_t h);
+cm_status cm_reload_knobs(void);
 const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
 cm_status cm_set_stream(cm_handle_t h, void *hip_stream); /* NULL = the handle's own stream */
 cm_status cm_synchronize(cm_handle_t h);

@@ -27,3 +27,28 @@ def oracle():
 
     orc.build()
     return orc
+
+
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment(monkeypatch):
+    """The library latches the CELLMAP_* knobs in cm_create; tests flip them with monkeypatch.setenv on a live handle, so
+    every native call made from a test first re-reads them when the environment has changed."""
+    try:
+        from cellmapper_amd import _native
+    except Exception:
+        yield
+        return
+    state = {"fp": None}
+    orig = _native.Handle.call
+
+    def call(self, name, *args):
+        fp = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("CELLMAP_")))
+        if fp != state["fp"]:
+            state["fp"] = fp
+            _native.reload_knobs()
+        return orig(self, name, *args)
+
+    monkeypatch.setattr(_native.Handle, "call", call)
+    yield
+    if os.path.exists(_native.LIB_PATH):
+        _native.reload_knobs()

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     import torch
+    from cellmapper_amd import _native
     from cellmapper_amd.device import DevicePipeline
     pipe = DevicePipeline(0); torch.cuda.set_stream(pipe.stream)
     rng = np.random.default_rng(a.seed)
@@ -38,6 +39,7 @@ def main():
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ.pop(v, None)
         os.environ["CELLMAP_Q4"] = "2" if case % 2 == 0 else "1"   # the four-accumulator filter wherever it exists / by its size rule
+        _native.reload_knobs()   # (the library latches the knobs in cm_create)
         t0 = time.perf_counter()
         d1, i1 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
         t1 = time.perf_counter()
@@ -45,6 +47,7 @@ def main():
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ[v] = "1"
         os.environ["CELLMAP_Q4"] = "0"
+        _native.reload_knobs()
         d2, i2 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
         t2 = time.perf_counter()
         st2 = pipe.h.knn_stats()

@@ -79,9 +79,19 @@ def test_config2_all_rows_by_an_independent_route(pipe, oracle, monkeypatch):
 
 def _args(**kw):
     a = argparse.Namespace(config=2, nq=0, nref=0, d=50, k=30, genes=0, density=0.03, tile=0, ncat=20, kernel="gaussian",
-                           metric="euclidean", steps=1, warmup=0, check=1, cpu_sample=0)
+                           metric="euclidean", steps=1, warmup=0, check=256, cpu_sample=0, ref_shards=0, exchange="alltoall")
     a.__dict__.update(kw)
     return a
+
+
+def _ctx(pipe, **kw):
+    """bench.py's per-rank context for a one-GPU run (the bench legs of configs 3 / 5 are the test bodies)."""
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    return bench.RunCtx(_args(**kw), torch, dist, 1, 0, pipe.device, pipe, False)
 
 
 def test_config3_full_size_dense_layer_transfer(pipe):
@@ -96,8 +106,8 @@ def test_config3_full_size_dense_layer_transfer(pipe):
     n, G = 1_500_000, 20_000
     if free_b < n * G * 4 + (24 << 30):
         pytest.skip(f"needs the 120 GB payload resident: {free_b >> 30} GiB free")
-    r = bench_wide.run_config3(_args(config=3, nq=n, nref=n, genes=G), pipe, torch)
-    assert r["parity_check"]["ok"], r["parity_check"]
+    r, ok = bench_wide.run_config3(_ctx(pipe, config=3, nq=n, nref=n, genes=G))
+    assert ok and r["parity_check"]["ok"], r["parity_check"]
     assert r["roofline"]["frac"] > 0.5, r["roofline"]
     torch.cuda.empty_cache()
 
@@ -181,6 +191,6 @@ def test_config5_full_size_spatial_self_mapping_and_sparse_imputation(pipe, orac
     assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
     del dist, idx, srt
     torch.cuda.empty_cache()
-    r = bench_wide.run_config5(_args(config=5, nq=200_000, nref=200_000, d=2, k=k, genes=30_000), pipe, torch)
-    assert r["parity_check"]["ok"], r["parity_check"]
+    r, ok = bench_wide.run_config5(_ctx(pipe, config=5, nq=200_000, nref=200_000, d=2, k=k, genes=30_000))
+    assert ok and r["parity_check"]["ok"], r["parity_check"]
     assert r["config"]["output_nnz"] > 200_000 * 20_000   # near-dense product rows (the union of 90 neighbours' supports)
