@@ -22,8 +22,8 @@ BUILD_HINT = (
 
 CM_F32, CM_F64 = 0, 1
 # metric names as sklearn spells them (the reference hands `metric` to sklearn, knn.py:343,429); minkowski: p = 2, its default
-METRICS = {"euclidean": 0, "l2": 0, "minkowski": 0, "cosine": 1, "manhattan": 2, "cityblock": 2, "l1": 2, "chebyshev": 3, "infinity": 3}
-SUPPORTED_METRICS_TEXT = "euclidean / l2 / minkowski (p = 2), cosine, manhattan / cityblock / l1, chebyshev / infinity"
+METRICS = {"euclidean": 0, "l2": 0, "minkowski": 0, "cosine": 1, "manhattan": 2, "cityblock": 2, "l1": 2, "chebyshev": 3, "infinity": 3, "sqeuclidean": 4}
+SUPPORTED_METRICS_TEXT = "euclidean / l2 / minkowski (p = 2), sqeuclidean, cosine, manhattan / cityblock / l1, chebyshev / infinity"
 FORMS = {"auto": 0, "gemm": 1, "direct": 2}
 KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
 CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK, CM_KNN_F64_OUT = 1, 2, 4
@@ -462,6 +462,7 @@ class DeviceGraph:
         self.dist_dtype = np.float32 if (METRICS[metric] == 1 and ref.dtype == np.float32) else np.float64
         self.nnz = None
         self.param = None
+        self.map_tag = None
 
     def close(self):
         if getattr(self, "_g", None) and getattr(self.h, "_h", None):
@@ -494,8 +495,12 @@ class DeviceGraph:
                 "'inverse_distance', 'equal'.")
         nnz, param = C.c_int64(0), C.c_double(0.0)
         self.nnz = None
+        self.map_tag = None
         self.h.call("cm_graph_mapping", self._g, KERNELS[kernel], float(epsilon), C.byref(nnz), C.byref(param))
         self.nnz, self.param = nnz.value, param.value
+        # which kernel the RESIDENT mapping matrix was made with: a graph is shared between NeighborsResults and CellMapper,
+        # and either may re-run the mapping in place (the holder of an older matrix checks this tag before using the graph)
+        self.map_tag = (kernel, float(epsilon))
         return self.nnz, self.param
 
     @property

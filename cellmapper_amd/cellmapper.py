@@ -39,6 +39,7 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
         self.knn: Neighbors | None = None
         self._mapping_matrix: csr_matrix | None = None
         self._mapping_graph = None   # device-resident mapping matrix (a DeviceGraph); scipy CSR is built on first read
+        self._mapping_tag = None     # (kernel, epsilon) that matrix was made with
         self.label_transfer_metrics: dict[str, Any] | None = None
         self.label_transfer_report: pd.DataFrame | None = None
         self.prediction_postfix: str | None = None
@@ -59,6 +60,9 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
     def mapping_matrix(self):
         """Row-normalised mapping matrix, scipy CSR float32 of shape ``(n_query, n_reference)``.  After
         ``compute_mapping_matrix`` with a kernel method it lives on the device; the scipy object is built when read."""
+        if self._mapping_graph is not None and self._mapping_graph.map_tag != self._mapping_tag:
+            self._mapping_graph.mapping(*self._mapping_tag)   # (re-mapped in place by the shared NeighborsResults: restore)
+            self._mapping_matrix = None
         if self._mapping_matrix is None and self._mapping_graph is not None:
             indptr, cols, vals = self._mapping_graph.fetch_mapping()
             m = csr_matrix((vals, cols, indptr), shape=(self.query.n_obs, self.reference.n_obs))
@@ -182,6 +186,7 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
             if getattr(yx, "_graph_dev", None) is not None:   # resident graph: K1-K3 on the device, nothing moves
                 yx._graph_dev.mapping(method)
                 self._mapping_graph, self._mapping_matrix = yx._graph_dev, None
+                self._mapping_tag = yx._graph_dev.map_tag
             else:
                 self._mapping_graph = None
                 self._mapping_matrix = yx.normalized_mapping_matrix(kernel=method)
@@ -201,6 +206,11 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
             raise ValueError("Mapping matrix has not been computed. Call compute_mapping_matrix() first.")
         g = self._mapping_graph
         if g is not None:
+            # the graph is shared with `self.knn.yx`: if somebody re-ran the mapping on it with another kernel
+            # (NeighborsResults.normalized_mapping_matrix), put this mapper's own matrix back before using it
+            if g.map_tag != self._mapping_tag:
+                g.mapping(*self._mapping_tag)
+                self._mapping_matrix = None
             return g.label_vote, g.spmm_dense, g.spmm_csr
         indptr, cols, vals = self._require_mapping()
         h = _native.default_handle()

@@ -2276,6 +2276,11 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
     if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
     if (d > RR_DMAX - 1) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, RR_DMAX - 1);
+    if (metric == CM_METRIC_SQEUCLIDEAN) {   // sklearn: brute force only, squared distances out (knn.py:429 hands the name through)
+        metric = CM_METRIC_EUCLIDEAN;
+        form = CM_FORM_GEMM;
+        flags |= CM_KNN_SQUARED;
+    }
     if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
     if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {

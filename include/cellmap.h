@@ -56,6 +56,9 @@ typedef enum {
  * row width is limited to d <= 128 (two queries per lane up to 64 floats per row, one beyond).  CM_E_UNSUPPORTED beyond that. */
 #define CM_METRIC_MANHATTAN 2
 #define CM_METRIC_CHEBYSHEV 3
+/* sklearn's "sqeuclidean": always brute force (no tree supports it), EuclideanArgKmin with squared=True -- the euclidean GEMM-form
+ * search whose float64 ranking values are returned WITHOUT the final square root, whatever d is. */
+#define CM_METRIC_SQEUCLIDEAN 4
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt

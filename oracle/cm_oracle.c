@@ -141,6 +141,10 @@ static void tile_direct_form(const double *restrict q, const double *restrict Rt
     }
 }
 
+/* sklearn's metric="sqeuclidean" (EuclideanArgKmin, squared=True: _argkmin.pyx.tp skips the final sqrt): set before the call */
+static int g_squared_out = 0;
+void cmo_set_squared_output(int on) { g_squared_out = on != 0; }
+
 int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d, int32_t is_f64,
                       int32_t k, int32_t form, double *out_dist, int64_t *out_idx) {
     if (k < 1 || k > n_ref || d < 1 || nq < 0) return CMO_EINVAL;
@@ -202,7 +206,7 @@ int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t n
                 for (int u = 0; u < nb; u++) {
                     pair_t *hu = h + (size_t)u * k;
                     qsort(hu, (size_t)k, sizeof(pair_t), pair_cmp);
-                    for (int32_t t = 0; t < k; t++) { out_dist[(i0 + u) * k + t] = sqrt(hu[t].v); out_idx[(i0 + u) * k + t] = hu[t].i; }
+                    for (int32_t t = 0; t < k; t++) { out_dist[(i0 + u) * k + t] = g_squared_out ? hu[t].v : sqrt(hu[t].v); out_idx[(i0 + u) * k + t] = hu[t].i; }
                 }
             }
         }

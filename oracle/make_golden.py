@@ -266,8 +266,15 @@ def main():
             "synth_d10_manhattan_k15": (xr10, yr10, 15, "manhattan", "X_emb"),
             "spatial32_self_manhattan_k20": (coords, coords, 20, "manhattan", "spatial"),
             "spatial32_self_chebyshev_k20": (coords, coords, 20, "chebyshev", "spatial"),
+            # round 3: sqeuclidean (brute force whatever d is; squared float64 distances out)
+            "synth_f32_sqeuclidean_k15": (xr, yr, 15, "sqeuclidean", "X_emb"),
+            "synth_d10_sqeuclidean_k15": (xr10, yr10, 15, "sqeuclidean", "X_emb"),
+            "spatial32_self_sqeuclidean_k20": (coords, coords, 20, "sqeuclidean", "spatial"),
         }
+        only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. `--only metrics sqeuclidean`: just the cases of one metric
         for name, (a_, b_, k_, m_, key_) in cases.items():
+            if only and m_ != only:
+                continue
             np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_mapping_case(cm_mod, name, a_, b_, k_, metric=m_, rep_key=key_, G=24))
             print(name, "written")
         return

@@ -40,6 +40,8 @@ def exact_dist(ref, qry_row, cols, metric):
         return np.abs(r - q).sum(1)
     if metric == "chebyshev":
         return np.abs(r - q).max(1)
+    if metric == "sqeuclidean":
+        return ((r - q) ** 2).sum(1)
     return np.sqrt(((r - q) ** 2).sum(1))
 
 

@@ -528,3 +528,31 @@ def test_joint_representations_match_reference_and_oracle(oracle):
     cm2.compute_joint_pca(n_comps=nc)
     np.testing.assert_allclose(reference.obsm["X_pca"], g["pca_scores"][:nr], atol=2e-5 * np.abs(Z).max())
     np.testing.assert_allclose(query.obsm["X_pca"], g["pca_scores"][nr:], atol=2e-5 * np.abs(Z).max())
+
+
+def test_shared_device_graph_is_not_silently_remapped(oracle):
+    """`cm.knn.yx` and `cm` share ONE device graph.  Re-running the mapping on it through NeighborsResults with another
+    kernel must not change what the CellMapper applies (round-2 advisor finding): the mapper restores its own matrix."""
+    import pandas as pd
+
+    from cellmapper_amd import CellMapper, MiniAnnData
+
+    rng = np.random.default_rng(9)
+    n_ref, nq, d, k = 4000, 900, 30, 12
+    ref = rng.standard_normal((n_ref, d)).astype(np.float32)
+    qry = rng.standard_normal((nq, d)).astype(np.float32)
+    umap = rng.standard_normal((n_ref, 2)).astype(np.float32)
+    reference = MiniAnnData(X=np.zeros((n_ref, 2), np.float32), obs=pd.DataFrame(index=[str(i) for i in range(n_ref)]),
+                            obsm={"X_emb": ref, "X_umap": umap})
+    query = MiniAnnData(X=np.zeros((nq, 2), np.float32), obsm={"X_emb": qry})
+    cm = CellMapper(query, reference)
+    cm.compute_neighbors(n_neighbors=k, use_rep="X_emb", only_yx=True)
+    cm.compute_mapping_matrix("gaussian")
+    before = cm.mapping_matrix.copy()
+    other = cm.knn.yx.normalized_mapping_matrix("equal")          # re-maps the SHARED graph in place
+    assert np.allclose(other.data, 1.0 / k)
+    cm.map_obsm("X_umap")
+    o = oracle.run_path(ref, qry, k, obsm=umap)
+    np.testing.assert_allclose(query.obsm["X_umap_pred"], o["obsm_pred"], rtol=1e-5, atol=1e-6)   # gaussian weights, not equal
+    after = cm.mapping_matrix
+    assert np.array_equal(after.indices, before.indices) and np.array_equal(after.data, before.data)

@@ -768,6 +768,34 @@ def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, n
     assert np.array_equal(d2, d3) and np.array_equal(i2, i3)
 
 
+@pytest.mark.parametrize("dtype,d,n_ref,nq,k", [(np.float32, 50, 12000, 700, 30), (np.float64, 33, 9000, 500, 15),
+                                                (np.float32, 10, 12000, 800, 8), (np.float32, 2, 6000, 6000, 20),
+                                                (np.float32, 128, 6000, 300, 30)])
+def test_sqeuclidean_is_the_gemm_form_without_the_root(hip, oracle, dtype, d, n_ref, nq, k):
+    """sklearn's "sqeuclidean" (knn.py:343,429 pass the name through): brute force whatever d is, float64 ranking values
+    returned without the square root -- bit-equal to the oracle (pinned on the reference by tests/golden/*sqeuclidean*), and
+    the same neighbours as "euclidean" in its GEMM form."""
+    rng = np.random.default_rng(77 + d)
+    ref = (rng.standard_normal((n_ref, d)) * (50.0 if d <= 3 else 1.0)).astype(dtype)
+    ref[100:110] = ref[100]
+    qry = ref.copy() if nq == n_ref else (rng.standard_normal((nq, d)) * (50.0 if d <= 3 else 1.0)).astype(dtype)
+    qry[3] = ref[100]
+    dist, idx = hip.knn(ref, qry, k, metric="sqeuclidean")
+    od, oi = oracle.knn_euclidean(ref, qry, k, squared=True)
+    assert dist.dtype == np.float64 and np.array_equal(idx, oi) and np.array_equal(dist, od)
+    d2, i2 = hip.knn(ref, qry, k, metric="euclidean", form="gemm")
+    assert np.array_equal(i2, idx) and np.array_equal(d2, np.sqrt(dist))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "sqeuclidean" in n])
+def test_sqeuclidean_matches_reference_golden(name, hip):
+    g = load_golden(name)
+    xrep, yrep = rep(g)
+    dist, idx = hip.knn(xrep, yrep, int(g["k"]), metric="sqeuclidean")
+    assert np.array_equal(idx, g["yx_idx"])
+    np.testing.assert_allclose(dist, g["yx_dist"], rtol=2e-15, atol=0)   # (BLAS accumulation order upstream: last bit)
+
+
 def test_metric_passthrough_limits_and_names(hip):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((500, 130)).astype(np.float32)

@@ -26,6 +26,13 @@ def test_oracle_matches_reference(name, oracle):
         dist, idx = oracle.knn_cosine(xrep, yrep, k)
     elif metric in ("manhattan", "chebyshev"):
         dist, idx = oracle.knn_minkowski_family(xrep, yrep, k, metric)
+    elif metric == "sqeuclidean":
+        dist, idx = oracle.knn_euclidean(xrep, yrep, k, squared=True)
+        # the float64 GEMM of sklearn's chunks accumulates in BLAS order (OpenBLAS kernels), the oracle in a sequential fma chain:
+        # last-bit differences in the squared values (1e-15 relative), identical neighbours.  ("euclidean" hides them behind the
+        # square root for float64 input.)
+        np.testing.assert_allclose(dist, g["yx_dist"], rtol=2e-15, atol=0)
+        assert np.array_equal(idx, g["yx_idx"])
     else:
         dist, idx = oracle.knn_euclidean(xrep, yrep, k)
     assert dist.dtype == g["yx_dist"].dtype
