@@ -44,6 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CM2_SB8
 #define CM2_SB8 0   // K = 128 hi*hi kernel: 1 = single fragment set (see knn_cand_f16); measured 0.8 % slower, so off
 #endif
+#ifndef CM2_PROD_SB
+#define CM2_PROD_SB 0   // production K = 128 body: 1 = single fragment set (32 VGPRs less; measured slower in round 2, and the 12 bytes of scratch left are prologue spills)
+#endif
 #ifndef CM2_EXP
 #define CM2_EXP 0  // timing experiments only (scripts/ablate_skeleton.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads, 8 no min trees
 #endif
@@ -510,8 +513,18 @@ __device__ __forceinline__ void min_step(int I, const f32x16 &P0, const f32x16 &
 // different sub-tiles hold different rows, so at least SEEDL rows of the lane's half of the sample lie at or below its
 // SEEDL-th entry; the two lanes of a query own disjoint halves, hence at least 2*SEEDL sample rows lie at or below the
 // larger of their SEEDL-th entries -- that value is written to cthr[] as the query's seed (see knn_run_staged).
-template <int KSTEPS, int NP, bool CEN = false, int SEEDL = 0>
-__global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
+// PROD = true (round 3, instantiated for the K = 128 hi*hi level = config 4's kernel): the production body.
+//   * the CELLMAP_DBG modes are compiled out (a.dbg is a constant 0 in a local copy of the arguments: every runtime test of
+//     it folds away -- two vector and a dozen scalar instructions per accumulator and sub-tile, and the counters' SGPRs);
+//   * the 64 registers of query fragments live in the ACCUMULATION half of the register file and feed the matrix core from
+//     there (B operand of `v_mfma`; loaded straight into AGPRs, the MFMAs written as inline asm -- left to the compiler the
+//     fragments are parked there and copied back in front of every MFMA): round 2's body needed 256 VGPRs + 44 bytes of
+//     scratch, this one fits the 256-register budget of two waves per SIMD without scratch.
+template <int KSTEPS, int NP, bool CEN, int SEEDL, bool PROD>
+__device__ __forceinline__ void knn_cand_f16_body(P1Args a_in) {
+    P1Args a = a_in;
+    if constexpr (PROD) a.dbg = 0;
+    constexpr bool AQ = false && PROD && NP == 1;   // query fragments in AGPRs (off: see below)
     constexpr bool LO3 = NP == 3;
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = img_row_bytes(KSTEPS, !LO3);
@@ -612,14 +625,21 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         for (int j = 0; j < 2; ++j) {
             const _Float16 *qrow = a.Q + (qbase + j * 32 + c) * (2 * K);
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) qh[j][s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
+            for (int s = 0; s < KSTEPS; ++s) {
+                if constexpr (AQ) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qh[j][s]) : "v"(qrow + (2 * s + hh) * 8) : "memory");
+                else qh[j][s] = *reinterpret_cast<const half8 *>(qrow + (2 * s + hh) * 8);
+            }
 #pragma unroll
             for (int s = 0; s < KL; ++s) ql[j][s] = *reinterpret_cast<const half8 *>(qrow + K + (2 * s + hh) * 8);
         }
+        if constexpr (AQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // Touch the query fragments here: the compiler places its vmcnt wait for the loads above at this first use
         // instead of in front of the first MFMA of the tile loop, where it would also wait for the tile prefetch.
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[0][s]), "v"(qh[1][s]));
+        for (int s = 0; s < KSTEPS; ++s) {
+            if constexpr (AQ) asm volatile("" ::"a"(qh[0][s]), "a"(qh[1][s]));
+            else asm volatile("" ::"v"(qh[0][s]), "v"(qh[1][s]));
+        }
 #pragma unroll
         for (int s = 0; s < KL; ++s) asm volatile("" ::"v"(ql[0][s]), "v"(ql[1][s]));
         const float thr_init = (a.dbg & 1) ? -INFINITY : INFINITY;
@@ -689,7 +709,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         // behind it for the next sub-tile, 14 MFMAs (~450 cycles) before its next use; saves the 32 VGPRs of the second set
         // (scratch 44 -> 12 bytes per lane).  Measured at 1.5 M x 1.5 M x d=128 on one box, alternating: 520.3 ms with two
         // sets, 524.0 ms with one -- the spilled values are not touched in the tile loop, so the default keeps two sets.
-        constexpr bool SB = !LO3 && KSTEPS >= 8 && CM2_SB8;
+        constexpr bool SB = !LO3 && KSTEPS >= 8 && (CM2_SB8 || (PROD && CM2_PROD_SB));
         half8 ah[KSTEPS], al[SB ? 1 : KSTEPS];   // LO3: hi / lo fragments; otherwise the two hi fragment buffers
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -770,6 +790,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
                         } else if (pr == 1) {
                             if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[1][s % KL], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], ql[0][s % KL], acc0, 0, 0, 0);
+                        } else if constexpr (AQ) {
+                            if (jq) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "v"(cur[s]), "a"(qh[1][s]));
+                            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "v"(cur[s]), "a"(qh[0][s]));
                         } else {
                             if (jq) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[1][s], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[s], qh[0][s], acc0, 0, 0, 0);
@@ -887,6 +910,18 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
         atomicAdd(&a.ctr[11], c_loopcyc);
         atomicAdd(&a.ctr[12], c_fincyc);
     }
+}
+
+// the kernels proper: the generic family, and the production form of the K = 128 hi*hi level (config 4), whose register budget
+// is split 192 VGPRs + 64 accumulation registers (the query fragments) by the attribute -- left alone the compiler halves
+// the 256 registers of a two-waves-per-SIMD kernel between the two files and spills
+template <int KSTEPS, int NP, bool CEN = false, int SEEDL = 0>
+__global__ __launch_bounds__(NT, 2) void knn_cand_f16(P1Args a) {
+    knn_cand_f16_body<KSTEPS, NP, CEN, SEEDL, false>(a);
+}
+template <int KSTEPS>
+__global__ __launch_bounds__(NT, 2) void knn_cand_f16p(P1Args a) {
+    knn_cand_f16_body<KSTEPS, 1, false, 0, true>(a);
 }
 
 

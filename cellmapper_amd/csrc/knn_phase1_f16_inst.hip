@@ -31,7 +31,18 @@ cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const
         CM_F16_CASE(2) CM_F16_CASE(4)
 #undef CM_F16_CASE
     case 8:   // K = 128: only the hi*hi level runs on this kernel (64 queries per wave); level 3 uses knn_cand_f16w
+        // (production body unless a CELLMAP_DBG mode is on: diagnostics compiled out, query fragments in the accumulation registers)
+#ifdef CM2_NO_PROD   // (A/B builds: round 2's body)
         if (a.nprod == 1) return launch_f16<8, 1>(h, grid, lds, a);
+#endif
+        if (a.nprod == 1 && a.dbg) return launch_f16<8, 1>(h, grid, lds, a);
+        if (a.nprod == 1) {
+            auto kern = cmk2::knn_cand_f16p<8>;
+            CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
+            CM_HIP(h, hipGetLastError());
+            return CM_OK;
+        }
         break;
     }
     CM_FAIL(h, CM_E_INTERNAL, "phase1/f16: no instantiation for KSTEPS=%d with %d products", KSTEPS, a.nprod);

@@ -131,6 +131,41 @@ static void tile_gemm_form(const double *restrict q, const double *restrict Rt, 
     }
 }
 
+/* Four queries against one tile (round 3): the same fma chains, but a loaded vector of reference values now feeds four
+ * queries' accumulators -- 16 vector accumulators (4 queries x 32 rows) stay in registers over the feature loop, where the
+ * one-query form kept its 256 partial sums in memory (three memory operations per fused multiply-add).  Per-pair
+ * arithmetic and order unchanged: the same bits (the golden vectors pin it). */
+#define CMO_JB 32
+__attribute__((target_clones("avx512f", "avx2,fma", "default")))
+static void tile_gemm_form4(const double *restrict q, const double *restrict Rt, const double *restrict yn, int32_t d,
+                            const double *restrict xn, double *restrict d2 /* [4][CMO_RB] */) {
+    const double *restrict q0 = q, *restrict q1 = q + d, *restrict q2 = q + 2 * (size_t)d, *restrict q3 = q + 3 * (size_t)d;
+    for (int j0 = 0; j0 < CMO_RB; j0 += CMO_JB) {
+        double a0[CMO_JB], a1[CMO_JB], a2[CMO_JB], a3[CMO_JB];
+        for (int j = 0; j < CMO_JB; j++) { a0[j] = 0.0; a1[j] = 0.0; a2[j] = 0.0; a3[j] = 0.0; }
+        for (int32_t c = 0; c < d; c++) {
+            const double *restrict y = Rt + (size_t)c * CMO_RB + j0;
+            const double c0 = q0[c], c1 = q1[c], c2 = q2[c], c3 = q3[c];
+            for (int j = 0; j < CMO_JB; j++) {
+                const double yj = y[j];
+                a0[j] = fma(c0, yj, a0[j]);
+                a1[j] = fma(c1, yj, a1[j]);
+                a2[j] = fma(c2, yj, a2[j]);
+                a3[j] = fma(c3, yj, a3[j]);
+            }
+        }
+        for (int j = 0; j < CMO_JB; j++) {
+            const double ynj = yn[j0 + j];
+            double v0 = (xn[0] + (-2.0 * a0[j])) + ynj, v1 = (xn[1] + (-2.0 * a1[j])) + ynj;
+            double v2 = (xn[2] + (-2.0 * a2[j])) + ynj, v3 = (xn[3] + (-2.0 * a3[j])) + ynj;
+            d2[j0 + j] = v0 > 0.0 ? v0 : 0.0;
+            d2[CMO_RB + j0 + j] = v1 > 0.0 ? v1 : 0.0;
+            d2[2 * CMO_RB + j0 + j] = v2 > 0.0 ? v2 : 0.0;
+            d2[3 * CMO_RB + j0 + j] = v3 > 0.0 ? v3 : 0.0;
+        }
+    }
+}
+
 __attribute__((target_clones("avx512f", "avx2,fma", "default")))
 static void tile_direct_form(const double *restrict q, const double *restrict Rt, int32_t d, double *restrict d2) {
     for (int j = 0; j < CMO_RB; j++) d2[j] = 0.0;
@@ -176,7 +211,7 @@ int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t n
     {
         pair_t *h = (pair_t *)malloc(sizeof(pair_t) * (size_t)k * CMO_QB);
         double *q = (double *)malloc(sizeof(double) * (size_t)d * CMO_QB);
-        double xn[CMO_QB], d2[CMO_RB];
+        double xn[CMO_QB], d2[4 * CMO_RB];
         if (!h || !q) {
 #pragma omp atomic write
             err = CMO_ENOMEM;
@@ -195,10 +230,21 @@ int cmo_knn_euclidean(const void *ref, int64_t n_ref, const void *qry, int64_t n
                     const double *T = Rt + (size_t)t * CMO_RB * d;
                     const int64_t j0 = t * CMO_RB;
                     const int nr = (int)((n_ref - j0) < CMO_RB ? (n_ref - j0) : CMO_RB);
-                    for (int u = 0; u < nb; u++) {
+                    int u = 0;
+                    if (form == 0)
+                        for (; u + 4 <= nb; u += 4) {   /* four queries share every loaded reference vector */
+                            tile_gemm_form4(q + (size_t)u * d, T, yn + j0, d, xn + u, d2);
+                            for (int w = 0; w < 4; w++) {
+                                pair_t *hu = h + (size_t)(u + w) * k;
+                                const double *dw = d2 + (size_t)w * CMO_RB;
+                                for (int j = 0; j < nr; j++)   /* rows in ascending index order, as sklearn scans them */
+                                    if (dw[j] <= hu[0].v) { pair_t x = { dw[j], j0 + j }; heap_push(hu, k, x); }
+                            }
+                        }
+                    for (; u < nb; u++) {
                         pair_t *hu = h + (size_t)u * k;
-                        if (form == 0) tile_gemm_form(q + u * d, T, yn + j0, d, xn[u], d2);
-                        else tile_direct_form(q + u * d, T, d, d2);
+                        if (form == 0) tile_gemm_form(q + (size_t)u * d, T, yn + j0, d, xn[u], d2);
+                        else tile_direct_form(q + (size_t)u * d, T, d, d2);
                         for (int j = 0; j < nr; j++)   /* rows in ascending index order, as sklearn scans them */
                             if (d2[j] <= hu[0].v) { pair_t x = { d2[j], j0 + j }; heap_push(hu, k, x); }
                     }
