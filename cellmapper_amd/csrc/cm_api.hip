@@ -640,8 +640,12 @@ cm_status cm_label_vote(cm_handle_t h, const int64_t *indptr, const int32_t *col
     return sync(h);
 }
 
+// c_begin / c_end: only the payload columns [c_begin, c_end) are transferred (gene-column sharding of the multi-device handle);
+// `out` is always the full [nq, n_out] array
 static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_cols, const float *d_vals, int64_t nq,
-                                   const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out) {
+                                   const void *B, int64_t n_ref, int64_t n_out, int32_t b_dtype, void *out, int64_t c_begin = 0,
+                                   int64_t c_end = -1) {
+    if (c_end < 0) c_end = n_out;
     if (b_dtype != CM_F32 && b_dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "spmm: unknown dtype id %d", b_dtype);
     if (n_out < 1) CM_FAIL(h, CM_E_INVALID, "spmm: payload has no columns");
     CM_TRY(tile_streams(h));
@@ -651,7 +655,7 @@ static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const
     // to two output tiles, the output into query tiles; tile i is copied to the caller's buffer on a second stream while
     // tile i+1 is computed.  Nothing of size nq x n_out is ever resident.
     const size_t budget = device_budget(h, cm_get_knobs().spmm_budget_mb);
-    int64_t cw = n_out;
+    int64_t cw = std::max<int64_t>(c_end - c_begin, 1);
     int64_t qt = std::max<int64_t>(1, std::min<int64_t>(nq, 1 << 16));           // query rows per output tile
     auto need = [&](int64_t w, int64_t t) { return es * ((size_t)n_ref * w + 2 * (size_t)t * w); };
     while (need(cw, qt) > budget && qt > 1024) qt /= 2;
@@ -663,8 +667,8 @@ static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const
     CM_TRY(dB.alloc(h, es * (size_t)n_ref * cw));
     CM_TRY(dO[0].alloc(h, es * (size_t)qt * cw));
     CM_TRY(dO[1].alloc(h, es * (size_t)qt * cw));
-    for (int64_t c0 = 0; c0 < n_out; c0 += cw) {
-        const int64_t w = std::min<int64_t>(cw, n_out - c0);
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += cw) {
+        const int64_t w = std::min<int64_t>(cw, c_end - c0);
         CM_HIP(h, hipMemcpy2DAsync(dB.p, es * w, (const char *)B + es * c0, es * n_out, es * w, (size_t)n_ref, hipMemcpyHostToDevice, h->stream));
         int it = 0;
         for (int64_t q0 = 0; q0 < nq; q0 += qt, ++it) {
@@ -837,6 +841,8 @@ struct GraphPart {
     DevBuf dist, idx;              // k-NN result as the reference returns it: float64 (float32: cosine on float32 input), int64
     DevBuf indptr, cols, vals;     // row-normalised mapping matrix rows of the part, canonical CSR (indptr starts at 0)
     int64_t nnz = 0;
+    DevBuf f_indptr, f_cols, f_vals;   // multi-device: the WHOLE mapping matrix on this part's device (built on first use by a wide
+    bool has_full = false;             // dense transfer: gene-column sharding needs every row on every device)
 };
 struct cm_graph_s {
     int64_t nq = 0, n_ref = 0;
@@ -876,6 +882,42 @@ std::vector<cm_handle_t> part_handles(const cm_graph_s *g) {
     std::vector<cm_handle_t> v;
     for (auto &p : g->parts) v.push_back(p.h);
     return v;
+}
+__global__ void add_offset_i64(int64_t *p, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += base;
+}
+// Every device gets the WHOLE mapping matrix (peer copies of the other parts' rows; row pointers re-based): what a
+// gene-column-sharded transfer needs (366 MB at 1.5 M x 30, then no further communication).
+cm_status ensure_full_matrix(cm_handle_t h, cm_graph_s *g) {
+    const size_t P = g->parts.size();
+    bool all = true;
+    for (auto &p : g->parts) all = all && p.has_full;
+    if (all) return CM_OK;
+    std::vector<int64_t> base(P + 1, 0);
+    for (size_t i = 0; i < P; ++i) base[i + 1] = base[i] + g->parts[i].nnz;
+    return for_parts(h, P, part_handles(g), [&](size_t i) -> cm_status {
+        GraphPart &p = g->parts[i];
+        CM_TRY(begin_call(p.h, 0));
+        CM_TRY(p.f_indptr.alloc(p.h, 8 * ((size_t)g->nq + 1)));
+        CM_TRY(p.f_cols.alloc(p.h, 4 * (size_t)std::max<int64_t>(base[P], 1)));
+        CM_TRY(p.f_vals.alloc(p.h, 4 * (size_t)std::max<int64_t>(base[P], 1)));
+        for (size_t r = 0; r < P; ++r) {
+            const GraphPart &s = g->parts[r];
+            const int64_t n = s.nq + (r + 1 == P ? 1 : 0);   // the last part also brings the end pointer
+            CM_HIP(p.h, hipMemcpyPeerAsync(p.f_indptr.as<int64_t>() + s.q_lo, p.h->device, s.indptr.p, s.h->device, 8 * (size_t)n, p.h->stream));
+            if (base[r] && n > 0)
+                hipLaunchKernelGGL(add_offset_i64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.h->stream, p.f_indptr.as<int64_t>() + s.q_lo, n, base[r]);
+            if (s.nnz) {
+                CM_HIP(p.h, hipMemcpyPeerAsync(p.f_cols.as<int32_t>() + base[r], p.h->device, s.cols.p, s.h->device, 4 * (size_t)s.nnz, p.h->stream));
+                CM_HIP(p.h, hipMemcpyPeerAsync(p.f_vals.as<float>() + base[r], p.h->device, s.vals.p, s.h->device, 4 * (size_t)s.nnz, p.h->stream));
+            }
+        }
+        CM_HIP(p.h, hipGetLastError());
+        CM_TRY(sync(p.h));
+        p.has_full = true;
+        return CM_OK;
+    });
 }
 // the part's distances as float64 on its device (float32 graphs: widened into the part's workspace)
 cm_status part_dist64(GraphPart &p, const cm_graph_s *g, const double **out) {
@@ -1052,6 +1094,7 @@ cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g) {
             (void)hipSetDevice(p.h->device);
             if (p.h->a3_session && static_cast<A3Session *>(p.h->a3_session)->mp == p.indptr.as<int64_t>()) a3_session_drop(p.h);
             p.dist.release(); p.idx.release(); p.indptr.release(); p.cols.release(); p.vals.release();
+            p.f_indptr.release(); p.f_cols.release(); p.f_vals.release();
         }
     (void)hipSetDevice(h->device);
     delete g;
@@ -1077,8 +1120,10 @@ cm_status cm_graph_mapping(cm_handle_t h, cm_graph_t g, int32_t kernel, double e
     if (!g) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     g->has_map = false;
-    for (auto &p : g->parts)   // a pending sparse-product session holds the OLD mapping-matrix arrays of this graph
+    for (auto &p : g->parts) {  // a pending sparse-product session holds the OLD mapping-matrix arrays of this graph
         if (p.h->a3_session) { (void)hipSetDevice(p.h->device); a3_session_drop(p.h); }
+        p.has_full = false;
+    }
     (void)hipSetDevice(h->device);
     const size_t P = g->parts.size();
     const auto hs = part_handles(g);
@@ -1209,7 +1254,22 @@ cm_status cm_graph_spmm_dense(cm_handle_t h, cm_graph_t g, const void *B, int64_
     CM_NEED_MAP(h, g);
     if (n_ref != g->n_ref) CM_FAIL(h, CM_E_INVALID, "graph: payload with %lld rows for %lld reference cells", (long long)n_ref, (long long)g->n_ref);
     const size_t es = b_dtype == CM_F64 ? 8 : 4;
-    return for_parts(h, g->parts.size(), part_handles(g), [&](size_t i) -> cm_status {   // payload streamed to every device, rows by slice
+    const size_t P = g->parts.size();
+    if (P > 1 && n_out >= (int64_t)(64 * P)) {
+        // wide payload (a layer): GENE COLUMNS sharded over the devices -- each uploads only its slab (the PCIe copy of the
+        // payload is what a host-tier layer transfer waits for) and multiplies ALL query rows with it; the mapping matrix is
+        // replicated once per graph by peer copies.  A column's sum is the same sequence of multiply-adds on any device.
+        CM_TRY(ensure_full_matrix(h, g));
+        return for_parts(h, P, part_handles(g), [&](size_t i) -> cm_status {
+            GraphPart &p = g->parts[i];
+            const int64_t cb = n_out / (int64_t)P, ce = n_out % (int64_t)P;
+            const int64_t c_lo = (int64_t)i * cb + std::min<int64_t>((int64_t)i, ce), c_hi = c_lo + cb + ((int64_t)i < ce ? 1 : 0);
+            CM_TRY(begin_call(p.h, 0));
+            return spmm_dense_stream(p.h, p.f_indptr.as<int64_t>(), p.f_cols.as<int32_t>(), p.f_vals.as<float>(), g->nq, B, n_ref, n_out, b_dtype,
+                                     out, c_lo, c_hi);
+        });
+    }
+    return for_parts(h, P, part_handles(g), [&](size_t i) -> cm_status {   // narrow payload: replicated, rows by slice
         GraphPart &p = g->parts[i];
         CM_TRY(begin_call(p.h, 0));
         return spmm_dense_stream(p.h, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, B, n_ref, n_out, b_dtype,

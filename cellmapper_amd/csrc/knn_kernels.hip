@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+cm_status cm_p1_wide_launch(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds, const float *Q, const float *R, int tps, int n_tiles,
+                            int Kc, int C, int *cand, float *cthr);   // knn_phase1_inst.hip (group 3): K-chunked kernel, d >= 260
 cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
@@ -40,7 +42,9 @@ namespace {
 
 constexpr int kSupportedKP[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 84, 100, 132, 164, 196, 260};
 constexpr int RR_NCMAX = 1024;  // max candidates per query handled by the re-rank / merge kernels
-constexpr int RR_DMAX = 260;
+constexpr int RR_DMAX = 260;   // LDS stride (doubles) of a staged query row for d <= 259; wider rows: q_stride(d)
+constexpr int KNN_DMAX = 2047;  // widest embedding (round 3: the K-chunked f32 filter, knn_cand_mfma_wide)
+__host__ __device__ constexpr int q_stride(int d) { return d < RR_DMAX ? RR_DMAX : ((d + 4) & ~3); }
 constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
 constexpr int FB_CAP = 4096;    // fallback collection capacity per query
 constexpr int FB_BLOCKS = 1024;
@@ -436,8 +440,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     extern __shared__ __align__(16) unsigned char rr_smem[];
     const int cap = ncap > 0 ? ncap : S * Kc;
     const int ncp = (cap + 1) & ~1;
-    double(*s_q)[RR_DMAX] = reinterpret_cast<double(*)[RR_DMAX]>(rr_smem);
-    double *s_vb = reinterpret_cast<double *>(rr_smem + sizeof(double) * 4 * RR_DMAX);
+    const int qs = q_stride(d);
+    double *s_qb = reinterpret_cast<double *>(rr_smem);   // [4][qs]: the four waves' query rows
+    double *s_vb = reinterpret_cast<double *>(rr_smem + sizeof(double) * 4 * qs);
     int *s_ib = reinterpret_cast<int *>(s_vb + 4 * ncp);
     double *s_kth = reinterpret_cast<double *>(s_ib + 4 * ncp);
     double *s_kc = s_kth + 4;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     if (lane == 0) { s_kc[w] = INFINITY; s_kth[w] = INFINITY; }   // (fewer than k valid candidates: bound = inf)
     const int64_t io = qmap ? (int64_t)qmap[i] : i;
     if (io < 0) return;   // padding row of the bucket-aligned packing
-    double *q = s_q[w];
+    double *q = s_qb + (size_t)w * qs;
     for (int c = lane; c < d; c += 64) q[c] = (double)qry[io * d + c];
     __builtin_amdgcn_wave_barrier();
     double xn = 0.0;
@@ -586,9 +591,9 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     }
 }
 
-static inline size_t rerank_lds_bytes(int S, int Kc) {
+static inline size_t rerank_lds_bytes(int S, int Kc, int d = 0) {
     const int ncp = (S * Kc + 1) & ~1;
-    return sizeof(double) * 4 * RR_DMAX + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
+    return sizeof(double) * 4 * q_stride(d) + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
 }
 
 // ------------------------------------------------------------------ exact fallback ------------------
@@ -603,7 +608,8 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
                                                            const double *__restrict__ bound, void *__restrict__ out_dist,
                                                            int64_t *__restrict__ out_idx, int *__restrict__ overflow,
                                                            int f_start) {
-    __shared__ double s_q[RR_DMAX];
+    extern __shared__ __align__(16) unsigned char fb_smem[];
+    double *s_q = reinterpret_cast<double *>(fb_smem);   // [q_stride(d)] (dynamic: wide rows)
     __shared__ double s_v[FB_CAP];
     __shared__ int s_i[FB_CAP];
     __shared__ int s_n;
@@ -657,8 +663,9 @@ __global__ __launch_bounds__(256) void knn_fallback_scan(const T *__restrict__ r
     // Rows are staged through LDS in chunks of rc rows (coalesced copy; one thread per row afterwards, which keeps
     // pair_value's sequential summation order) and every staged chunk serves FBS_QG flagged queries.
     extern __shared__ __align__(16) unsigned char fbs_smem[];
-    T *s_rows = reinterpret_cast<T *>(fbs_smem);  // [rc][d]
-    __shared__ double s_q[FBS_QG][RR_DMAX];
+    const int qs_ = q_stride(d);
+    double *s_qb = reinterpret_cast<double *>(fbs_smem);                          // [FBS_QG][qs_]: the flagged queries' rows
+    T *s_rows = reinterpret_cast<T *>(fbs_smem + sizeof(double) * FBS_QG * qs_);  // [rc][d]
     int nf = *flag_cnt;
     if (nf > FBS_NQ) nf = FBS_NQ;
     const int64_t per = (n_ref + gridDim.x - 1) / gridDim.x;
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256) void knn_fallback_scan(const T *__restrict__ r
         __syncthreads();
         for (int t = threadIdx.x; t < ng * d; t += blockDim.x) {
             const int g = t / d, c = t - g * d;
-            s_q[g][c] = (double)qry[(int64_t)flag_list[f0 + g] * d + c];
+            s_qb[(size_t)g * qs_ + c] = (double)qry[(int64_t)flag_list[f0 + g] * d + c];
         }
         __syncthreads();
         double xn[FBS_QG], b[FBS_QG];
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(256) void knn_fallback_scan(const T *__restrict__ r
             xn[g] = 0.0;
             b[g] = -1.0;
             if (g < ng) {
-                for (int c = 0; c < d; ++c) xn[g] = fma(s_q[g][c], s_q[g][c], xn[g]);
+                for (int c = 0; c < d; ++c) xn[g] = fma(s_qb[(size_t)g * qs_ + c], s_qb[(size_t)g * qs_ + c], xn[g]);
                 b[g] = bound[flag_list[f0 + g]];
             }
         }
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(256) void knn_fallback_scan(const T *__restrict__ r
 #pragma unroll
                 for (int g = 0; g < FBS_QG; ++g) {
                     if (g < ng) {
-                        const double v = pair_value<T>(s_q[g], xn[g], s_rows + (size_t)r * d, d, metric, form);
+                        const double v = pair_value<T>(s_qb + (size_t)g * qs_, xn[g], s_rows + (size_t)r * d, d, metric, form);
                         if (v <= b[g]) {
                             const int pos = atomicAdd(&gcount[f0 + g], 1);
                             if (pos < FB_CAP) {
@@ -815,16 +822,21 @@ struct KnnPlan {
 
 cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan *p) {
     p->KP = pick_kp(d);
-    if (p->KP < 0) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of 259", d);
+    // d > 128 (every width the split-fp16 families do not serve): the K-chunked kernel, prepared rows padded to a multiple of its
+    // chunk width -- beyond KP = 260 nothing else fits on chip, and from 129 on it is several times faster than the one-piece
+    // kernel, whose 128 x KP tile leaves LDS for a single wave of queries (d = 256: 881 -> see DESIGN.md 7b)
+    const bool wide = p->KP < 0 || d > 128;
+    if (wide) p->KP = (d + 1 + cmk::KCW - 1) / cmk::KCW * cmk::KCW;
+    if (d > KNN_DMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, KNN_DMAX);
     int slack = k / 4 > 8 ? k / 4 : 8;
     p->Kc = k + slack;
-    p->C = p->Kc + 64;
+    p->C = p->Kc + (wide ? 40 : 64);   // (wide rows: room for four waves next to the 34-KB chunk)
     p->NW = 0;
     for (int nw : {4, 2, 1}) {
-        if (cmk::phase1_lds_bytes(p->KP, nw, p->C) <= 160 * 1024) { p->NW = nw; break; }
+        if ((wide ? cmk::phase1_wide_lds_bytes(nw, p->C) : cmk::phase1_lds_bytes(p->KP, nw, p->C)) <= 160 * 1024) { p->NW = nw; break; }
     }
     if (!p->NW) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip candidate buffers", k);
-    p->lds = cmk::phase1_lds_bytes(p->KP, p->NW, p->C);
+    p->lds = wide ? cmk::phase1_wide_lds_bytes(p->NW, p->C) : cmk::phase1_lds_bytes(p->KP, p->NW, p->C);
     int QB = p->NW * 32;
     p->nq_pad = (nq + QB - 1) / QB * QB;
     p->n_tiles = (int)((n_ref + cmk::BR - 1) / cmk::BR);
@@ -1649,7 +1661,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             CM_TRY(cm_grid_query<T>(h, d_qry, nsub, d, qmap, grid_info, grid_start, grid_xyz, grid_idx, k, Kc0, words, cand, cthr));
             if (marks) cm_mark(h, 2);
             last_Kc = Kc0; last_S = 1;
-            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rerank_lds_bytes(1, Kc0), st, d_ref, d_qry, nsub, d, cand, cthr,
+            hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rerank_lds_bytes(1, Kc0, d), st, d_ref, d_qry, nsub, d, cand, cthr,
                                1, Kc0, k, metric, form, qnorm, words, -(float)(d + 4) * 2.0f * 5.9604645e-8f, 0.f,
                                (const float *)nullptr, (const double *)nullptr, idx_offset, flags, d_out_dist, d_out_idx, flag_out,
                                (int *)(words + 2), bound, qmap, 0, (const float *)nullptr, 0, (const int *)nullptr);
@@ -1971,7 +1983,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (marks) cm_mark(h, 2);
         if (!rerank) return CM_OK;
         const int pilot_kc = pilot ? p2.Kc : 0;
-        const size_t rr_lds = rr_ncap ? rerank_lds_bytes(1, rr_ncap) : rerank_lds_bytes(p2.S, p2.Kc);
+        const size_t rr_lds = rr_ncap ? rerank_lds_bytes(1, rr_ncap, d) : rerank_lds_bytes(p2.S, p2.Kc, d);
         hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nsub + 3) / 4)), dim3(256), rr_lds, st, d_ref, d_qry, nsub, d, rr_cand, rr_cthr,
                            rr_S, p2.Kc, k, metric, form, qnorm, words, c_eps, c_split,
                            level == 4 ? (const float *)nullptr : scale3, level == 4 ? (const double *)nullptr : (const double *)d_mean,
@@ -2119,9 +2131,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // ---- exact float64 scan for the queries no stage could certify
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
-        int rc = (int)(52 * 1024 / ((size_t)d * sizeof(T)));   // rows per staged chunk
+        int rc = (int)((52 * 1024 - (d >= RR_DMAX ? sizeof(double) * FBS_QG * q_stride(d) / 2 : 0)) / ((size_t)d * sizeof(T)));   // rows per staged chunk
         rc = rc >= 256 ? 256 : (rc >= 32 ? rc / 32 * 32 : (rc < 1 ? 1 : rc));
-        const size_t fb_lds = (size_t)rc * d * sizeof(T);
+        const size_t fb_lds = (size_t)rc * d * sizeof(T) + sizeof(double) * FBS_QG * q_stride(d);
         auto scan = knn_fallback_scan<T>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds));
         hipLaunchKernelGGL(scan, dim3(FBS_SLICES, FBS_FY), dim3(256), fb_lds, st, d_ref, n_ref, d_qry, d, metric, form, flag_out,
@@ -2130,7 +2142,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_out,
                        (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
                        d_out_idx, (int *)(words + 3));
-    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
+    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_out, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
                        (int *)(words + 3), FBS_NQ);
     CM_HIP(h, hipGetLastError());
@@ -2179,7 +2191,8 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     cm_mark(h, 1);
     dim3 grid((unsigned)(p.nq_pad / (p.NW * 32)), (unsigned)p.S);
     cm_status s = CM_E_INTERNAL;
-    bool ok = cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
+    bool ok = (d > 128 && ((s = cm_p1_wide_launch(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr)), true)) ||
+              cm_p1_launch_g0(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
               cm_p1_launch_g1(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
               cm_p1_launch_g2(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s) ||
               cm_p1_launch_g3(h, p.KP, p.NW, grid, p.lds, Qp, Rp, p.tps, p.n_tiles, p.Kc, p.C, cand, cthr, &s);
@@ -2188,16 +2201,16 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     cm_mark(h, 2);
     // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
     const float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
-    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), rerank_lds_bytes(S, Kc), st, d_ref, d_qry, nq, d, cand, cthr,
+    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), rerank_lds_bytes(S, Kc, d), st, d_ref, d_qry, nq, d, cand, cthr,
                        S, Kc, k, metric, form, qnorm, words, c_eps, 0.f, (const float *)nullptr, (const double *)nullptr,
                        idx_offset, flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0,
                        (const float *)nullptr, 0, (const int *)nullptr);
     cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
     {
-        int rc = (int)(52 * 1024 / ((size_t)d * sizeof(T)));   // rows per staged chunk
+        int rc = (int)((52 * 1024 - (d >= RR_DMAX ? sizeof(double) * FBS_QG * q_stride(d) / 2 : 0)) / ((size_t)d * sizeof(T)));   // rows per staged chunk
         rc = rc >= 256 ? 256 : (rc >= 32 ? rc / 32 * 32 : (rc < 1 ? 1 : rc));
-        const size_t fb_lds = (size_t)rc * d * sizeof(T);
+        const size_t fb_lds = (size_t)rc * d * sizeof(T) + sizeof(double) * FBS_QG * q_stride(d);
         auto scan = knn_fallback_scan<T>;
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds));
         hipLaunchKernelGGL(scan, dim3(FBS_SLICES, FBS_FY), dim3(256), fb_lds, st, d_ref, n_ref, d_qry, d, metric, form, flag_list,
@@ -2206,7 +2219,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_list,
                        (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
                        d_out_idx, (int *)(words + 3));
-    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), 0, st, d_ref, n_ref, d_qry, d, k, metric, form,
+    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
                        (int *)(words + 3), FBS_NQ);
     CM_HIP(h, hipGetLastError());
@@ -2261,7 +2274,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     }
     if (!use_f16_path(d, k)) {   // f32-input kernel: prepared rows of KP floats
         int KP = pick_kp(d);
-        if (KP < 0) KP = 260;
+        if (KP < 0 || d > 128) KP = (d + 1 + cmk::KCW - 1) / cmk::KCW * cmk::KCW;   // chunked kernel: padded to the chunk width
         int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
         b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP);
     }
@@ -2275,7 +2288,7 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     if (k < 1 || k > n_ref)
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
     if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
-    if (d > RR_DMAX - 1) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, RR_DMAX - 1);
+    if (d > KNN_DMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, KNN_DMAX);
     if (metric == CM_METRIC_SQEUCLIDEAN) {   // sklearn: brute force only, squared distances out (knn.py:429 hands the name through)
         metric = CM_METRIC_EUCLIDEAN;
         form = CM_FORM_GEMM;

@@ -50,3 +50,22 @@ bool CM_P1_FN(CM_P1_GROUP)(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds,
     }
     return false;
 }
+
+#if CM_P1_GROUP == 3
+// wide rows (KP a multiple of 128 beyond 260): the K-chunked kernel
+cm_status cm_p1_wide_launch(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds, const float *Q, const float *R, int tps, int n_tiles,
+                            int Kc, int C, int *cand, float *cthr) {
+    if (KP % cmk::KCW != 0 || KP < cmk::KCW) CM_FAIL(h, CM_E_INTERNAL, "phase1 (wide): KP=%d is not a multiple of %d", KP, cmk::KCW);
+#define CM_P1W(nw_)                                                                                                          \
+    case nw_: {                                                                                                              \
+        auto kern = cmk::knn_cand_mfma_wide<nw_>;                                                                            \
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(nw_ * 64), lds, h->stream, Q, R, KP, tps, n_tiles, Kc, C, cand, cthr);          \
+        CM_HIP(h, hipGetLastError());                                                                                        \
+        return CM_OK;                                                                                                        \
+    }
+    switch (NW) { CM_P1W(4) CM_P1W(2) CM_P1W(1) }
+#undef CM_P1W
+    CM_FAIL(h, CM_E_INTERNAL, "phase1 (wide): bad NW %d", NW);
+}
+#endif

@@ -131,7 +131,8 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
  *   ref [n_ref, d], qry [nq, d]  dtype CM_F32 / CM_F64 (both the same)
  *   out_dist: float64 [nq, k] for euclidean; for cosine the input dtype (sklearn keeps float32), [nq, k]
  *   out_idx : int64 [nq, k]
- * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859). */
+ * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859); d > 2047 -> CM_E_UNSUPPORTED
+ * (d <= 61: split-fp16 MFMA filter K = 64; <= 128: K = 128; <= 259: f32 MFMA; <= 2047: f32 MFMA chunked over d). */
 cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d,
                  int32_t dtype, int32_t k, int32_t metric, int32_t form, void *out_dist, int64_t *out_idx);
 

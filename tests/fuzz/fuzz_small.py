@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check on SMALL shapes (run on the GPU box): reference sets of 1 .. 6 000 rows, 1 .. 1 500 queries, widths
-1 .. 259, k from 1 to the reference size (capped at 200), float32 / float64, duplicated rows, all four metrics -- the host tier's
+1 .. 2 047, k from 1 to the reference size (capped at 200), float32 / float64, duplicated rows, all five metrics -- the host tier's
 cm_knn against the CPU oracle, bit for bit (float32 cosine: sklearn's float32 arithmetic, compared at 4e-7 with tie sets).
 The large-shape fuzzers never visit these corners (k close to n_ref, one query, one reference row per tile ...)."""
 import argparse, json, os, sys, time
@@ -18,8 +18,8 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev"]))
-        d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259]))
+        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean"]))
+        d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259, 260, 300, 512, 777, 1024, 2047]))
         if metric in ("manhattan", "chebyshev") and d > 128:
             d = 128
         n_ref = int(rng.choice([1, 2, 31, 129, 513, 2000, 6000]))
@@ -39,6 +39,8 @@ def main():
             dist, idx = h.knn(ref, qry, k, metric=metric)
             if metric == "euclidean":
                 od, oi = orc.knn_euclidean(ref, qry, k)
+            elif metric == "sqeuclidean":
+                od, oi = orc.knn_euclidean(ref, qry, k, squared=True)
             elif metric == "cosine":
                 od, oi = orc.knn_cosine(ref, qry, k)
             else:

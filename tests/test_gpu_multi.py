@@ -31,6 +31,7 @@ def test_multi_device_graph_equals_single_device(problem, ndev, kernel, oracle):
     rng = np.random.default_rng(3)
     codes = rng.integers(0, n_cat, ref.shape[0]).astype(np.int32)
     X = rng.random((ref.shape[0], G), dtype=np.float32)
+    Xw = rng.random((ref.shape[0], 200), dtype=np.float32)     # >= 64 columns per device: the gene-column-sharded transfer
     Xs = sp.csr_matrix((X * (rng.random(X.shape) < 0.15)).astype(np.float32))
     Xs.sort_indices()
     outs = []
@@ -45,8 +46,10 @@ def test_multi_device_graph_equals_single_device(problem, ndev, kernel, oracle):
         ip, cc, vv = g.fetch_mapping()
         code, conf = g.label_vote(codes, n_cat)
         dense = g.spmm_dense(X)
+        wide = g.spmm_dense(Xw)
+        wide64 = g.spmm_dense(Xw.astype(np.float64))
         cp, ccols, cvals = g.spmm_csr(Xs.indptr, Xs.indices, Xs.data, G)
-        outs.append(dict(dist=dist, idx=idx, nnz=nnz, param=param, ip=ip, cc=cc, vv=vv, code=code, conf=conf, dense=dense,
+        outs.append(dict(dist=dist, idx=idx, nnz=nnz, param=param, ip=ip, cc=cc, vv=vv, code=code, conf=conf, dense=dense, wide=wide, wide64=wide64,
                          csr=sp.csr_matrix((cvals, ccols, cp), shape=(qry.shape[0], G)).toarray()))
         g.close()
         h.close()
@@ -62,6 +65,10 @@ def test_multi_device_graph_equals_single_device(problem, ndev, kernel, oracle):
     assert (many["code"] == one["code"]).mean() > 0.9995
     np.testing.assert_allclose(many["conf"], one["conf"], rtol=1e-6)
     np.testing.assert_allclose(many["dense"], one["dense"], rtol=1e-6)
+    assert many["wide"].dtype == np.float32 and many["wide64"].dtype == np.float64
+    np.testing.assert_allclose(many["wide"], one["wide"], rtol=1e-6)
+    np.testing.assert_allclose(many["wide64"], one["wide64"], rtol=1e-6)
+    np.testing.assert_allclose(many["wide"], oracle.spmm_dense(o["indptr"], o["cols"], o["vals"], Xw), rtol=1e-5)
     np.testing.assert_allclose(many["csr"], one["csr"], rtol=1e-6)
 
 

@@ -796,6 +796,37 @@ def test_sqeuclidean_matches_reference_golden(name, hip):
     np.testing.assert_allclose(dist, g["yx_dist"], rtol=2e-15, atol=0)   # (BLAS accumulation order upstream: last bit)
 
 
+@pytest.mark.parametrize("d,n_ref,nq,k,dtype,metric", [
+    (260, 6000, 700, 30, np.float32, "euclidean"),      # first width of the K-chunked filter (KP = 384: three chunks)
+    (512, 9000, 900, 15, np.float32, "euclidean"),      # foundation-model embedding width
+    (512, 5000, 400, 20, np.float64, "euclidean"),
+    (1000, 4000, 300, 10, np.float32, "cosine"),
+    (2047, 3000, 200, 10, np.float32, "euclidean"),     # the widest supported row
+    (700, 40000, 130, 30, np.float32, "euclidean"),     # few query blocks: reference splits + multi-list re-rank
+])
+def test_wide_rows_chunked_filter_is_exact(hip, oracle, d, n_ref, nq, k, dtype, metric):
+    """260 <= d <= 2047 (round 3; `knn.py:429` sets no limit on the width): the f32 MFMA filter with the contraction chunked
+    over the feature dimension (`knn_cand_mfma_wide`), float64 re-rank and exact fallback with LDS sized by the row width --
+    neighbours and distances bit-equal to the oracle, duplicated reference rows included."""
+    rng = np.random.default_rng(d + n_ref)
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    ref[50:58] = ref[50]
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    qry[7] = ref[50]
+    dist, idx = hip.knn(ref, qry, k, metric=metric)
+    st = hip.knn_stats()
+    if metric == "cosine":
+        od, oi = oracle.knn_cosine(ref, qry, k)
+        assert (np.sort(idx, 1) == np.sort(oi, 1)).mean() > 0.9999 and np.allclose(dist, od, rtol=0, atol=4e-7), st
+    else:
+        od, oi = oracle.knn_euclidean(ref, qry, k)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), st
+        assert idx[7, 0] == 50 and np.all(dist[7, :8] == 0)
+    assert st["lowd_path"] == 1 and st["fallback_queries"] <= max(16, nq // 20), st
+    with pytest.raises(NotImplementedError, match="supported maximum"):
+        hip.knn(np.zeros((100, 2048), np.float32), np.zeros((10, 2048), np.float32), 5)
+
+
 def test_metric_passthrough_limits_and_names(hip):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((500, 130)).astype(np.float32)
