@@ -135,6 +135,8 @@ struct A3Session {
     int64_t token = 0;   // fingerprint of the output row pointer the count call produced (pointer identity alone is not
                          // enough: numpy / the pool hand out recycled addresses)
     DevBuf dp, dc, dv, bp, bc, bv, op;
+    DevBuf oc, ov, pidx;   // single-pass form (round 3): the product's entries, made during the count call and kept for the fill call
+    bool filled = false;
     // the mapping matrix on the device: the session's own upload (dp / dc / dv) or a cm_graph's arrays
     const int64_t *mp = nullptr;
     const int32_t *mc = nullptr;
@@ -698,6 +700,20 @@ cm_status cm_spmm_dense(cm_handle_t h, const int64_t *indptr, const int32_t *col
 }
 
 // shared by the host tier (mapping matrix in host arrays) and the graph tier (mapping matrix already on the device: d_m*)
+// upper bound of the product's entry count: row i has at most min(n_out, sum of its neighbours' payload row lengths) entries
+static __global__ void a3_row_upper_bound(const int64_t *__restrict__ mp, const int32_t *__restrict__ mc, int64_t nq,
+                                          const int64_t *__restrict__ bp, int64_t n_out, unsigned long long *__restrict__ total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long ub = 0;
+    if (i < nq) {
+        for (int64_t p = mp[i]; p < mp[i + 1]; ++p) { const int64_t j = mc[p]; ub += bp[j + 1] - bp[j]; }
+        if (ub > n_out) ub = n_out;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ub += __shfl_xor(ub, o);
+    if ((threadIdx.x & 63) == 0 && ub) atomicAdd(total, (unsigned long long)ub);
+}
+
 // fingerprint of a host row pointer: its end and 64 evenly spaced entries
 static int64_t indptr_token(const int64_t *p, int64_t nq) {
     uint64_t t = 0x9E3779B97F4A7C15ull ^ (uint64_t)p[nq];
@@ -711,7 +727,7 @@ static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const i
                                    const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                                    int64_t n_out, int64_t *out_indptr) {
     if (nq < 0 || n_ref < 0 || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
-    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + 4096));
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + cm_align(8 * ((size_t)std::max<int64_t>(nq, 0) + 2)) + 8192));
     a3_session_drop(h);
     A3Session *ss = new (std::nothrow) A3Session();
     if (!ss) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: out of host memory");
@@ -729,6 +745,43 @@ static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const i
     }
     if (rc == CM_OK) rc = upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv);
     if (rc == CM_OK) rc = ss->op.alloc(h, 8 * ((size_t)nq + 1));
+    // Single-pass form (round 3): when a worst-case buffer for the WHOLE product fits the device budget, counts, offsets and
+    // entries come from ONE gather (the wave-sliced kernel of cm_spmm_csr_fused_dev) during this call and stay on the device;
+    // the fill call then only copies them out -- the count pass used to repeat the whole product to learn the row lengths.
+    if (rc == CM_OK && nq > 0 && n_ref > 0 && cm_spmm_csr_single_pass_ok(n_out)) {
+        unsigned long long *d_ub = (unsigned long long *)cm_ws_alloc(h, 64);
+        unsigned long long ub = 0;
+        if (d_ub && hipMemsetAsync(d_ub, 0, 8, h->stream) == hipSuccess) {
+            hipLaunchKernelGGL(a3_row_upper_bound, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->stream, ss->mp, ss->mc, nq,
+                               ss->bp.as<int64_t>(), n_out, d_ub);
+            if (d2h(h, &ub, d_ub, 8) == CM_OK && sync(h) == CM_OK && ub > 0) {
+                const int64_t ilen = cm_payload_index_len_impl(n_ref, n_out);
+                const size_t need = 8 * (size_t)ub + 4 * (size_t)std::max<int64_t>(ilen, 0) + 8 * ((size_t)nq + 2);
+                if (ilen > 0 && need <= device_budget(h, cm_get_knobs().spgemm_budget_mb) / 2) {
+                    int *flag = (int *)cm_ws_alloc(h, 64);
+                    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, 8 * (size_t)(nq + 2));
+                    int bad = 1;
+                    if (flag && chain && ss->pidx.alloc(h, 4 * (size_t)ilen) == CM_OK && ss->oc.alloc(h, 4 * (size_t)ub) == CM_OK &&
+                        ss->ov.alloc(h, 4 * (size_t)ub) == CM_OK) {
+                        h->a3_index = nullptr;
+                        if (cm_payload_index_run(h, ss->bp.as<int64_t>(), ss->bc.as<int32_t>(), n_ref, n_out, ss->pidx.as<int32_t>(), flag) == CM_OK &&
+                            d2h(h, &bad, flag, 4) == CM_OK && sync(h) == CM_OK && !bad) {
+                            rc = cm_spmm_csr_sliced_run(h, ss->mp, ss->mc, ss->mv, nq, ss->bp.as<int64_t>(), ss->bc.as<int32_t>(), ss->bv.as<float>(),
+                                                        n_ref, ss->pidx.as<int32_t>(), n_out, ss->op.as<int64_t>(), ss->oc.as<int32_t>(),
+                                                        ss->ov.as<float>(), (int64_t)ub, nullptr, chain, nullptr);
+                            if (rc == CM_OK) rc = d2h(h, out_indptr, ss->op.p, 8 * ((size_t)nq + 1));
+                            if (rc == CM_OK) rc = sync(h);
+                            if (rc == CM_OK) { ss->filled = true; ss->token = indptr_token(out_indptr, nq); }
+                            if (rc != CM_OK) a3_session_drop(h);
+                            return rc;
+                        }
+                    }
+                    ss->pidx.release(); ss->oc.release(); ss->ov.release();   // (no room, or a payload row is not canonical CSR: two passes)
+                    h->err.clear();
+                }
+            }
+        }
+    }
     if (rc == CM_OK) rc = rn.alloc(h, 4 * (size_t)nq);
     if (rc == CM_OK)
         rc = cm_spmm_csr_count_run(h, ss->mp, ss->mc, ss->mv, nq, ss->bp.as<int64_t>(), ss->bc.as<int32_t>(), ss->bv.as<float>(), n_out,
@@ -765,6 +818,17 @@ static cm_status spmm_csr_fill_impl(cm_handle_t h, const int64_t *indptr, const 
         CM_TRY(upload_csr(h, b_indptr, b_cols, b_vals, n_ref, ss->bp, ss->bc, ss->bv));
         CM_TRY(ss->op.alloc(h, 8 * ((size_t)nq + 1)));
         CM_TRY(h2d(h, ss->op.p, out_indptr, 8 * ((size_t)nq + 1)));
+    }
+    if (ss != &local && ss->filled) {   // single-pass session: the entries are already on the device
+        const int64_t nnz_ = out_indptr[nq];
+        cm_status rcf = CM_OK;
+        if (nnz_ > 0) {
+            rcf = d2h(h, out_cols, ss->oc.p, 4 * (size_t)nnz_);
+            if (rcf == CM_OK) rcf = d2h(h, out_vals, ss->ov.p, 4 * (size_t)nnz_);
+        }
+        if (rcf == CM_OK) rcf = sync(h);
+        a3_session_drop(h);
+        return rcf;
     }
     // Query tiles: the output (which approaches nq x n_out for dense neighbourhoods) is produced in tiles of at most `cap`
     // entries, copied to the caller's arrays on a second stream while the next tile is computed.

@@ -266,3 +266,34 @@ def test_spgemm_sliced_kernel_shapes(oracle):
     bad_cols[lo:hi] = bad_cols[lo:hi][::-1]
     with pytest.raises(ValueError, match="ascending"):
         pipe.payload_index(d["bp"], t(bad_cols, np.int32), n_out)
+
+
+def test_host_tier_single_pass_product_equals_the_count_and_fill_pair(hip, oracle, monkeypatch):
+    """Round 3: when a worst-case buffer for the whole product fits the device budget, cm_spmm_csr_nnz makes counts, offsets
+    and entries in ONE gather and cm_spmm_csr only copies them out.  Same bits as the two-pass pair (forced here by a
+    4 MB budget) and as the oracle; a non-canonical payload (unsorted columns) silently takes the pair."""
+    rng = np.random.default_rng(12)
+    n_ref, nq, k, G = 7000, 2600, 25, 900
+    idx = np.stack([rng.choice(n_ref, k, replace=False) for _ in range(nq)]).astype(np.int64)
+    dist = np.sort(rng.random((nq, k)) + 0.1, axis=1)
+    ip, cc, vv, _, _ = hip.mapping_matrix(dist, idx, n_ref, "gaussian")
+    X = sp.random(n_ref, G, density=0.08, format="csr", dtype=np.float32, random_state=rng)
+    X.sort_indices()
+    one = hip.spmm_csr(ip, cc, vv, X.indptr, X.indices, X.data, G)                       # single pass (fits easily)
+    monkeypatch.setenv("CELLMAP_SPGEMM_BUDGET_MB", "4")
+    two = hip.spmm_csr(ip, cc, vv, X.indptr, X.indices, X.data, G)                       # tiled count + fill pair
+    monkeypatch.delenv("CELLMAP_SPGEMM_BUDGET_MB")
+    for a_, b_ in zip(one, two):
+        assert np.array_equal(a_, b_)
+    want = oracle.spmm_csr(ip, cc, vv, X)
+    got = sp.csr_matrix((one[2], one[1], one[0]), shape=(nq, G)).toarray()
+    assert np.array_equal(got, want)
+    # unsorted payload columns: the payload index refuses it, the barrier pair (which only needs distinct columns) runs
+    Xu = X.copy()
+    for r in range(0, n_ref, 3):
+        a0, a1 = Xu.indptr[r], Xu.indptr[r + 1]
+        if a1 - a0 > 1:
+            Xu.indices[a0:a1] = Xu.indices[a0:a1][::-1].copy()
+            Xu.data[a0:a1] = Xu.data[a0:a1][::-1].copy()
+    un = hip.spmm_csr(ip, cc, vv, Xu.indptr, Xu.indices, Xu.data, G)
+    assert np.array_equal(sp.csr_matrix((un[2], un[1], un[0]), shape=(nq, G)).toarray(), want)
