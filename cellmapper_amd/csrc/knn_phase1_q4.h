@@ -23,6 +23,9 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
 #define CM2Q_EXP 0   // timing experiments only (scripts/ablate_q4.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads,
                      // 8 no min trees, 16 no threshold test, 64 thresholds at -inf (never append)
 #endif
+#ifndef CM2Q_EVMASK
+#define CM2Q_EVMASK 1   // 1: event path with the six group tests hoisted into scalar masks (A/B: profiles/r03_filter_ablation.md)
+#endif
 #ifndef CM2Q_PRIO
 #define CM2Q_PRIO 0   // wave priority while an append event is handled (s_setprio; 0 = leave it alone)
 #endif
@@ -36,9 +39,21 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
         const float tj_ = thr[J];                                                                              \
         int cj_ = cnt[J];                                                                                      \
         const unsigned loff_ = (unsigned)((((J) * 32 + c) * 2 + hh) * CL * 8);                                 \
+        if (CM2Q_EVMASK) {   /* all six group tests issued back to back into scalar masks: ONE vector -> scalar hand-over  \
+                                instead of one per group, then scalar-only branching */                                \
+            const unsigned long long g0_ = __ballot((T0) < tj_), g1_ = __ballot((T1) < tj_), g2_ = __ballot((T2) < tj_); \
+            const unsigned long long g3_ = __ballot((T3) < tj_), g4_ = __ballot((T4) < tj_), g5_ = __ballot((ACC)[15] < tj_); \
+            if (g0_) { CM2_APPEND_B((ACC)[0], 0, RB, loff_) CM2_APPEND_B((ACC)[1], 1, RB, loff_) CM2_APPEND_B((ACC)[2], 2, RB, loff_) } \
+            if (g1_) { CM2_APPEND_B((ACC)[3], 3, RB, loff_) CM2_APPEND_B((ACC)[4], 4, RB, loff_) CM2_APPEND_B((ACC)[5], 5, RB, loff_) } \
+            if (g2_) { CM2_APPEND_B((ACC)[6], 6, RB, loff_) CM2_APPEND_B((ACC)[7], 7, RB, loff_) CM2_APPEND_B((ACC)[8], 8, RB, loff_) } \
+            if (g3_) { CM2_APPEND_B((ACC)[9], 9, RB, loff_) CM2_APPEND_B((ACC)[10], 10, RB, loff_) CM2_APPEND_B((ACC)[11], 11, RB, loff_) } \
+            if (g4_) { CM2_APPEND_B((ACC)[12], 12, RB, loff_) CM2_APPEND_B((ACC)[13], 13, RB, loff_) CM2_APPEND_B((ACC)[14], 14, RB, loff_) } \
+            if (g5_) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                                                    \
+        } else {                                                                                               \
         CM2_GROUP_B(ACC, T0, 0, RB, loff_) CM2_GROUP_B(ACC, T1, 1, RB, loff_) CM2_GROUP_B(ACC, T2, 2, RB, loff_) \
         CM2_GROUP_B(ACC, T3, 3, RB, loff_) CM2_GROUP_B(ACC, T4, 4, RB, loff_)                                  \
         if (__ballot((ACC)[15] < tj_) != 0ull) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                          \
+        }                                                                                                      \
         cnt[J] = cj_;                                                                                          \
         if (adbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                         \
         if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(0);                                                          \
