@@ -23,6 +23,7 @@ void latch_knobs() {
     if (const char *e = getenv("CELLMAP_PHASE1")) k.phase1 = !strcmp(e, "f32") ? 1 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "direct") ? 3 : 0));
     k.spgemm_ct = (int)num("CELLMAP_SPGEMM_CT", 0);
     k.spgemm_dbg = (int)num("CELLMAP_SPGEMM_DBG", 0);
+    k.a3_gather = (int)num("CELLMAP_A3_GATHER", 0);
     k.spmm_budget_mb = num("CELLMAP_SPMM_BUDGET_MB", -1);
     k.spgemm_budget_mb = num("CELLMAP_SPGEMM_BUDGET_MB", -1);
     k.pool_mb = num("CELLMAP_POOL_MB", -1);

@@ -17,6 +17,7 @@ struct cm_knobs {
     int phase1 = 0;              // CELLMAP_PHASE1: 1 f32, 2 f16, 3 direct
     int spgemm_ct = 0;           // CELLMAP_SPGEMM_CT: columns per accumulator pass of the sparse product (tests)
     int spgemm_dbg = 0;          // CELLMAP_SPGEMM_DBG: timing experiments
+    int a3_gather = 0;           // CELLMAP_A3_GATHER: 1 = entry-per-lane gather of the wave-sliced sparse product (A/B against the 16-byte one)
     long long spmm_budget_mb = -1, spgemm_budget_mb = -1;   // CELLMAP_SPMM_BUDGET_MB / CELLMAP_SPGEMM_BUDGET_MB: device budget of the streaming host tiers
     long long pool_mb = -1;      // CELLMAP_POOL_MB: cap of the per-handle device allocation pool
     bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,

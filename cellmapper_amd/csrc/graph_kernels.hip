@@ -8,10 +8,19 @@
 //   cellmapper.py:338,373,628  mapping_matrix @ dense          cellmapper.py:373  mapping_matrix @ sparse
 #include "cm_internal.h"
 
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 
 #include <math.h>
+
+#ifndef CM_A3_EXP
+#define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 1 aligned 16-byte loads, 2 no
+                       // accumulator updates (loads kept), 4 no payload loads, 8 no output stores, 16 no wait for the rows in front
+#endif
+#ifndef CM_A3_NSET
+#define CM_A3_NSET 2   // register sets of the 16-byte gather (3 = two batches in flight behind the one being applied: measured no faster, 32 registers more)
+#endif
 
 namespace {
 
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(512) void spgemm_rows(const int64_t *__restrict__ i
                         __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     long long excl = 0;
-                    for (int64_t pos = row - 1; pos >= 0;) {   // 64 predecessors at a time, nearest on lane 0
+                    for (int64_t pos = (CM_A3_EXP & 16) ? -1 : row - 1; pos >= 0;) {   // 64 predecessors at a time, nearest on lane 0
                         const int64_t i = pos - lane;
                         unsigned long long v, empty, incl;
                         for (;;) {
@@ -1098,14 +1107,25 @@ __global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb
     }
 }
 
-template <int EPL>
+// NCH: compile-time bound on the 64-column chunks of a wave's slice (W / 64 <= NCH).  The finished slice is read ONCE into
+// NCH registers per lane (all LDS reads issued back to back, one wait), cleared behind those reads for the next row,
+// counted and emitted from the registers: the count and the emission used to be two loops of read -> wait -> ballot
+// with one LDS round trip per 64 columns each (round 3: ~2 x 59 x 130 cycles per row at 30 000 genes).
+// X4 (round 3): a lane holds FOUR CONSECUTIVE entries of a slice per 16-byte load (entries 256 g + 4 lane ..) instead of
+// EPL entries 64 apart -- a 113-entry slice of config 5 is 2 loads per neighbour instead of 8, so the 63 loads a wave may
+// have in flight carry four times the bytes -- and THREE register sets rotate (two batches in flight behind the one being
+// applied): the gather is bound by latency x bytes in flight, not by bandwidth.  EPL = 4 or 8 entries per lane (1 or 2
+// groups).  A 16-byte load may run up to three entries past the end of its slice (never used): a slice that ends within
+// three entries of the END OF THE ARRAY (b_nnz) takes the entry-per-lane loop instead.
+template <int EPL, int NCH, bool X4>
 __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
                                                       const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
                                                       const float *__restrict__ bvals, const int32_t *__restrict__ bidx_, int nb1,
                                                       int n_out, int W, int64_t *out_indptr, int32_t *__restrict__ ocols,
                                                       float *__restrict__ ovals, const int32_t *__restrict__ order,
-                                                      unsigned long long *chain, int64_t capacity, int32_t *__restrict__ out_rows) {
+                                                      unsigned long long *chain, int64_t capacity, int32_t *__restrict__ out_rows,
+                                                      int64_t b_nnz) {
     // EPL entries per lane and neighbour are held in registers (slices of up to 64 EPL entries; longer ones take a scalar
     // loop), NBATCH = 16 / EPL neighbours per register set: the same 2 x 32 registers of payload in flight per lane
     constexpr int NBATCH = 16 / EPL;
@@ -1115,8 +1135,10 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     int *wsum = reinterpret_cast<int *>(acc + 8 * W);                   // [2][8] wave totals (by row parity)
     long long *tk = reinterpret_cast<long long *>(wsum + 16);           // [0] ticket of the row after next, [1] the row's first entry
     float *dummy = reinterpret_cast<float *>(tk + 2);                   // [512] where lanes without an entry do their add
+    float *zero = dummy + 512;                                          // [64] zeros: what a chunk beyond the slice reads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wlo = wave * W, whi = (wlo + W < n_out) ? wlo + W : n_out;   // this wave's output columns (possibly none)
+    const int wlo = wave * W;   // this wave's output columns: [wlo, min(wlo + W, n_out)) (possibly none)
+    if (tid < 64) zero[tid] = 0.f;
     const int dix = (int)(dummy - acc) + lane;
     const bool ticketed = !out_rows;   // chained scan: rows by ticket (a predecessor is always held by a running workgroup)
     int parity = 0;
@@ -1131,6 +1153,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
         __syncthreads();
     } else {
         row = blockIdx.x; nxt = row + gridDim.x;
+        __syncthreads();   // (zero[] is written)
     }
 
     // ---- neighbour metadata of a row, per wave: lane l holds neighbours l and l + 64 (slice start, slice length, weight)
@@ -1176,17 +1199,105 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     stage0(g, row); stage1(g); stage2(g); stage3(g); finish(g, cur);
     if (!ticketed) stage0(g, nxt);
 
+    const int nch = W / 64;   // chunks of this wave's slice (<= NCH; columns at or beyond n_out are never written: they stay 0)
+    const int zix = (int)(zero - acc);
+    // the row whose entries wait in registers for their place (deferred emission, see the end of the row loop)
+    float rv[NCH];
+    int64_t prev_row = 0;
+    int prev_all = 0, prev_before = 0;
+    bool have_prev = false;
+    // wave 0: the sum of the counts of all rows in front of row r -- published counts back to the nearest published
+    // inclusive prefix, 256 rows per step (four loads per lane in flight; the nearest inclusive prefix is a few hundred
+    // rows back: every workgroup places a row one row after counting it)
+    auto lookback = [&](int64_t r) -> long long {
+        constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
+        long long excl = 0;
+        for (int64_t pos = (CM_A3_EXP & 16) ? -1 : r - 1; pos >= 0; pos -= 256) {
+            unsigned long long v[4];
+            int ustar = 4, fi = 63;
+            for (;;) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = pos - 64 * u - lane;
+                    v[u] = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                }
+                bool retry = false;
+                ustar = 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long empty = __ballot((v[u] >> 62) == 0ull), incl = __ballot((v[u] >> 62) == 2ull);
+                    if (ustar == 4 && !retry) {
+                        if (incl != 0ull && (empty == 0ull || __ffsll((long long)incl) < __ffsll((long long)empty))) {
+                            ustar = u; fi = __ffsll((long long)incl) - 1;
+                        } else if (empty != 0ull) retry = true;
+                    }
+                }
+                if (!retry) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            long long part = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < ustar || (u == ustar && lane <= fi)) part += (long long)(v[u] & VMASK);
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+            excl += part;
+            if (ustar < 4) break;
+        }
+        return excl;
+    };
+    // the place of row r (count n) in the output -> tk[1]; also the row's indptr entry and, chained, its inclusive prefix
+    auto place = [&](int64_t r, int n) {
+        if (!ticketed) {
+            if (tid == 0) {
+                const unsigned long long old = atomicAdd(chain + nq + 1, (1ull << 40) | (unsigned long long)n);
+                const long long j = (long long)(old >> 40), o = (long long)(old & ((1ull << 40) - 1ull));
+                out_indptr[j] = o;
+                if (j == nq - 1) out_indptr[nq] = o + n;
+                out_rows[j] = (int32_t)r;
+                tk[1] = o;
+            }
+        } else if (wave == 0) {
+            const long long excl = lookback(r);
+            if (lane == 0) {
+                if (r > 0)
+                    __hip_atomic_store(chain + r, (2ull << 62) | (unsigned long long)(excl + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else out_indptr[0] = 0;
+                out_indptr[r + 1] = excl + n;
+                tk[1] = excl;
+            }
+        }
+    };
+    // this wave's slice of a row (ascending columns; consecutive lanes write consecutive entries)
+    auto emit = [&](float (&r_)[NCH], int64_t row_out, int before, int all) {
+        if (row_out + all > capacity) return;
+        int64_t o = row_out + before;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float v = r_[i];
+            const bool nz = v != 0.f;
+            const unsigned long long m = __ballot(nz);
+            if (m != 0ull) {   // (uniform)
+                if (nz && !(CM_A3_EXP & 8)) {
+                    const int64_t q = o + __popcll(m & ((1ull << lane) - 1ull));
+                    ocols[q] = wlo + 64 * i + lane;
+                    ovals[q] = v;
+                }
+                o += __popcll(m);
+            }
+        }
+    };
+    {   // the slice starts cleared; every row clears it again right behind its read-out
+        float4 *a4 = reinterpret_cast<float4 *>(acc + wlo);
+        for (int c = lane; c < W / 4; c += 64) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     while (row < nq) {
         // the next row: static stride, its metadata fetched in four stages spread over this row -- or, with tickets, taken
         // now, known to the waves after the first barrier and fetched during the emission (a ticket held for longer is a
         // row the other workgroups wait for)
         const int64_t nxt2 = nxt + gridDim.x;
         if (ticketed && tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
-        // ---- clear this wave's slice
-        {
-            float4 *a4 = reinterpret_cast<float4 *>(acc + wlo);
-            for (int c = lane; c < W / 4; c += 64) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         if (!ticketed) stage1(g);
         // ---- the gather: batches of NBATCH neighbours, two register sets
         const int nn = cur.deg < 128 ? cur.deg : 128;
@@ -1250,6 +1361,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                 }
             }
         };
+        if constexpr (!X4) {
         BM ma = pick(0), mb;
         load_batch(ca, va, ma);
         for (int ub = 0; ub < nn; ub += 2 * NBATCH) {
@@ -1260,6 +1372,126 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             ma = pick(ub + 2 * NBATCH);
             load_batch(ca, va, ma);
             apply_batch(cb, vb, mb);
+        }
+        } else {
+            constexpr int EPG = EPL / 4, NB = 4 / EPG;   // groups of 4 entries per lane, neighbours per register set
+            typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            // (uniform) the 16-byte loads of this slice stay inside the payload arrays
+            auto safe = [&](int64_t st, int len) { const int r = (len + 3) & ~3; return st + (r < 4 ? 4 : r) <= b_nnz; };
+            // FAST: every slice of this row and wave fits the registers and none touches the end of the arrays -- the loop
+            // then holds no load besides the register sets' (a conditional entry-per-lane loop between two neighbours makes
+            // the compiler's load counting conservative: it waited for part of the NEXT set before every neighbour)
+            auto gather = [&](auto fast_) {
+                constexpr bool FAST = decltype(fast_)::value;
+                i32x4 c0[NB][EPG], c1[NB][EPG], c2[NB][EPG];
+                f32x4 v0[NB][EPG], v1[NB][EPG], v2[NB][EPG];
+                auto load_set = [&](i32x4 (&cc)[NB][EPG], f32x4 (&vv)[NB][EPG], const BM &bm) {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        int64_t st; int len; float wa;
+                        uni(bm, n, st, len, wa);
+                        const bool has = len > 0 && (FAST || safe(st, len));
+                        const char *pc = reinterpret_cast<const char *>(has ? bcols + st : reinterpret_cast<const int32_t *>(indptr));
+                        const char *pv = reinterpret_cast<const char *>(has ? bvals + st : reinterpret_cast<const float *>(indptr));
+                        const int lim = has ? len : 0;
+#pragma unroll
+                        for (int q = 0; q < EPG; ++q) {
+                            const int f = 256 * q + 4 * lane;
+                            unsigned o_ = f < lim ? (unsigned)f << 2 : 0u;
+                            if (CM_A3_EXP & 4) {
+                                cc[n][q] = i32x4{4 * lane, 4 * lane + 1, 4 * lane + 2, 4 * lane + 3} + (int)((st * 7) & 1023);
+                                vv[n][q] = f32x4{1.f, 2.f, 3.f, 4.f};
+                                asm volatile("" : "+v"(cc[n][q]), "+v"(vv[n][q]));
+                            } else if (CM_A3_EXP & 1) {   // timing experiment: aligned 16-byte loads (wrong entries)
+                                o_ &= ~15u;
+                                cc[n][q] = *reinterpret_cast<const i32x4 *>(reinterpret_cast<const char *>((uintptr_t)pc & ~(uintptr_t)15) + o_);
+                                vv[n][q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>((uintptr_t)pv & ~(uintptr_t)15) + o_);
+                            } else {
+                                cc[n][q] = *reinterpret_cast<const i32x4u *>(pc + o_);
+                                vv[n][q] = *reinterpret_cast<const f32x4u *>(pv + o_);
+                            }
+                        }
+                    }
+                };
+                auto apply_set = [&](i32x4 (&cc)[NB][EPG], f32x4 (&vv)[NB][EPG], const BM &bm) {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        int64_t st; int len; float wa;
+                        uni(bm, n, st, len, wa);
+                        if (CM_A3_EXP & 2) {
+#pragma unroll
+                            for (int q = 0; q < EPG; ++q) asm volatile("" ::"v"(cc[n][q]), "v"(vv[n][q]));
+                        } else if (len > 0) {   // (uniform)
+                            int t0 = 0;
+                            if (FAST || safe(st, len)) {   // (uniform)
+                                float *ap_[EPL]; float x_[EPL];
+#pragma unroll
+                                for (int q = 0; q < EPG; ++q)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        int col_ = cc[n][q][e];
+                                        if (CM_A3_EXP & 1) col_ = (int)((unsigned)col_ % (unsigned)n_out);
+                                        ap_[4 * q + e] = acc + (256 * q + 4 * lane + e < len ? col_ : dix + 64 * (4 * q + e));
+                                        x_[4 * q + e] = *ap_[4 * q + e];
+                                    }
+#pragma unroll
+                                for (int q = 0; q < EPG; ++q)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) *ap_[4 * q + e] = __fadd_rn(x_[4 * q + e], __fmul_rn(wa, vv[n][q][e]));
+                                t0 = 256 * EPG;
+                            }
+                            if constexpr (!FAST) {
+                                if (len > t0) {   // (uniform) beyond the registers, or a slice at the very end of the arrays
+                                    for (int t = t0 + lane; t < len; t += 64) {
+                                        float *ap = acc + bcols[st + t];
+                                        *ap = __fadd_rn(*ap, __fmul_rn(wa, bvals[st + t]));
+                                    }
+                                }
+                            }
+                        }
+                    }
+                };
+                if constexpr (CM_A3_NSET == 3) {
+                    BM m0 = pick(0), m1 = pick(NB), m2;
+                    load_set(c0, v0, m0);
+                    load_set(c1, v1, m1);
+                    for (int ub = 0; ub < nn; ub += 3 * NB) {
+                        m2 = pick(ub + 2 * NB);
+                        load_set(c2, v2, m2);
+                        apply_set(c0, v0, m0);
+                        if (ub == 0 && !ticketed) stage2(g);
+                        m0 = pick(ub + 3 * NB);
+                        load_set(c0, v0, m0);
+                        apply_set(c1, v1, m1);
+                        m1 = pick(ub + 4 * NB);
+                        load_set(c1, v1, m1);
+                        apply_set(c2, v2, m2);
+                    }
+                } else {
+                    BM m0 = pick(0), m1;
+                    load_set(c0, v0, m0);
+                    for (int ub = 0; ub < nn; ub += 2 * NB) {
+                        m1 = pick(ub + NB);
+                        load_set(c1, v1, m1);
+                        apply_set(c0, v0, m0);
+                        if (ub == 0 && !ticketed) stage2(g);
+                        m0 = pick(ub + 2 * NB);
+                        load_set(c0, v0, m0);
+                        apply_set(c1, v1, m1);
+                    }
+                }
+            };
+            bool slow_ = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t st = ((int64_t)cur.shi[h] << 32) | (uint32_t)cur.slo[h];
+                slow_ = slow_ || cur.len[h] > 256 * EPG || (cur.len[h] > 0 && !safe(st, cur.len[h]));
+            }
+            if (__ballot(slow_) == 0ull) gather(std::integral_constant<bool, true>{});
+            else gather(std::integral_constant<bool, false>{});
         }
         if (nn == 0 && !ticketed) stage2(g);   // (a row without neighbours: the loop above did not run)
         // neighbours beyond the 128 held in registers (rows of very high degree): one at a time
@@ -1275,89 +1507,53 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             }
         }
         if (!ticketed) stage3(g);
-        // ---- count this wave's slice
-        int wcount = 0;
-        for (int c = wlo; c < whi; c += 64) {
-            const bool nz = (c + lane < whi) && acc[c + lane] != 0.f;
-            wcount += __popcll(__ballot(nz));
-        }
-        if (lane == 0) wsum[parity * 8 + wave] = wcount;
+        // ---- the row in front of this one: its entries have been waiting in registers while this row was gathered
+        // (deferred emission, round 3).  A row's place is the sum of the counts of ALL rows in front of it, and the ~255 rows
+        // right in front are the ones the other workgroups hold: placed at once, a row waited for the slowest of them -- a
+        // barrier across the whole grid per row (a quarter of the kernel's time).  One row later they have all published
+        // their counts.  The stores go out BEFORE the read-out and the count of this row (LDS only), so they have left
+        // the memory pipeline when the next row's first loads are waited for.
+        if (have_prev) place(prev_row, prev_all);
         __syncthreads();
-        if (ticketed) {
-            nxt = tk[0];
-            if (wave != 0) { stage0(g, nxt); stage1(g); }
+        if (ticketed) { nxt = tk[0]; stage0(g, nxt); stage1(g); }
+        if (have_prev) emit(rv, tk[1], prev_before, prev_all);
+        // ---- read the finished slice out into registers, clear it for the next row, count its non-zeros
+        int nch_ = nch;
+        asm volatile("" : "+s"(nch_));   // (the NCH chunk offsets are formed here, not hoisted out of the row loop into NCH registers)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) rv[i] = acc[(i < nch_ ? wlo + 64 * i : zix) + lane];   // (uniform select, no branch)
+        {
+            float4 *a4 = reinterpret_cast<float4 *>(acc + wlo);
+            for (int c = lane; c < W / 4; c += 64) a4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        int wcount = 0;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wcount += __popcll(__ballot(rv[i] != 0.f));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(rv[i]));   // (the emission tests again: 64 masks would not stay in SGPRs)
+        if (lane == 0) wsum[parity * 8 + wave] = wcount;
+        if (ticketed) stage2(g);
+        __syncthreads();
         int before = 0, all = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) { const int s_ = wsum[parity * 8 + w]; all += s_; if (w < wave) before += s_; }
         parity ^= 1;
-        // ---- the row's place in the output
-        if (!ticketed) {
-            if (tid == 0) {
-                const unsigned long long old = atomicAdd(chain + nq + 1, (1ull << 40) | (unsigned long long)all);
-                const long long j = (long long)(old >> 40), o = (long long)(old & ((1ull << 40) - 1ull));
-                out_indptr[j] = o;
-                if (j == nq - 1) out_indptr[nq] = o + all;
-                out_rows[j] = (int32_t)row;
-                tk[1] = o;
-            }
-        } else if (wave == 0) {
-            constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
-            if (lane == 0)
-                __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            long long excl = 0;
-            for (int64_t pos = row - 1; pos >= 0;) {   // 64 predecessors at a time, nearest on lane 0
-                const int64_t i = pos - lane;
-                unsigned long long v, empty, incl;
-                for (;;) {
-                    v = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-                    empty = __ballot((v >> 62) == 0ull);
-                    incl = __ballot((v >> 62) == 2ull);
-                    if (empty == 0ull || (incl != 0ull && __ffsll((long long)incl) < __ffsll((long long)empty))) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                const int fi = incl ? __ffsll((long long)incl) - 1 : 63;
-                long long part = lane <= fi ? (long long)(v & VMASK) : 0ll;
-#pragma unroll
-                for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
-                excl += part;
-                if (incl) break;
-                pos -= 64;
-            }
-            if (lane == 0) {
-                if (row > 0)
-                    __hip_atomic_store(chain + row, (2ull << 62) | (unsigned long long)(excl + all), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                else out_indptr[0] = 0;
-                out_indptr[row + 1] = excl + all;
-                tk[1] = excl;
-            }
-        }
-        if (ticketed && wave == 0) { stage0(g, nxt); stage1(g); }
-        __syncthreads();
-        const int64_t row_out = tk[1];
-        if (ticketed) stage2(g);
-        // ---- emit this wave's slice (ascending columns; consecutive lanes write consecutive entries)
-        if (row_out + all <= capacity) {
-            int64_t o = row_out + before;
-            for (int c = wlo; c < whi; c += 64) {
-                const float v = (c + lane < whi) ? acc[c + lane] : 0.f;
-                const bool nz = v != 0.f;
-                const unsigned long long m = __ballot(nz);
-                if (nz) {
-                    const int64_t q = o + __popcll(m & ((1ull << lane) - 1ull));
-                    ocols[q] = c + lane;
-                    ovals[q] = v;
-                }
-                o += __popcll(m);
-            }
-        }
+        // this row's count is published at once (row 0: it is its own inclusive prefix)
+        if (ticketed && wave == 0 && lane == 0)
+            __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        prev_row = row; prev_all = all; prev_before = before; have_prev = true;
         // ---- next row
         if (ticketed) stage3(g);
         finish(g, cur);
         row = nxt;
         if (!ticketed) { nxt = nxt2; stage0(g, nxt); }
+    }
+    // ---- the last row of this workgroup
+    if (have_prev) {
+        place(prev_row, prev_all);
+        __syncthreads();
+        emit(rv, tk[1], prev_before, prev_all);
     }
 }
 }  // namespace
@@ -1418,8 +1614,7 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     CM_TRY(cm_payload_index_header(h, d_index, &max_slice, &nnz));
     int want = max_slice;
     if (max_slice > 512 && n_ref > 0) want = (int)std::min<long long>(512, (3 * nnz) / (2 * n_ref * nb) + 1);
-    const int epl = want <= 128 ? 2 : (want <= 256 ? 4 : 8);
-    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 2048;
+    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 2048 + 256;
     if (h->n_cu <= 0) {
         hipDeviceProp_t pr;
         CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
@@ -1427,11 +1622,24 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (lds + 1024)));
     const unsigned grid = (unsigned)std::min<int64_t>(nq, (int64_t)h->n_cu * per_cu);
-    auto kern = epl == 2 ? spgemm_sliced<2> : (epl == 4 ? spgemm_sliced<4> : spgemm_sliced<8>);
+    const int nch = W / 64;
+    // slices of more than 64 entries: the 16-byte gather (X4) with 4 or 8 entries per lane; shorter ones (and
+    // CELLMAP_A3_GATHER=1, the A/B switch) keep the entry-per-lane gather
+    const bool x4 = cm_get_knobs().a3_gather == 0 && want > 64;
+    const int epl = x4 ? (want <= 256 ? 4 : 8) : (want <= 128 ? 2 : (want <= 256 ? 4 : 8));
+    auto pick_nch = [&](auto e, auto x) {
+        constexpr int E = decltype(e)::value;
+        constexpr bool X = decltype(x)::value;
+        return nch <= 16 ? spgemm_sliced<E, 16, X> : (nch <= 32 ? spgemm_sliced<E, 32, X> : spgemm_sliced<E, 64, X>);
+    };
+    typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
+    auto kern = x4 ? (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, T_{}) : pick_nch(std::integral_constant<int, 8>{}, T_{}))
+                   : (epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, F_{})
+                               : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, F_{}) : pick_nch(std::integral_constant<int, 8>{}, F_{})));
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, d_index, nb + 1,
-                       (int)n_out, W, d_out_indptr, d_out_cols, d_out_vals, d_order, d_chain, capacity, d_out_rows);
+                       (int)n_out, W, d_out_indptr, d_out_cols, d_out_vals, d_order, d_chain, capacity, d_out_rows, (int64_t)nnz);
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
