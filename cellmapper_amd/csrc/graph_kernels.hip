@@ -18,6 +18,9 @@
 #define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 1 aligned 16-byte loads, 2 no
                        // accumulator updates (loads kept), 4 no payload loads, 8 no output stores, 16 no wait for the rows in front
 #endif
+#ifndef CM_A3_LBW
+#define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
+#endif
 #ifndef CM_A3_NSET
 #define CM_A3_NSET 2   // register sets of the 16-byte gather (3 = two batches in flight behind the one being applied: measured no faster, 32 registers more)
 #endif
@@ -1112,11 +1115,11 @@ __global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb
 // counted and emitted from the registers: the count and the emission used to be two loops of read -> wait -> ballot
 // with one LDS round trip per 64 columns each (round 3: ~2 x 59 x 130 cycles per row at 30 000 genes).
 // X4 (round 3): a lane holds FOUR CONSECUTIVE entries of a slice per 16-byte load (entries 256 g + 4 lane ..) instead of
-// EPL entries 64 apart -- a 113-entry slice of config 5 is 2 loads per neighbour instead of 8, so the 63 loads a wave may
-// have in flight carry four times the bytes -- and THREE register sets rotate (two batches in flight behind the one being
-// applied): the gather is bound by latency x bytes in flight, not by bandwidth.  EPL = 4 or 8 entries per lane (1 or 2
-// groups).  A 16-byte load may run up to three entries past the end of its slice (never used): a slice that ends within
-// three entries of the END OF THE ARRAY (b_nnz) takes the entry-per-lane loop instead.
+// EPL entries 64 apart: a 113-entry slice of config 5 is 2 loads per neighbour instead of 8.  Measured equal to the
+// entry-per-lane gather (and to three rotating register sets instead of two: CM_A3_NSET): the gather is not bound by
+// the bytes in flight but by the read -> add -> write round trip through LDS per neighbour (profiles/r03_a3_ablation.md).
+// EPL = 4 or 8 entries per lane (1 or 2 groups).  A 16-byte load may run up to three entries past the end of its slice
+// (never used): a slice that ends within three entries of the END OF THE ARRAY (b_nnz) takes the entry-per-lane loop.
 template <int EPL, int NCH, bool X4>
 __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
@@ -1207,26 +1210,29 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     int prev_all = 0, prev_before = 0;
     bool have_prev = false;
     // wave 0: the sum of the counts of all rows in front of row r -- published counts back to the nearest published
-    // inclusive prefix, 256 rows per step (four loads per lane in flight; the nearest inclusive prefix is a few hundred
-    // rows back: every workgroup places a row one row after counting it)
+    // inclusive prefix, 64 x CM_A3_LBW rows per step (that many loads per lane in flight; the nearest inclusive prefix is
+    // a few hundred rows back: every workgroup places a row one row after counting it)
+    // (Reading the first window early -- from inside the gather loop of the next row -- was measured: +10 %, the loads
+    // in the loop make the compiler's load counting of the gather conservative.)
     auto lookback = [&](int64_t r) -> long long {
         constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
+        constexpr int LBW = CM_A3_LBW;   // loads per lane and step
         long long excl = 0;
-        for (int64_t pos = (CM_A3_EXP & 16) ? -1 : r - 1; pos >= 0; pos -= 256) {
-            unsigned long long v[4];
-            int ustar = 4, fi = 63;
+        for (int64_t pos = (CM_A3_EXP & 16) ? -1 : r - 1; pos >= 0; pos -= 64 * LBW) {
+            unsigned long long v[LBW];
+            int ustar = LBW, fi = 63;
             for (;;) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < LBW; ++u) {
                     const int64_t i = pos - 64 * u - lane;
                     v[u] = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
                 }
                 bool retry = false;
-                ustar = 4;
+                ustar = LBW;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < LBW; ++u) {
                     const unsigned long long empty = __ballot((v[u] >> 62) == 0ull), incl = __ballot((v[u] >> 62) == 2ull);
-                    if (ustar == 4 && !retry) {
+                    if (ustar == LBW && !retry) {
                         if (incl != 0ull && (empty == 0ull || __ffsll((long long)incl) < __ffsll((long long)empty))) {
                             ustar = u; fi = __ffsll((long long)incl) - 1;
                         } else if (empty != 0ull) retry = true;
@@ -1237,12 +1243,12 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             }
             long long part = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < LBW; ++u)
                 if (u < ustar || (u == ustar && lane <= fi)) part += (long long)(v[u] & VMASK);
 #pragma unroll
             for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
             excl += part;
-            if (ustar < 4) break;
+            if (ustar < LBW) break;
         }
         return excl;
     };
@@ -1344,6 +1350,8 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                 uni(bm, n, st, len, wa);
                 if (len > 0) {   // (uniform)
                     // the entries of one neighbour row have distinct columns: all reads go out before the writes
+                    // (skipping, under a uniform branch, the entry sets that lie wholly beyond a slice was measured: 131 ->
+                    // 158 ms per million rows -- a branch around LDS operations makes the compiler's wait counting conservative)
                     float *ap_[EPL]; float x_[EPL];
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
