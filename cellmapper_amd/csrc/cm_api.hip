@@ -124,7 +124,7 @@ cm_status sync(cm_handle_t h) {
 }
 cm_status check_fallback_overflow(cm_handle_t h) {
     h->knn_stats[0] = h->d_nflag_pinned[0];
-    if (h->d_nflag_pinned[1]) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN exact fallback overflow: more than 4096 reference rows tie within a query's k-th distance");
+    if (h->d_nflag_pinned[1]) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN exact fallback overflow: more than 16384 queries each have more than 4096 reference rows tied within their k-th distance");
     return CM_OK;
 }
 

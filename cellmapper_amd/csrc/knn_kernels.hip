@@ -46,7 +46,8 @@ constexpr int RR_DMAX = 260;   // LDS stride (doubles) of a staged query row for
 constexpr int KNN_DMAX = 2047;  // widest embedding (round 3: the K-chunked f32 filter, knn_cand_mfma_wide)
 __host__ __device__ constexpr int q_stride(int d) { return d < RR_DMAX ? RR_DMAX : ((d + 4) & ~3); }
 constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
-constexpr int FB_CAP = 4096;    // fallback collection capacity per query
+constexpr int FB_CAP = 4096;    // fallback collection capacity per query (a query with more rows inside its bound goes to knn_fallback_select)
+constexpr int OVF_CAP = 16384;  // queries the selection kernel takes per call (more: the call fails loudly)
 constexpr int FB_BLOCKS = 1024;
 constexpr int FBS_SLICES = 512;  // sliced fallback: reference slices scanned in parallel per flagged query ...
 constexpr int FBS_NQ = 1024;     // ... for the first FBS_NQ flagged queries (the rest: one workgroup per query)
@@ -596,6 +597,15 @@ static inline size_t rerank_lds_bytes(int S, int Kc, int d = 0) {
     return sizeof(double) * 4 * q_stride(d) + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
 }
 
+// a query whose collection overflowed FB_CAP: handed to knn_fallback_select (ovf = words + 3: ovf[0] = flag "list
+// full", ovf[OVF_SLOT] = words[20] = count; words[4..] up to the scales belong to the row preparation)
+constexpr int OVF_SLOT = 17;
+__device__ __forceinline__ void push_overflow(int *ovf, int *ovf_list, int64_t i) {
+    const int pos = atomicAdd(ovf + OVF_SLOT, 1);
+    if (pos < OVF_CAP) ovf_list[pos] = (int)i;
+    else atomicExch(ovf, 1);
+}
+
 // ------------------------------------------------------------------ exact fallback ------------------
 // For queries that could not be certified: one workgroup scans ALL reference rows in float64 (same arithmetic as
 // phase 2), collects every row whose value is <= the k-th candidate value (an upper bound of the true k-th),
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
                                                            const int *__restrict__ flag_cnt,
                                                            const double *__restrict__ bound, void *__restrict__ out_dist,
                                                            int64_t *__restrict__ out_idx, int *__restrict__ overflow,
-                                                           int f_start) {
+                                                           int *__restrict__ ovf_list, int f_start) {
     extern __shared__ __align__(16) unsigned char fb_smem[];
     double *s_q = reinterpret_cast<double *>(fb_smem);   // [q_stride(d)] (dynamic: wide rows)
     __shared__ double s_v[FB_CAP];
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
         }
         __syncthreads();
         int m = s_n;
-        if (m > FB_CAP) { m = FB_CAP; if (threadIdx.x == 0) atomicExch(overflow, 1); }
+        if (m > FB_CAP) { if (threadIdx.x == 0) push_overflow(overflow, ovf_list, i); continue; }   // (uniform)
         for (int s = threadIdx.x; s < m; s += blockDim.x) {
             double v = s_v[s];
             int id = s_i[s];
@@ -717,7 +727,8 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
                                                          const int *__restrict__ flag_list, const int *__restrict__ flag_cnt,
                                                          const int *__restrict__ gcount, const double *__restrict__ gv,
                                                          const int *__restrict__ gi, void *__restrict__ out_dist,
-                                                         int64_t *__restrict__ out_idx, int *__restrict__ overflow) {
+                                                         int64_t *__restrict__ out_idx, int *__restrict__ overflow,
+                                                         int *__restrict__ ovf_list) {
     __shared__ double s_v[FB_CAP];
     __shared__ int s_i[FB_CAP];
     int nf = *flag_cnt;
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
     for (int f = blockIdx.x; f < nf; f += gridDim.x) {
         const int64_t i = flag_list[f];
         int m = gcount[f];
-        if (m > FB_CAP) { m = FB_CAP; if (threadIdx.x == 0) atomicExch(overflow, 1); }
+        if (m > FB_CAP) { if (threadIdx.x == 0) push_overflow(overflow, ovf_list, i); continue; }   // (uniform)
         __syncthreads();
         for (int s = threadIdx.x; s < m; s += blockDim.x) { s_v[s] = gv[(size_t)f * FB_CAP + s]; s_i[s] = gi[(size_t)f * FB_CAP + s]; }
         __syncthreads();
@@ -741,6 +752,63 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
                 else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
                 out_idx[i * k + rk] = (int64_t)id + idx_offset;
             }
+        }
+    }
+}
+
+// More than FB_CAP reference rows inside a query's bound (thousands of rows tied with its k-th neighbour: duplicated
+// cells): no collection at all -- k passes over the reference, pass r keeps the smallest (value, index) pair that comes
+// after the pair of pass r - 1.  Same arithmetic (pair_value) and the same order as everywhere else; k x n_ref x d
+// operations per query, for the handful of queries that get here.  One workgroup per query.
+template <typename T>
+__global__ __launch_bounds__(256) void knn_fallback_select(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry, int d,
+                                                           int k, int metric, int form, int64_t idx_offset, int flags,
+                                                           const int *__restrict__ ovf, const int *__restrict__ ovf_list,
+                                                           void *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
+    extern __shared__ __align__(16) unsigned char fsel_smem[];
+    double *s_q = reinterpret_cast<double *>(fsel_smem);   // [q_stride(d)]
+    __shared__ double s_rv[4];
+    __shared__ long long s_ri[4];
+    int n = ovf[OVF_SLOT];
+    if (n > OVF_CAP) n = OVF_CAP;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int f = blockIdx.x; f < n; f += gridDim.x) {
+        const int64_t i = ovf_list[f];
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+        __syncthreads();
+        double xn = 0.0;
+        for (int c = 0; c < d; ++c) xn = fma(s_q[c], s_q[c], xn);
+        double pv = 0.0;
+        long long pj = -1;
+        for (int rk = 0; rk < k; ++rk) {
+            double bv = INFINITY;
+            long long bj = 0x7fffffffffffffffLL;
+            for (int64_t j = threadIdx.x; j < n_ref; j += blockDim.x) {
+                const double v = pair_value<T>(s_q, xn, ref + j * d, d, metric, form);
+                if ((rk == 0 || pair_before(pv, pj, v, j)) && pair_before(v, j, bv, bj)) { bv = v; bj = j; }
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const double ov = __shfl_xor(bv, sft);
+                const long long oj = __shfl_xor(bj, sft);
+                if (pair_before(ov, oj, bv, bj)) { bv = ov; bj = oj; }
+            }
+            __syncthreads();   // (the previous pass's minima have been read)
+            if (lane == 0) { s_rv[w] = bv; s_ri[w] = bj; }
+            __syncthreads();
+            bv = s_rv[0]; bj = s_ri[0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+                if (pair_before(s_rv[u], s_ri[u], bv, bj)) { bv = s_rv[u]; bj = s_ri[u]; }
+            if (threadIdx.x == 0) {
+                double o = bv;
+                if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(bv);
+                if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[i * k + rk] = (T)o;
+                else reinterpret_cast<double *>(out_dist)[i * k + rk] = o;
+                out_idx[i * k + rk] = (int64_t)bj + idx_offset;
+            }
+            pv = bv; pj = bj;
         }
     }
 }
@@ -1521,6 +1589,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
+    int *ovf_list = (int *)cm_ws_alloc(h, sizeof(int) * OVF_CAP);   // queries with more than FB_CAP rows inside their bound
     // any tile image: <= 256 B per row (K <= 64) / 512 B per row + side block (K = 128)
     const bool big_rows = wide || dl > 64;   // 512 B per prepared row: K = 128 images, direct rows of more than 64 floats
     char *Rp = (char *)cm_ws_alloc(h, (size_t)pf.n_tiles * (big_rows ? (size_t)cmk2::wide_tile_bytes() : (size_t)cmk2::tile_bytes(4)));
@@ -1530,7 +1599,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     uint2 *lbuf = (uint2 *)cm_ws_alloc(h, sizeof(uint2) * (size_t)320 * cmk2::NW * 128 * 2 * cmk2::CL);
     double *cpart = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_BLOCKS * CMEAN_COLS);
     double *d_mean = (double *)cm_ws_alloc(h, sizeof(double) * CMEAN_COLS);
-    if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp ||
+    if (!qnorm || !qlo || !cand || !cthr || !flag_a || !flag_b || !sample || !bound || !words || !fb_count || !fb_v || !fb_i || !ovf_list || !Rp ||
         !Qp || !kept || !lbuf || !cpart || !d_mean || !seedb || !seed_sub)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     if (pf.grid > 320) CM_FAIL(h, CM_E_INTERNAL, "k-NN: unexpected resident workgroup count %d", pf.grid);
@@ -2141,10 +2210,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     }
     hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_out,
                        (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
-                       d_out_idx, (int *)(words + 3));
+                       d_out_idx, (int *)(words + 3), ovf_list);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_out, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
-                       (int *)(words + 3), FBS_NQ);
+                       (int *)(words + 3), ovf_list, FBS_NQ);
+    // queries with more than FB_CAP rows inside their bound (words[20] counts them; empty launch otherwise)
+    hipLaunchKernelGGL(knn_fallback_select<T>, dim3(256), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
+                       idx_offset, flags, (const int *)(words + 3), (const int *)ovf_list, d_out_dist, d_out_idx);
     CM_HIP(h, hipGetLastError());
     cm_mark(h, 4);
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2176,9 +2248,10 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     int *fb_count = (int *)cm_ws_alloc(h, sizeof(int) * FBS_NQ);                       // sliced exact fallback: candidate lists
     double *fb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)FBS_NQ * FB_CAP);
     int *fb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)FBS_NQ * FB_CAP);
+    int *ovf_list = (int *)cm_ws_alloc(h, sizeof(int) * OVF_CAP);
     float *Rp = (float *)cm_ws_alloc(h, sizeof(float) * p.nref_pad * p.KP);
     float *Qp = (float *)cm_ws_alloc(h, sizeof(float) * p.nq_pad * p.KP);
-    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words || !fb_count || !fb_v || !fb_i || !Rp || !Qp)
+    if (!qnorm || !cand || !cthr || !flag_list || !bound || !words || !fb_count || !fb_v || !fb_i || !ovf_list || !Rp || !Qp)
         CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
@@ -2218,10 +2291,13 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     }
     hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_list,
                        (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
-                       d_out_idx, (int *)(words + 3));
+                       d_out_idx, (int *)(words + 3), ovf_list);
     hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
-                       (int *)(words + 3), FBS_NQ);
+                       (int *)(words + 3), ovf_list, FBS_NQ);
+    // queries with more than FB_CAP rows inside their bound (words[20] counts them; empty launch otherwise)
+    hipLaunchKernelGGL(knn_fallback_select<T>, dim3(256), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
+                       idx_offset, flags, (const int *)(words + 3), (const int *)ovf_list, d_out_dist, d_out_idx);
     CM_HIP(h, hipGetLastError());
     cm_mark(h, 4);
     // stats mirror (read back lazily by cm_knn_stats after a synchronize)
@@ -2239,7 +2315,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
     size_t b = 512 * 1024 + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
-               cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + 1024;
+               cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + cm_align(4 * OVF_CAP) + 1024;
     // (d <= 128 always takes the staged sizing: the manhattan / chebyshev metrics run the staged search whatever k is, and
     //  this function does not see the metric)
     if (use_f16_path(d, k) || d <= 128) {

@@ -119,9 +119,10 @@ cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
  * out[1] = candidate-list size K', out[2] = reference splits + 100 * (filter level the full set started at),
  * out[3] = filter family (1 f32-input MFMA, 2 split-fp16 MFMA K <= 64, 3 direct VALU / grid, 4 split-fp16 MFMA K = 128)
  *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning),
- * out[4] = 1 if the exact fallback overflowed (more than 4096 rows within a query's bound: that query's list is
- *          truncated; cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that
- *          synchronise the stream themselves must check it), out[5..7] reserved (0).  Read after the stream is idle. */
+ * out[4] = 1 if the exact fallback overflowed (more than 16 384 queries of one call each had more than 4 096 rows
+ *          within their bound -- up to that many take a selection pass and are exact; beyond it lists are truncated:
+ *          cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that synchronise the
+ *          stream themselves must check it), out[5..7] reserved (0).  Read after the stream is idle. */
 cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
 
 /* ---------------------------------------------------------------- K0: exact k-NN ------------------

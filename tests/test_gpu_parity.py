@@ -200,7 +200,8 @@ def test_knn_forced_fallback_and_duplicates(hip, oracle):
 def test_mass_duplicates_within_the_kth_distance(hip, oracle):
     """3 000 identical reference rows: every query that sits on them has 3 000 rows tied at its k-th distance -- beyond every
     candidate list, so the exact fallback collects them all (capacity 4 096 per query) and the lowest indices win, like the
-    oracle's (value, index) order.  5 000 of them overflow the collection: an error, never a truncated answer."""
+    oracle's (value, index) order.  5 000 of them overflow the collection: those queries take the selection kernel (k
+    passes over the reference, no collection at all) -- the reference (sklearn) accepts such inputs, so must this."""
     rng = np.random.default_rng(99)
     d, k = 24, 10
     ref = rng.standard_normal((20000, d)).astype(np.float32)
@@ -215,8 +216,19 @@ def test_mass_duplicates_within_the_kth_distance(hip, oracle):
     dup2 = rng.choice(20000, 5000, replace=False)
     ref[dup2] = ref[dup2[0]]
     qry[:5] = ref[dup2[0]]
-    with pytest.raises(NotImplementedError, match="overflow"):
-        hip.knn(ref, qry, k)
+    qry[200] = ref[dup2[0]] + np.float32(1e-3)   # just off the pile: 5 000 rows tied at its FIRST distance
+    dist, idx = hip.knn(ref, qry, k)
+    od, oi = oracle.knn_euclidean(ref, qry, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert np.array_equal(idx[0], np.sort(dup2)[:k]) and np.all(dist[:5] == 0)
+    # the same through the forced exact scan (sliced scan + rank kernels for the first 1 024 queries, then one workgroup each)
+    import torch
+    from cellmapper_amd.device import DevicePipeline
+    pipe = DevicePipeline(0)
+    with torch.cuda.stream(pipe.stream):
+        dd, di = pipe.knn(torch.from_numpy(ref).cuda(), torch.from_numpy(np.tile(qry, (5, 1))).cuda(), k, force_fallback=True)
+        torch.cuda.synchronize()
+    assert np.array_equal(dd.cpu().numpy(), np.tile(od, (5, 1))) and np.array_equal(di.cpu().numpy(), np.tile(oi, (5, 1)))
 
 
 def test_exact_fallback_sliced_and_per_query_paths(oracle):
