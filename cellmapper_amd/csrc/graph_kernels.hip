@@ -1417,21 +1417,26 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             apply_batch(cb, vb, mb);
         }
         } else {
-            constexpr int EPG = EPL / 4, NB = 4 / EPG;   // groups of 4 entries per lane, neighbours per register set
-            typedef int i32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            // (uniform) the 16-byte loads of this slice stay inside the payload arrays
-            auto safe = [&](int64_t st, int len) { const int r = (len + 3) & ~3; return st + (r < 4 ? 4 : r) <= b_nnz; };
+            // EPL = 2, 3, 4 or 8 entries per lane: one group of 2 / 3 / 4 CONSECUTIVE entries (one 8- / 12- / 16-byte load
+            // per array) or two groups of 4.  The LDS updates are what the gather costs (bank conflicts of ~random columns),
+            // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
+            // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
+            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = 4 / EPG;   // groups per lane, entries per group, neighbours per set
+            static_assert(GE * EPG == EPL && GE >= 2 && GE <= 4, "entries per lane: 2, 3, 4 or 8");
+            typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
+            typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
+            typedef int iv_t __attribute__((ext_vector_type(GE)));
+            typedef float fv_t __attribute__((ext_vector_type(GE)));
+            // (uniform) the vector loads of this slice stay inside the payload arrays
+            auto safe = [&](int64_t st, int len) { const int r = (len + GE - 1) / GE * GE; return st + (r < GE ? GE : r) <= b_nnz; };
             // FAST: every slice of this row and wave fits the registers and none touches the end of the arrays -- the loop
             // then holds no load besides the register sets' (a conditional entry-per-lane loop between two neighbours makes
             // the compiler's load counting conservative: it waited for part of the NEXT set before every neighbour)
             auto gather = [&](auto fast_) {
                 constexpr bool FAST = decltype(fast_)::value;
-                i32x4 c0[NB][EPG], c1[NB][EPG], c2[NB][EPG];
-                f32x4 v0[NB][EPG], v1[NB][EPG], v2[NB][EPG];
-                auto load_set = [&](i32x4 (&cc)[NB][EPG], f32x4 (&vv)[NB][EPG], const BM &bm) {
+                iv_t c0[NB][EPG], c1[NB][EPG], c2[NB][EPG];
+                fv_t v0[NB][EPG], v1[NB][EPG], v2[NB][EPG];
+                auto load_set = [&](iv_t (&cc)[NB][EPG], fv_t (&vv)[NB][EPG], const BM &bm) {
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         int64_t st; int len; float wa;
@@ -1442,24 +1447,14 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                         const int lim = has ? len : 0;
 #pragma unroll
                         for (int q = 0; q < EPG; ++q) {
-                            const int f = 256 * q + 4 * lane;
-                            unsigned o_ = f < lim ? (unsigned)f << 2 : 0u;
-                            if (CM_A3_EXP & 4) {
-                                cc[n][q] = i32x4{4 * lane, 4 * lane + 1, 4 * lane + 2, 4 * lane + 3} + (int)((st * 7) & 1023);
-                                vv[n][q] = f32x4{1.f, 2.f, 3.f, 4.f};
-                                asm volatile("" : "+v"(cc[n][q]), "+v"(vv[n][q]));
-                            } else if (CM_A3_EXP & 1) {   // timing experiment: aligned 16-byte loads (wrong entries)
-                                o_ &= ~15u;
-                                cc[n][q] = *reinterpret_cast<const i32x4 *>(reinterpret_cast<const char *>((uintptr_t)pc & ~(uintptr_t)15) + o_);
-                                vv[n][q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>((uintptr_t)pv & ~(uintptr_t)15) + o_);
-                            } else {
-                                cc[n][q] = *reinterpret_cast<const i32x4u *>(pc + o_);
-                                vv[n][q] = *reinterpret_cast<const f32x4u *>(pv + o_);
-                            }
+                            const int f = 64 * GE * q + GE * lane;
+                            const unsigned o_ = f < lim ? (unsigned)f << 2 : 0u;
+                            cc[n][q] = *reinterpret_cast<const ivu_t *>(pc + o_);
+                            vv[n][q] = *reinterpret_cast<const fvu_t *>(pv + o_);
                         }
                     }
                 };
-                auto apply_set = [&](i32x4 (&cc)[NB][EPG], f32x4 (&vv)[NB][EPG], const BM &bm) {
+                auto apply_set = [&](iv_t (&cc)[NB][EPG], fv_t (&vv)[NB][EPG], const BM &bm) {
 #pragma unroll
                     for (int n = 0; n < NB; ++n) {
                         int64_t st; int len; float wa;
@@ -1467,24 +1462,24 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                         if (CM_A3_EXP & 2) {
 #pragma unroll
                             for (int q = 0; q < EPG; ++q) asm volatile("" ::"v"(cc[n][q]), "v"(vv[n][q]));
-                        } else if (len > 0) {   // (uniform)
+                        } else if (FAST || len > 0) {   // (uniform; FAST: no branch at all -- a neighbour slot without entries works on the
+                                                        //  lanes' private slots only, and the updates of consecutive neighbours are one
+                                                        //  straight stretch the compiler can schedule: 132 -> 129 ms per million rows)
                             int t0 = 0;
                             if (FAST || safe(st, len)) {   // (uniform)
                                 float *ap_[EPL]; float x_[EPL];
 #pragma unroll
                                 for (int q = 0; q < EPG; ++q)
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        int col_ = cc[n][q][e];
-                                        if (CM_A3_EXP & 1) col_ = (int)((unsigned)col_ % (unsigned)n_out);
-                                        ap_[4 * q + e] = acc + (256 * q + 4 * lane + e < len ? col_ : dix + 64 * (4 * q + e));
-                                        x_[4 * q + e] = *ap_[4 * q + e];
+                                    for (int e = 0; e < GE; ++e) {
+                                        ap_[GE * q + e] = acc + (64 * GE * q + GE * lane + e < len ? cc[n][q][e] : dix + 64 * (GE * q + e));
+                                        x_[GE * q + e] = *ap_[GE * q + e];
                                     }
 #pragma unroll
                                 for (int q = 0; q < EPG; ++q)
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) *ap_[4 * q + e] = __fadd_rn(x_[4 * q + e], __fmul_rn(wa, vv[n][q][e]));
-                                t0 = 256 * EPG;
+                                    for (int e = 0; e < GE; ++e) *ap_[GE * q + e] = __fadd_rn(x_[GE * q + e], __fmul_rn(wa, vv[n][q][e]));
+                                t0 = 64 * EPL;
                             }
                             if constexpr (!FAST) {
                                 if (len > t0) {   // (uniform) beyond the registers, or a slice at the very end of the arrays
@@ -1533,7 +1528,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int64_t st = ((int64_t)cur.shi[h] << 32) | (uint32_t)cur.slo[h];
-                slow_ = slow_ || cur.len[h] > 256 * EPG || (cur.len[h] > 0 && !safe(st, cur.len[h]));
+                slow_ = slow_ || cur.len[h] > 64 * EPL || (cur.len[h] > 0 && !safe(st, cur.len[h]));
             }
             if (__ballot(slow_) == 0ull) gather(std::integral_constant<bool, true>{});
             else gather(std::integral_constant<bool, false>{});
@@ -1671,14 +1666,16 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     // slices of more than 64 entries: the 16-byte gather (X4) with 4 or 8 entries per lane; shorter ones (and
     // CELLMAP_A3_GATHER=1, the A/B switch) keep the entry-per-lane gather
     const bool x4 = cm_get_knobs().a3_gather == 0 && want > 64;
-    const int epl = x4 ? (want <= 256 ? 4 : 8) : (want <= 128 ? 2 : (want <= 256 ? 4 : 8));
+    const int epl = x4 ? (want <= 128 ? 2 : (want <= 192 ? 3 : (want <= 256 ? 4 : 8))) : (want <= 128 ? 2 : (want <= 256 ? 4 : 8));
     auto pick_nch = [&](auto e, auto x) {
         constexpr int E = decltype(e)::value;
         constexpr bool X = decltype(x)::value;
         return nch <= 16 ? spgemm_sliced<E, 16, X> : (nch <= 32 ? spgemm_sliced<E, 32, X> : spgemm_sliced<E, 64, X>);
     };
     typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
-    auto kern = x4 ? (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, T_{}) : pick_nch(std::integral_constant<int, 8>{}, T_{}))
+    auto kern = x4 ? (epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, T_{})
+                               : (epl == 3 ? pick_nch(std::integral_constant<int, 3>{}, T_{})
+                                           : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, T_{}) : pick_nch(std::integral_constant<int, 8>{}, T_{}))))
                    : (epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, F_{})
                                : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, F_{}) : pick_nch(std::integral_constant<int, 8>{}, F_{})));
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
