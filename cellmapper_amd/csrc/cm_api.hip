@@ -335,7 +335,7 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]) {
 cm_status cm_knn_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
                      void *d_out_dist, int64_t *d_out_idx) {
-    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype)));
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype, metric)));
     return cm_knn_run(h, d_ref, n_ref, d_qry, nq, d, dtype, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
 }
 
@@ -466,7 +466,7 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
                             double *d_out_dist, int64_t *d_out_idx) {
     size_t nk = (size_t)nq * k;
     size_t extra = cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024;
-    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype) + extra));
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, nq, d, k, dtype, metric) + extra));
     double *dist = d_out_dist ? d_out_dist : (double *)cm_ws_alloc(h, 8 * nk);
     int64_t *idx = d_out_idx ? d_out_idx : (int64_t *)cm_ws_alloc(h, 8 * nk);
     int32_t *cols = (int32_t *)cm_ws_alloc(h, 4 * nk);
@@ -512,7 +512,7 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     const size_t des = (metric == CM_METRIC_COSINE) ? es : 8;  // element size of the returned distances
     const int64_t QCH = 1 << 21;
     const int64_t chunk = std::min<int64_t>(nq, QCH);
-    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, chunk, d, k, dtype)));
+    CM_TRY(begin_call(h, cm_knn_ws_bytes(n_ref, chunk, d, k, dtype, metric)));
     DevBuf dref, dq, dd, di;
     CM_TRY(dref.alloc(h, es * n_ref * d));
     CM_TRY(dq.alloc(h, es * chunk * d));
@@ -1062,7 +1062,7 @@ static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const DevBuf &ref
     int64_t nflag = 0;
     for (int64_t q0 = 0; q0 < qry->n; q0 += QCH) {
         const int64_t nqc = std::min<int64_t>(QCH, qry->n - q0);
-        CM_TRY(begin_call(hp, cm_knn_ws_bytes(n_rows, nqc, ref->d, k, ref->dtype)));
+        CM_TRY(begin_call(hp, cm_knn_ws_bytes(n_rows, nqc, ref->d, k, ref->dtype, metric)));
         CM_TRY(cm_knn_run(hp, (const char *)refbuf.p + es * r_lo * ref->d, n_rows, (const char *)qbuf.p + es * q0 * ref->d, nqc, ref->d,
                           ref->dtype, k, metric, form, r_lo, flags, (char *)d_dist + des * q0 * k, d_idx + q0 * k));
         CM_TRY(sync(hp));

@@ -2310,7 +2310,10 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
 
 }  // namespace
 
-size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t /*dtype*/) {
+size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric) {
+    if (metric == CM_METRIC_CORRELATION)   // float64 centred copies of both sides, then the cosine search over them
+        return cm_knn_ws_bytes(n_ref, nq, d, k, CM_F64, CM_METRIC_COSINE) + cm_align(8 * (size_t)n_ref * d) + cm_align(8 * (size_t)nq * d) + 4096;
+    (void)dtype;
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
@@ -2357,6 +2360,20 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     return b + (b >> 6) + (8u << 20);   // (+1.5 % and 8 MB: alignment of the many small allocations of the staged search)
 }
 
+// "correlation" (scipy.spatial.distance.cdist through sklearn's brute force): x - mean(x) per row, in float64.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void center_rows(const T *__restrict__ x, int64_t n, int d, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = lane; c < d; c += 64) s += (double)x[i * d + c];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+    const double m = s / (double)d;
+    for (int c = lane; c < d; c += 64) out[i * d + c] = (double)x[i * d + c] - m;
+}
+
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
                      void *d_out_dist, int64_t *d_out_idx) {
@@ -2365,6 +2382,20 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
     if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
     if (d > KNN_DMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, KNN_DMAX);
+    if (metric == CM_METRIC_CORRELATION) {   // cosine over float64 centred copies (cellmap.h); float64 distances out
+        if (dtype != CM_F32 && dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "k-NN: unknown dtype id %d", dtype);
+        double *rc = (double *)cm_ws_alloc(h, 8 * (size_t)n_ref * d), *qc = (double *)cm_ws_alloc(h, 8 * (size_t)(nq > 0 ? nq : 1) * d);
+        if (!rc || !qc) CM_FAIL(h, CM_E_NOMEM, "k-NN (correlation): device workspace exhausted");
+        if (dtype == CM_F32) {
+            hipLaunchKernelGGL(center_rows<float>, dim3((unsigned)((n_ref + 3) / 4)), dim3(256), 0, h->stream, (const float *)d_ref, n_ref, d, rc);
+            if (nq > 0) hipLaunchKernelGGL(center_rows<float>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, (const float *)d_qry, nq, d, qc);
+        } else {
+            hipLaunchKernelGGL(center_rows<double>, dim3((unsigned)((n_ref + 3) / 4)), dim3(256), 0, h->stream, (const double *)d_ref, n_ref, d, rc);
+            if (nq > 0) hipLaunchKernelGGL(center_rows<double>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, h->stream, (const double *)d_qry, nq, d, qc);
+        }
+        CM_HIP(h, hipGetLastError());
+        return knn_run_t<double>(h, rc, n_ref, qc, nq, d, k, CM_METRIC_COSINE, form, idx_offset, flags | CM_KNN_F64_OUT, d_out_dist, d_out_idx);
+    }
     if (metric == CM_METRIC_SQEUCLIDEAN) {   // sklearn: brute force only, squared distances out (knn.py:429 hands the name through)
         metric = CM_METRIC_EUCLIDEAN;
         form = CM_FORM_GEMM;

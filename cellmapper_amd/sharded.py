@@ -187,7 +187,7 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int, exchange: 
     return mine
 
 
-SUPPORTED_METRICS = ("euclidean", "sqeuclidean", "cosine", "manhattan", "chebyshev")
+SUPPORTED_METRICS = ("euclidean", "sqeuclidean", "cosine", "correlation", "manhattan", "chebyshev")
 
 
 class ExchangeState:

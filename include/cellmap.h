@@ -59,6 +59,13 @@ typedef enum {
 /* sklearn's "sqeuclidean": always brute force (no tree supports it), EuclideanArgKmin with squared=True -- the euclidean GEMM-form
  * search whose float64 ranking values are returned WITHOUT the final square root, whatever d is. */
 #define CM_METRIC_SQEUCLIDEAN 4
+/* sklearn hands "correlation" to scipy.spatial.distance.cdist (brute force): rows centred in float64 (x - mean(x)), then the
+ * cosine distance of the centred rows, float64 out whatever the input type.  Searched as the COSINE metric over float64
+ * centred copies of both sides (workspace: 8 (n_ref + nq) d bytes more).  Not a bit-for-bit restatement: scipy's C loop
+ * and numpy's pairwise mean round differently in the last bits (distances agree to ~1e-15; neighbours equal except inside
+ * ties at that level) -- tests/parity.py states the tolerance.  A constant row has no correlation distance (scipy: nan);
+ * here it behaves like a zero row under cosine (distance 1 to everything). */
+#define CM_METRIC_CORRELATION 5
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt

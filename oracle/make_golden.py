@@ -270,6 +270,10 @@ def main():
             "synth_f32_sqeuclidean_k15": (xr, yr, 15, "sqeuclidean", "X_emb"),
             "synth_d10_sqeuclidean_k15": (xr10, yr10, 15, "sqeuclidean", "X_emb"),
             "spatial32_self_sqeuclidean_k20": (coords, coords, 20, "sqeuclidean", "spatial"),
+            # round 3: correlation (scipy.spatial.distance.cdist through sklearn's brute force; float64 distances out)
+            "synth_f32_correlation_k15": (xr, yr, 15, "correlation", "X_emb"),
+            "synth_f64_correlation_k30": (xr64, yr64, 30, "correlation", "X_emb"),
+            "synth_d10_correlation_k15": (xr10, yr10, 15, "correlation", "X_emb"),
         }
         only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. `--only metrics sqeuclidean`: just the cases of one metric
         for name, (a_, b_, k_, m_, key_) in cases.items():

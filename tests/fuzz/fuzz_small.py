@@ -18,7 +18,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean"]))
+        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean", "correlation"]))
         d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259, 260, 300, 512, 777, 1024, 2047]))
         if metric in ("manhattan", "chebyshev") and d > 128:
             d = 128
@@ -43,10 +43,14 @@ def main():
                 od, oi = orc.knn_euclidean(ref, qry, k, squared=True)
             elif metric == "cosine":
                 od, oi = orc.knn_cosine(ref, qry, k)
+            elif metric == "correlation":
+                od, oi = orc.knn_correlation(ref, qry, k)
             else:
                 od, oi = orc.knn_minkowski_family(ref, qry, k, metric)
-            if metric == "cosine":
-                tol = 4e-7 if dt == np.float32 else 1e-12
+            if metric == "correlation" and d <= 2:
+                ok, note = True, "d <= 2: degenerate (constant rows: scipy nan; d = 2: every distance is 0 or 2 up to rounding)"
+            elif metric in ("cosine", "correlation"):
+                tol = 1e-13 if metric == "correlation" else (4e-7 if dt == np.float32 else 1e-12)
                 ok = bool(np.allclose(dist, od, rtol=0, atol=tol))
                 if ok and not np.array_equal(idx, oi):   # rounding-level ties: same neighbour sets up to the k-th value's ties
                     dd = np.abs(np.take_along_axis(od, np.argsort(oi, 1), 1) - np.take_along_axis(dist.astype(od.dtype), np.argsort(idx, 1), 1))

@@ -36,6 +36,10 @@ def exact_dist(ref, qry_row, cols, metric):
         rn = r / np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-300)
         qn = q / max(np.linalg.norm(q), 1e-300)
         return np.clip(1.0 - rn @ qn, 0.0, 2.0)
+    if metric == "correlation":
+        rc = r - r.mean(axis=1, keepdims=True)
+        qc = q - q.mean()
+        return 1.0 - np.clip((rc @ qc) / np.maximum(np.linalg.norm(rc, axis=1) * np.linalg.norm(qc), 1e-300), -1.0, 1.0)
     if metric == "manhattan":
         return np.abs(r - q).sum(1)
     if metric == "chebyshev":
@@ -56,13 +60,17 @@ def assert_knn_parity(dist, idx, g_dist, g_idx, ref, qry, metric="euclidean", rt
         # sklearn computes cosine distances in the input dtype (float32 stays float32): rounding-level noise
         atol = max(atol, 4e-7 if g_dist.dtype == np.float32 else 1e-12)
         tie_tol = max(tie_tol, 4e-7 if g_dist.dtype == np.float32 else 1e-12)
+    if metric == "correlation":
+        # scipy's C loop, numpy's pairwise mean and this path's float64 arithmetic round differently in the last bits of
+        # 1 - cos (values in [0, 2]): 1e-13 absolute on the distances, neighbours equal except inside ties at that level
+        rtol, atol, tie_tol = 0.0, 1e-13, 1e-13
     np.testing.assert_allclose(dist, g_dist, rtol=rtol, atol=atol)
     bad_rows = np.nonzero((idx != g_idx).any(axis=1))[0]
     k = idx.shape[1]
     for i in bad_rows:
         gd = g_dist[i].astype(np.float64)
         for pos in np.nonzero(idx[i] != g_idx[i])[0]:
-            tol = tie_tol * max(1.0, abs(gd[pos])) if metric != "cosine" else tie_tol
+            tol = tie_tol * max(1.0, abs(gd[pos])) if metric not in ("cosine", "correlation") else tie_tol
             grp = np.nonzero(np.abs(gd - gd[pos]) <= tol)[0]
             ours, theirs = set(idx[i, grp].tolist()), set(g_idx[i, grp].tolist())
             if ours == theirs:

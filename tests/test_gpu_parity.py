@@ -588,6 +588,21 @@ def test_cosine_matches_oracle(hip, oracle):
     assert_knn_parity(dist, idx, od, oi, ref, qry, "cosine")
 
 
+@pytest.mark.parametrize("dtype,d,n_ref,nq,k", [(np.float32, 50, 6000, 500, 15), (np.float64, 37, 3000, 300, 30), (np.float32, 200, 2500, 200, 10)])
+def test_correlation_matches_oracle(hip, oracle, dtype, d, n_ref, nq, k):
+    """sklearn's "correlation" goes to scipy.spatial.distance.cdist: cosine distance of the row-centred data in float64.
+    Here: float64 centred copies of both sides, then the cosine search (staged, certified) -- compared with the oracle's
+    restatement (pinned on the reference by tests/golden/*correlation*) at the tolerance tests/parity.py states (1e-13)."""
+    rng = np.random.default_rng(29)
+    ref = (rng.standard_normal((n_ref, d)) + rng.standard_normal((n_ref, 1))).astype(dtype)   # rows with different means
+    qry = (rng.standard_normal((nq, d)) + 3.0).astype(dtype)
+    dist, idx = hip.knn(ref, qry, k, metric="correlation")
+    od, oi = oracle.knn_correlation(ref, qry, k)
+    assert dist.dtype == np.float64
+    assert_knn_parity(dist, idx, od, oi, ref, qry, "correlation")
+    assert len(tie_rows(idx, oi)) == 0
+
+
 def test_shared_neighbors_match_reference_and_scipy(hip):
     """jaccard / hnoca matrices (cellmapper.py:287-301) vs the golden mapping matrices and vs scipy SpGEMM counts."""
     g = load_golden("synth_full_d37_k10")

@@ -26,6 +26,8 @@ def test_oracle_matches_reference(name, oracle):
         dist, idx = oracle.knn_cosine(xrep, yrep, k)
     elif metric in ("manhattan", "chebyshev"):
         dist, idx = oracle.knn_minkowski_family(xrep, yrep, k, metric)
+    elif metric == "correlation":
+        dist, idx = oracle.knn_correlation(xrep, yrep, k)
     elif metric == "sqeuclidean":
         dist, idx = oracle.knn_euclidean(xrep, yrep, k, squared=True)
         # the float64 GEMM of sklearn's chunks accumulates in BLAS order (OpenBLAS kernels), the oracle in a sequential fma chain:
