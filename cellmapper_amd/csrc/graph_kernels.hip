@@ -25,6 +25,12 @@
 #define CM_A3_EARLY 0   // 1: the first look-back window is copied into LDS (LDS-DMA from inline assembly) in the last round of the next
                         // row's gather -- measured SLOWER (144.5 against 133.3 ms per million rows, profiles/r03_a3_ablation.md): off
 #endif
+#ifndef CM_A3_X1
+#define CM_A3_X1 1   // slices of at most 64 entries: the branch-free gather with one entry per lane (0: the entry-per-lane gather)
+#endif
+#ifndef CM_A3_EPL1
+#define CM_A3_EPL1 1
+#endif
 #ifndef CM_A3_LBW
 #define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
 #endif
@@ -1422,7 +1428,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
             // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
             constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = 4 / EPG;   // groups per lane, entries per group, neighbours per set
-            static_assert(GE * EPG == EPL && GE >= 2 && GE <= 4, "entries per lane: 2, 3, 4 or 8");
+            static_assert(GE * EPG == EPL && GE >= 1 && GE <= 4, "entries per lane: 1, 2, 3, 4 or 8");
             typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef int iv_t __attribute__((ext_vector_type(GE)));
@@ -1665,18 +1671,21 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     const int nch = W / 64;
     // slices of more than 64 entries: the 16-byte gather (X4) with 4 or 8 entries per lane; shorter ones (and
     // CELLMAP_A3_GATHER=1, the A/B switch) keep the entry-per-lane gather
-    const bool x4 = cm_get_knobs().a3_gather == 0 && want > 64;
-    const int epl = x4 ? (want <= 128 ? 2 : (want <= 192 ? 3 : (want <= 256 ? 4 : 8))) : (want <= 128 ? 2 : (want <= 256 ? 4 : 8));
+    const bool x4 = cm_get_knobs().a3_gather == 0 && (want > 64 || CM_A3_X1);
+    // entry-per-lane gather: 1 entry per lane when no slice is longer than 64 (narrow or very sparse payloads, gene-column
+    // shards of a multi-GPU run): one LDS read + write per neighbour instead of two
+    const int epl = x4 ? (want <= 64 ? 1 : (want <= 128 ? 2 : (want <= 192 ? 3 : (want <= 256 ? 4 : 8))))
+                       : (want <= 64 && CM_A3_EPL1 ? 1 : (want <= 128 ? 2 : (want <= 256 ? 4 : 8)));
     auto pick_nch = [&](auto e, auto x) {
         constexpr int E = decltype(e)::value;
         constexpr bool X = decltype(x)::value;
         return nch <= 16 ? spgemm_sliced<E, 16, X> : (nch <= 32 ? spgemm_sliced<E, 32, X> : spgemm_sliced<E, 64, X>);
     };
     typedef std::integral_constant<bool, true> T_; typedef std::integral_constant<bool, false> F_;
-    auto kern = x4 ? (epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, T_{})
+    auto kern = x4 ? (epl == 1 ? pick_nch(std::integral_constant<int, 1>{}, T_{}) : epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, T_{})
                                : (epl == 3 ? pick_nch(std::integral_constant<int, 3>{}, T_{})
                                            : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, T_{}) : pick_nch(std::integral_constant<int, 8>{}, T_{}))))
-                   : (epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, F_{})
+                   : (epl == 1 ? pick_nch(std::integral_constant<int, 1>{}, F_{}) : epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, F_{})
                                : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, F_{}) : pick_nch(std::integral_constant<int, 8>{}, F_{})));
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
