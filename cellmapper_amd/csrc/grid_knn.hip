@@ -120,8 +120,37 @@ __global__ void grid_scatter(const T *__restrict__ X, int64_t n, int d, const in
     sidx[pos] = (int)i;
 }
 
-// wave-wide: k-th smallest (1-based) of the n non-negative floats in v[] (LDS); radix select on the bit patterns
+// wave-wide: k-th smallest (1-based) of the n non-negative floats in v[] (LDS); radix select on the bit patterns.
+// wave_kth_regs: the same selection with the values read ONCE into NR registers per lane (n <= 64 NR): the 31 bit passes are
+// then compare / ballot / count only -- the LDS version re-reads every value in every pass (round 3: a third of grid_query).
+template <int NR>
+__device__ __forceinline__ float wave_kth_regs(const float *v, int n, int k, int lane) {
+    unsigned key[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { const int i = r * 64 + lane; key[r] = i < n ? __float_as_uint(v[i]) : 0xffffffffu; }
+    // invariant: `below` keys are smaller than `prefix`; the k-th smallest has the high bits of `prefix`.  One unsigned
+    // compare per register and bit: the keys with those high bits and a 0 at `bit` are the ones below prefix | 1 << bit
+    // that are not below prefix.  (Sign bit 0 for every entry; a padding key is 0xffffffff: never below anything tested.)
+    unsigned prefix = 0u;
+    int below = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned pivot = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) c += __popcll(__ballot(key[r] < pivot));
+        if (k > c) { prefix = pivot; below = c; }   // fewer than k keys below the pivot: the k-th has this bit set
+    }
+    (void)below;
+    return __uint_as_float(prefix);
+}
+__device__ __forceinline__ float wave_kth_lds(const float *v, int n, int k, int lane);
 __device__ __forceinline__ float wave_kth(const float *v, int n, int k, int lane) {
+    if (n <= 256) return wave_kth_regs<4>(v, n, k, lane);
+    if (n <= 512) return wave_kth_regs<8>(v, n, k, lane);
+    if (n <= 1024) return wave_kth_regs<16>(v, n, k, lane);
+    return wave_kth_lds(v, n, k, lane);
+}
+__device__ __forceinline__ float wave_kth_lds(const float *v, int n, int k, int lane) {
     unsigned prefix = 0u;
     int remaining = k;
     for (int bit = 30; bit >= 0; --bit) {   // sign bit is 0 for every entry
