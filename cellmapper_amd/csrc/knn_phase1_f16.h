@@ -192,16 +192,15 @@ __device__ __forceinline__ int prune_select(const unsigned (&key)[E], const unsi
         const int hb = diff ? 31 - __clz(diff) : -1;  // highest bit in which the keys differ
         unsigned prefix = hb >= 31 ? 0u : (kmin & ~((2u << (hb < 0 ? 0 : hb)) - 1u));
         if (hb < 0) prefix = kmin;
-        int remaining = Kc;  // rank (1-based) of the wanted key among the entries that match `prefix` so far
+        // Bit by bit: fewer than Kc keys below prefix | 1 << bit  =>  the Kc-th key has that bit set.  ONE unsigned compare per
+        // register and bit (round 3; was mask / compare / shift / test).  No key is below the starting prefix (the common
+        // leading bits), and an unused slot holds 0xffffffff, which is never below a pivot.
         for (int bit = hb; bit >= 0; --bit) {
-            const unsigned himask = bit == 31 ? 0u : ~((2u << bit) - 1u);
-            int cnt0 = 0;
+            const unsigned pivot = prefix | (1u << bit);
+            int c = 0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                bool m = valid[e] && ((key[e] & himask) == prefix) && !((key[e] >> bit) & 1u);
-                cnt0 += __popcll(__ballot(m));
-            }
-            if (remaining > cnt0) { prefix |= (1u << bit); remaining -= cnt0; }
+            for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e] < pivot));
+            if (Kc > c) prefix = pivot;
         }
         kth = prefix;
     }
