@@ -236,12 +236,27 @@ def test_spgemm_sliced_kernel_shapes(oracle):
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
     # (slices of ~225 entries: 4 per lane in registers; > 128 neighbours; 2 buckets for 8 waves; short slices; slices of ~130..250;
     #  slices of ~700 entries: 8 per lane + the scalar loop)
+    # round 3: entries per lane are chosen by the payload's longest slice -- 1 (<= 64), 2 (<= 128), 3 (<= 192), 4 (<= 256) consecutive
+    # entries per 4 / 8 / 12 / 16-byte load, 8 beyond -- and a vector load may run past the end of its slice: the LAST payload row,
+    # whose last slice ends with the arrays, is given a short last slice and a place in every mapping row (the slice at the very end
+    # of the arrays must take the entry-per-lane loop instead of reading past them)
     for seed, (n_ref, nq, k, n_out, density) in enumerate([(120, 300, 7, 3000, 0.6), (400, 150, 200, 900, 0.05), (60, 200, 4, 90, 0.3),
-                                                            (80, 100, 3, 1000, 0.2), (100, 200, 5, 4000, 0.35), (50, 120, 4, 8000, 0.7)]):
+                                                            (80, 100, 3, 1000, 0.2), (100, 200, 5, 4000, 0.35), (50, 120, 4, 8000, 0.7),
+                                                            (90, 150, 6, 4000, 0.17), (90, 150, 6, 4000, 0.29), (70, 130, 9, 2000, 0.1),
+                                                            (64, 90, 5, 30000, 0.03)]):
         rng = np.random.default_rng(90 + seed)
         indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
-        B = sp.random(n_ref, n_out, density=density, format="csr", dtype=np.float32, random_state=rng)
+        B = sp.random(n_ref, n_out, density=density, format="lil", dtype=np.float32, random_state=rng)
+        W = max(64, (((n_out + 7) // 8) + 63) // 64 * 64)
+        last_lo = (n_out - 1) // W * W                      # first column of the last bucket
+        B[n_ref - 1, last_lo:] = 0
+        B[n_ref - 1, n_out - 1] = 1.5                       # the last row's last slice: ONE entry, the last of the arrays
+        B = B.tocsr()
+        B.eliminate_zeros()
         B.sort_indices()
+        has = np.diff(indptr) > 0
+        cols = cols.copy()
+        cols[indptr[:-1][has]] = n_ref - 1                  # every non-empty mapping row gathers the last payload row
         dense = oracle.spmm_csr(indptr, cols, vals, B)
         want_ptr = np.concatenate([[0], np.cumsum((dense != 0).sum(1))])
         cap = int(want_ptr[-1])
