@@ -17,6 +17,13 @@ except Exception:
     torch = None
 
 
+# The suite is written for ONE device: the process-wide handle of the drop-in classes takes every visible GPU by default
+# (cellmapper_amd/_native.py: default_devices), which on a multi-GPU node would route every test through the multi-device
+# tier.  That tier has its own tests (tests/test_gpu_multi.py lists devices explicitly); CELLMAP_TEST_ALL_GPUS=1 lifts the pin.
+if not os.environ.get("CELLMAP_TEST_ALL_GPUS"):
+    os.environ.setdefault("CELLMAP_DEVICES", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
