@@ -18,13 +18,6 @@
 #define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 1 aligned 16-byte loads, 2 no
                        // accumulator updates (loads kept), 4 no payload loads, 8 no output stores, 16 no wait for the rows in front
 #endif
-#ifndef CM_A3_SC
-#define CM_A3_SC " sc1"   // coherence of the early window's loads (experiment: "" = may be served from a stale L2 line)
-#endif
-#ifndef CM_A3_EARLY
-#define CM_A3_EARLY 0   // 1: the first look-back window is copied into LDS (LDS-DMA from inline assembly) in the last round of the next
-                        // row's gather -- measured SLOWER (144.5 against 133.3 ms per million rows, profiles/r03_a3_ablation.md): off
-#endif
 #ifndef CM_A3_X1
 #define CM_A3_X1 1   // slices of at most 64 entries: the branch-free gather with one entry per lane (0: the entry-per-lane gather)
 #endif
@@ -1152,7 +1145,6 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     long long *tk = reinterpret_cast<long long *>(wsum + 16);           // [0] ticket of the row after next, [1] the row's first entry
     float *dummy = reinterpret_cast<float *>(tk + 2);                   // [512] where lanes without an entry do their add
     float *zero = dummy + 512;                                          // [64] zeros: what a chunk beyond the slice reads
-    unsigned long long *lbst = reinterpret_cast<unsigned long long *>(zero + 64);   // [256] early look-back window (lb_dma)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wlo = wave * W;   // this wave's output columns: [wlo, min(wlo + W, n_out)) (possibly none)
     if (tid < 64) zero[tid] = 0.f;
@@ -1226,35 +1218,13 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     // wave 0: the sum of the counts of all rows in front of row r -- published counts back to the nearest published
     // inclusive prefix, 64 x CM_A3_LBW rows per step (that many loads per lane in flight; the nearest inclusive prefix is
     // a few hundred rows back: every workgroup places a row one row after counting it)
-    // Experiment kept behind CM_A3_EARLY (off): the first window (the 256 rows in front) fetched a little early -- in the
-    // last round of the gather, behind its last payload loads, wave 0 copies it into LDS with two LDS-DMA loads issued from
-    // inline assembly (the compiler must not see them: ordinary loads inside the gather loop made its load counting
-    // conservative for every wave, +10 %), so that the round trip of these coherent loads (3.7 us per row, seven waves
-    // waiting) runs under the last eight neighbours' accumulator updates.  The window always resolves (no second read,
-    // identical results) and the kernel is 8 % SLOWER, with or without the coherence bit on the loads; issued half-way
-    // through the gather it costs the same (loads return in order: every payload load behind the window waits for it).
-    bool lb_early = false;
-    int64_t lb_base = 0;
-    auto lb_dma = [&]() {
-        if (CM_A3_EARLY && ticketed && wave == 0 && have_prev) {   // (uniform)
-            lb_base = prev_row > 256 ? prev_row - 256 : 0;         // LDS slot j <- row lb_base + j (rows past nq: never looked at)
-            int64_t i0 = lb_base + 2 * lane, i1 = i0 + 128;
-            i0 = i0 < nq ? i0 : nq; i1 = i1 < nq ? i1 : nq;        // (chain holds nq + 2 words)
-            const unsigned long long *p0 = chain + i0, *p1 = chain + i1;
-            const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned long long *)lbst;
-            asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, off" CM_A3_SC "\n\ts_add_u32 m0, m0, 1024\n\tglobal_load_lds_dwordx4 %1, off" CM_A3_SC
-                         ::"v"(p0), "v"(p1), "s"(ldsb));
-            lb_early = true;
-        }
-    };
+    // (Fetching the first window early -- an LDS-DMA of the 256 rows in front, issued from inline assembly in the last round of
+    // the next row's gather so that the round trip runs under the last neighbours' updates -- was built and measured: the
+    // window always resolves and the kernel is 8 % slower; profiles/r03_a3_ablation.md, section 4.)
     auto lookback = [&](int64_t r) -> long long {
         constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
         constexpr int LBW = CM_A3_LBW;   // loads per lane and step
-        static_assert(LBW == 4, "the early window holds 256 rows");
         long long excl = 0;
-        bool pre = lb_early;
-        lb_early = false;
-        if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the window has landed in LDS)
         for (int64_t pos = (CM_A3_EXP & 16) ? -1 : r - 1; pos >= 0; pos -= 64 * LBW) {
             unsigned long long v[LBW];
             int ustar = LBW, fi = 63;
@@ -1262,11 +1232,8 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
 #pragma unroll
                 for (int u = 0; u < LBW; ++u) {
                     const int64_t i = pos - 64 * u - lane;
-                    if (pre) v[u] = i >= 0 ? lbst[i - lb_base] : (2ull << 62);   // (first window only: i >= r - 256 >= lb_base)
-                    else v[u] = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                    v[u] = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
                 }
-                const bool was_pre = pre;
-                pre = false;
                 bool retry = false;
                 ustar = LBW;
 #pragma unroll
@@ -1278,7 +1245,6 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                         } else if (empty != 0ull) retry = true;
                     }
                 }
-                if (CM_A3_EARLY == 2 && was_pre) { if (ustar == LBW) ustar = 0; break; }   // timing experiment: trust the window
                 if (!retry) break;
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -1505,7 +1471,6 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                     for (int ub = 0; ub < nn; ub += 3 * NB) {
                         m2 = pick(ub + 2 * NB);
                         load_set(c2, v2, m2);
-                        if (ub + 3 * NB >= nn) lb_dma();
                         apply_set(c0, v0, m0);
                         if (ub == 0 && !ticketed) stage2(g);
                         m0 = pick(ub + 3 * NB);
@@ -1521,7 +1486,6 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
                     for (int ub = 0; ub < nn; ub += 2 * NB) {
                         m1 = pick(ub + NB);
                         load_set(c1, v1, m1);
-                        if (ub + 2 * NB >= nn) lb_dma();   // last round: behind the last payload loads, in front of the last updates
                         apply_set(c0, v0, m0);
                         if (ub == 0 && !ticketed) stage2(g);
                         m0 = pick(ub + 2 * NB);
@@ -1660,7 +1624,7 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
     CM_TRY(cm_payload_index_header(h, d_index, &max_slice, &nnz));
     int want = max_slice;
     if (max_slice > 512 && n_ref > 0) want = (int)std::min<long long>(512, (3 * nnz) / (2 * n_ref * nb) + 1);
-    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 2048 + 256 + 2048;
+    const size_t lds = (size_t)8 * W * 4 + 64 + 16 + 2048 + 256;
     if (h->n_cu <= 0) {
         hipDeviceProp_t pr;
         CM_HIP(h, hipGetDeviceProperties(&pr, h->device));
