@@ -422,13 +422,13 @@ cm_status cm_spmm_csr_fused_dev(cm_handle_t h, const int64_t *d_indptr, const in
                                 const int64_t *d_b_indptr, const int32_t *d_b_cols, const float *d_b_vals, int64_t n_ref,
                                 int64_t n_out, int64_t capacity, int64_t *d_out_indptr, int32_t *d_out_cols, float *d_out_vals,
                                 const int32_t *d_row_order, int32_t *d_out_rows, const int32_t *d_payload_index) {
-    CM_TRY(begin_call(h, cm_align(8 * (size_t)(std::max<int64_t>(nq, 0) + 2)) + 4096));
+    CM_TRY(begin_call(h, cm_align(cm_a3_chain_bytes(nq)) + 4096));
     if (nq < 0 || capacity < 0 || !d_out_indptr || (capacity > 0 && (!d_out_cols || !d_out_vals)))
         CM_FAIL(h, CM_E_INVALID, "spmm_csr (single pass): bad arguments");
     if (!cm_spmm_csr_single_pass_ok(n_out))
         CM_FAIL(h, CM_E_INVALID, "spmm_csr (single pass): %lld output columns do not fit one accumulator pass; use "
                                  "cm_spmm_csr_nnz_dev + cm_spmm_csr_dev", (long long)n_out);
-    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, 8 * (size_t)(nq + 2));
+    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, cm_a3_chain_bytes(nq));
     if (!chain) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: device workspace exhausted");
     if (d_payload_index)
         return cm_spmm_csr_sliced_run(h, d_indptr, d_cols, d_vals, nq, d_b_indptr, d_b_cols, d_b_vals, n_ref, d_payload_index, n_out,
@@ -728,7 +728,7 @@ static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const i
                                    const int64_t *b_indptr, const int32_t *b_cols, const float *b_vals, int64_t n_ref,
                                    int64_t n_out, int64_t *out_indptr) {
     if (nq < 0 || n_ref < 0 || !b_indptr || !out_indptr) CM_FAIL(h, CM_E_INVALID, "spmm_csr: bad arguments");
-    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + cm_align(8 * ((size_t)std::max<int64_t>(nq, 0) + 2)) + 8192));
+    CM_TRY(begin_call(h, cm_scan_ws_bytes(nq) + cm_align(cm_a3_chain_bytes(nq)) + 8192));
     a3_session_drop(h);
     A3Session *ss = new (std::nothrow) A3Session();
     if (!ss) CM_FAIL(h, CM_E_NOMEM, "spmm_csr: out of host memory");
@@ -757,10 +757,10 @@ static cm_status spmm_csr_nnz_impl(cm_handle_t h, const int64_t *indptr, const i
                                ss->bp.as<int64_t>(), n_out, d_ub);
             if (d2h(h, &ub, d_ub, 8) == CM_OK && sync(h) == CM_OK && ub > 0) {
                 const int64_t ilen = cm_payload_index_len_impl(n_ref, n_out);
-                const size_t need = 8 * (size_t)ub + 4 * (size_t)std::max<int64_t>(ilen, 0) + 8 * ((size_t)nq + 2);
+                const size_t need = 8 * (size_t)ub + 4 * (size_t)std::max<int64_t>(ilen, 0) + cm_a3_chain_bytes(nq);
                 if (ilen > 0 && need <= device_budget(h, cm_get_knobs().spgemm_budget_mb) / 2) {
                     int *flag = (int *)cm_ws_alloc(h, 64);
-                    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, 8 * (size_t)(nq + 2));
+                    unsigned long long *chain = (unsigned long long *)cm_ws_alloc(h, cm_a3_chain_bytes(nq));
                     int bad = 1;
                     if (flag && chain && ss->pidx.alloc(h, 4 * (size_t)ilen) == CM_OK && ss->oc.alloc(h, 4 * (size_t)ub) == CM_OK &&
                         ss->ov.alloc(h, 4 * (size_t)ub) == CM_OK) {

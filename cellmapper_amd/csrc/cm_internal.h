@@ -142,6 +142,7 @@ cm_status cm_spmm_csr_fill_run(cm_handle_t h, const int64_t *d_indptr, const int
                                const int32_t *d_order = nullptr);
 bool cm_spmm_csr_single_pass_ok(int64_t n_out);
 int cm_a3_bucket_width(int64_t n_out);
+size_t cm_a3_chain_bytes(int64_t nq);   // scratch of the single-pass sparse product's chained scan
 int64_t cm_payload_index_len_impl(int64_t n_ref, int64_t n_out);
 cm_status cm_payload_index_header(cm_handle_t h, const int32_t *d_index, int *max_slice, long long *nnz);
 cm_status cm_payload_index_run(cm_handle_t h, const int64_t *d_bptr, const int32_t *d_bcols, int64_t n_ref, int64_t n_out,

@@ -24,6 +24,9 @@
 #ifndef CM_A3_EPL1
 #define CM_A3_EPL1 1
 #endif
+#ifndef CM_A3_CSTRIDE
+#define CM_A3_CSTRIDE 1   // words between the chained scan's per-row entries (experiment: 8 = one cache line each)
+#endif
 #ifndef CM_A3_LBW
 #define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
 #endif
@@ -1156,7 +1159,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     if (ticketed) {
         // one ticket at a time (a workgroup's rows must interleave with the other workgroups' rows: a row waits for the counts
         // of ALL rows in front of it, and a ticket held back here is a row nobody works on)
-        if (tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
+        if (tid == 0) tk[0] = (long long)atomicAdd(chain + nq * CM_A3_CSTRIDE, 1ull);
         __syncthreads();
         row = tk[0]; nxt = nq;   // (the next row's ticket is taken when this one starts)
         __syncthreads();
@@ -1232,7 +1235,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
 #pragma unroll
                 for (int u = 0; u < LBW; ++u) {
                     const int64_t i = pos - 64 * u - lane;
-                    v[u] = i >= 0 ? __hip_atomic_load(chain + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+                    v[u] = i >= 0 ? __hip_atomic_load(chain + i * CM_A3_CSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
                 }
                 bool retry = false;
                 ustar = LBW;
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
     auto place = [&](int64_t r, int n) {
         if (!ticketed) {
             if (tid == 0) {
-                const unsigned long long old = atomicAdd(chain + nq + 1, (1ull << 40) | (unsigned long long)n);
+                const unsigned long long old = atomicAdd(chain + nq * CM_A3_CSTRIDE + 1, (1ull << 40) | (unsigned long long)n);
                 const long long j = (long long)(old >> 40), o = (long long)(old & ((1ull << 40) - 1ull));
                 out_indptr[j] = o;
                 if (j == nq - 1) out_indptr[nq] = o + n;
@@ -1274,7 +1277,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             const long long excl = lookback(r);
             if (lane == 0) {
                 if (r > 0)
-                    __hip_atomic_store(chain + r, (2ull << 62) | (unsigned long long)(excl + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(chain + r * CM_A3_CSTRIDE, (2ull << 62) | (unsigned long long)(excl + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else out_indptr[0] = 0;
                 out_indptr[r + 1] = excl + n;
                 tk[1] = excl;
@@ -1310,7 +1313,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
         // now, known to the waves after the first barrier and fetched during the emission (a ticket held for longer is a
         // row the other workgroups wait for)
         const int64_t nxt2 = nxt + gridDim.x;
-        if (ticketed && tid == 0) tk[0] = (long long)atomicAdd(chain + nq, 1ull);
+        if (ticketed && tid == 0) tk[0] = (long long)atomicAdd(chain + nq * CM_A3_CSTRIDE, 1ull);
         if (!ticketed) stage1(g);
         // ---- the gather: batches of NBATCH neighbours, two register sets
         const int nn = cur.deg < 128 ? cur.deg : 128;
@@ -1550,7 +1553,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
         parity ^= 1;
         // this row's count is published at once (row 0: it is its own inclusive prefix)
         if (ticketed && wave == 0 && lane == 0)
-            __hip_atomic_store(chain + row, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
+            __hip_atomic_store(chain + row * CM_A3_CSTRIDE, ((row == 0 ? 2ull : 1ull) << 62) | (unsigned long long)all, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         prev_row = row; prev_all = all; prev_before = before; have_prev = true;
         // ---- next row
@@ -1568,6 +1571,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
 }
 }  // namespace
 
+size_t cm_a3_chain_bytes(int64_t nq) { return 8 * ((size_t)(nq > 0 ? nq : 0) * CM_A3_CSTRIDE + 2); }
 int cm_a3_bucket_width(int64_t n_out) {
     const int64_t w = (((n_out + 7) / 8) + 63) & ~63LL;
     return (int)(w < 64 ? 64 : w);
@@ -1652,7 +1656,7 @@ cm_status cm_spmm_csr_sliced_run(cm_handle_t h, const int64_t *d_indptr, const i
                    : (epl == 1 ? pick_nch(std::integral_constant<int, 1>{}, F_{}) : epl == 2 ? pick_nch(std::integral_constant<int, 2>{}, F_{})
                                : (epl == 4 ? pick_nch(std::integral_constant<int, 4>{}, F_{}) : pick_nch(std::integral_constant<int, 8>{}, F_{})));
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CM_HIP(h, hipMemsetAsync(d_chain, 0, 8 * (size_t)(nq + 2), h->stream));
+    CM_HIP(h, hipMemsetAsync(d_chain, 0, cm_a3_chain_bytes(nq), h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, h->stream, d_indptr, d_cols, d_vals, nq, d_bptr, d_bcols, d_bvals, d_index, nb + 1,
                        (int)n_out, W, d_out_indptr, d_out_cols, d_out_vals, d_order, d_chain, capacity, d_out_rows, (int64_t)nnz);
     CM_HIP(h, hipGetLastError());
