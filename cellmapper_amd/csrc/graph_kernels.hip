@@ -27,6 +27,10 @@
 #ifndef CM_A3_CSTRIDE
 #define CM_A3_CSTRIDE 1   // words between the chained scan's per-row entries (experiment: 8 = one cache line each)
 #endif
+#ifndef CM_A3_NB8
+#define CM_A3_NB8 1   // neighbours per register set of the branch-free gather: 8 up to three entries per lane (1: measured -1 % at config 5,
+                       // -6 % on narrow payloads against 4; sixteen: +5 % again), 4 / 2 beyond
+#endif
 #ifndef CM_A3_LBW
 #define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
 #endif
@@ -1396,7 +1400,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             // per array) or two groups of 4.  The LDS updates are what the gather costs (bank conflicts of ~random columns),
             // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
             // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
-            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = 4 / EPG;   // groups per lane, entries per group, neighbours per set
+            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_NB8 && EPL <= 3) ? 8 : 4 / EPG;   // groups per lane, entries per group, neighbours per set
             static_assert(GE * EPG == EPL && GE >= 1 && GE <= 4, "entries per lane: 1, 2, 3, 4 or 8");
             typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
