@@ -31,6 +31,10 @@
 #define CM_A3_NB8 1   // neighbours per register set of the branch-free gather: 8 up to three entries per lane (1: measured -1 % at config 5,
                        // -6 % on narrow payloads against 4; sixteen: +5 % again), 4 / 2 beyond
 #endif
+#ifndef CM_A3_OCC4
+#define CM_A3_OCC4 2   // narrow payloads (at most 16 chunks per wave slice = 8 192 columns) with at most this many entries per lane: the kernel is
+                       // held to 128 registers so that TWO workgroups share a CU and overlap their phases (-24 ... -33 %); 0 = off
+#endif
 #ifndef CM_A3_LBW
 #define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
 #endif
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb
 // EPL = 4 or 8 entries per lane (1 or 2 groups).  A 16-byte load may run up to three entries past the end of its slice
 // (never used): a slice that ends within three entries of the END OF THE ARRAY (b_nnz) takes the entry-per-lane loop.
 template <int EPL, int NCH, bool X4>
-__global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+__global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= 16 && EPL <= CM_A3_OCC4 && X4) ? 4 : 2) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
                                                       const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
                                                       const float *__restrict__ bvals, const int32_t *__restrict__ bidx_, int nb1,
@@ -1400,7 +1404,7 @@ __global__ __launch_bounds__(512) void spgemm_sliced(const int64_t *__restrict__
             // per array) or two groups of 4.  The LDS updates are what the gather costs (bank conflicts of ~random columns),
             // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
             // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
-            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_NB8 && EPL <= 3) ? 8 : 4 / EPG;   // groups per lane, entries per group, neighbours per set
+            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_OCC4 && NCH <= 16 && EPL >= 2 && EPL <= CM_A3_OCC4) ? 4 / EPG : ((CM_A3_NB8 && EPL <= 3) ? 8 : 4 / EPG);   // groups per lane, entries per group, neighbours per set
             static_assert(GE * EPG == EPL && GE >= 1 && GE <= 4, "entries per lane: 1, 2, 3, 4 or 8");
             typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
