@@ -357,11 +357,11 @@ def run_config5(ctx):
                      if one_pass else "spgemm_rows<0> + spgemm_rows<1> (count + fill passes of the CSR x CSR product, A3)",
                      "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
                      "kernel_ms": ms, "algorithmic_bytes": alg_bytes,
-                     # the committed counter pass (profiles/r02_pmc_counters.md: 400 k cells, FETCH_SIZE x 2 + WRITE_SIZE = 0.545 x the
+                     # the committed counter pass (profiles/r03_pmc_counters.md: 400 k cells, FETCH_SIZE x 2 + WRITE_SIZE = 0.542 x the
                      # algorithmic bytes -- the locality order turns most of the gather into L2 / Infinity-Cache hits): the fraction of the
                      # HBM peak by the counters' bytes is what says how far the kernel is from the memory system's limit
-                     "frac_hbm_counters": 0.545 * achieved / PEAK_HBM_GBS if ctx.world == 1 else None,
-                     "frac_hbm_counters_source": "profiles/r02_pmc_counters.md (counter bytes / algorithmic bytes = 0.545 at 400 k cells)",
+                     "frac_hbm_counters": 0.542 * achieved / PEAK_HBM_GBS if ctx.world == 1 else None,
+                     "frac_hbm_counters_source": "profiles/r03_pmc_counters.md (counter bytes / algorithmic bytes = 0.542 at 400 k cells; round 2: 0.545)",
                      "kernel_ms_covers": ("all query tiles of one step incl. the locality sort and the payload index (one gather per row)" if one_pass else
                                           "both passes over all query tiles in one step (the gather is done twice: count, fill)")
                                          + ", rank 0's gene columns, mean over the timed steps"},
