@@ -28,8 +28,8 @@
 #define CM_A3_CSTRIDE 1   // words between the chained scan's per-row entries (experiment: 8 = one cache line each)
 #endif
 #ifndef CM_A3_NB8
-#define CM_A3_NB8 1   // neighbours per register set of the branch-free gather: 8 up to three entries per lane (1: measured -1 % at config 5,
-                       // -6 % on narrow payloads against 4; sixteen: +5 % again), 4 / 2 beyond
+#define CM_A3_NB8 1   // neighbours per register set of the branch-free gather: 8 up to two entries per lane (-6 % on narrow payloads against 4;
+                       // sixteen: +5 % again; at three entries per lane -1 % at 1 M rows of config 5 but nothing at 4 M), 4 / 2 beyond
 #endif
 #ifndef CM_A3_OCC4
 #define CM_A3_OCC4 2   // narrow payloads (at most 16 chunks per wave slice = 8 192 columns) with at most this many entries per lane: the kernel is
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= 16 && EPL <= CM_A3_OCC4 
             // per array) or two groups of 4.  The LDS updates are what the gather costs (bank conflicts of ~random columns),
             // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
             // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
-            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_OCC4 && NCH <= 16 && EPL >= 2 && EPL <= CM_A3_OCC4) ? 4 / EPG : ((CM_A3_NB8 && EPL <= 3) ? 8 : 4 / EPG);   // groups per lane, entries per group, neighbours per set
+            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_OCC4 && NCH <= 16 && EPL >= 2 && EPL <= CM_A3_OCC4) ? 4 / EPG : ((CM_A3_NB8 && EPL <= 2) ? 8 : 4 / EPG);   // groups per lane, entries per group, neighbours per set
             static_assert(GE * EPG == EPL && GE >= 1 && GE <= 4, "entries per lane: 1, 2, 3, 4 or 8");
             typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
