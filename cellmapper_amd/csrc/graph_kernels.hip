@@ -15,7 +15,7 @@
 #include <math.h>
 
 #ifndef CM_A3_EXP
-#define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 1 aligned 16-byte loads, 2 no
+#define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 2 no
                        // accumulator updates (loads kept), 4 no payload loads, 8 no output stores, 16 no wait for the rows in front
 #endif
 #ifndef CM_A3_X1
@@ -1131,12 +1131,15 @@ __global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb
 // NCH registers per lane (all LDS reads issued back to back, one wait), cleared behind those reads for the next row,
 // counted and emitted from the registers: the count and the emission used to be two loops of read -> wait -> ballot
 // with one LDS round trip per 64 columns each (round 3: ~2 x 59 x 130 cycles per row at 30 000 genes).
-// X4 (round 3): a lane holds FOUR CONSECUTIVE entries of a slice per 16-byte load (entries 256 g + 4 lane ..) instead of
-// EPL entries 64 apart: a 113-entry slice of config 5 is 2 loads per neighbour instead of 8.  Measured equal to the
-// entry-per-lane gather (and to three rotating register sets instead of two: CM_A3_NSET): the gather is not bound by
-// the bytes in flight but by the read -> add -> write round trip through LDS per neighbour (profiles/r03_a3_ablation.md).
-// EPL = 4 or 8 entries per lane (1 or 2 groups).  A 16-byte load may run up to three entries past the end of its slice
-// (never used): a slice that ends within three entries of the END OF THE ARRAY (b_nnz) takes the entry-per-lane loop.
+// X4 (round 3, the default; the name is historical): the BRANCH-FREE gather.  A lane holds EPL = 1, 2, 3, 4 (one group) or 8
+// (two groups of 4) CONSECUTIVE entries of a slice, fetched with one 4- / 8- / 12- / 16-byte load per array, EPL chosen by
+// the launcher as the smallest that covers the payload's longest slice: the accumulator updates -- one LDS read and one
+// write instruction per entry of a lane, bank-conflicted on ~random columns -- are what the gather costs, not the bytes in
+// flight (two or three register sets, entry-per-lane or vector loads: no difference; profiles/r03_a3_ablation.md).  A row
+// whose slices all fit the registers takes a loop with no branch around any memory operation (FAST); a vector load may run
+// up to three entries past the end of its slice (never used), so a slice that ends within three entries of the END OF THE
+// ARRAYS (b_nnz) sends its row to the general loop.  !X4 (CELLMAP_A3_GATHER=1): round 2's entry-per-lane gather, for A/B.
+// Narrow payloads (NCH <= 16) with at most two entries per lane are held to 128 registers: two workgroups per CU.
 template <int EPL, int NCH, bool X4>
 __global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= 16 && EPL <= CM_A3_OCC4 && X4) ? 4 : 2) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
