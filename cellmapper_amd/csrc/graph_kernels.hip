@@ -16,7 +16,7 @@
 
 #ifndef CM_A3_EXP
 #define CM_A3_EXP 0    // timing experiments only (scripts/build_a3_variant.sh; wrong results): 2 no
-                       // accumulator updates (loads kept), 4 no payload loads, 8 no output stores, 16 no wait for the rows in front
+                       // accumulator updates (loads kept), 8 no output stores, 16 no wait for the rows in front
 #endif
 #ifndef CM_A3_X1
 #define CM_A3_X1 1   // slices of at most 64 entries: the branch-free gather with one entry per lane (0: the entry-per-lane gather)
