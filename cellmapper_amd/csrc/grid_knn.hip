@@ -84,9 +84,12 @@ __global__ void grid_setup(const unsigned *__restrict__ bb, int d, double ncell_
 
 __device__ __forceinline__ void cell_of_point(const GridInfo &gi, const float *p, int d, int *cc) {
     cc[0] = cc[1] = cc[2] = 0;
-    for (int c = 0; c < d; ++c) {
-        int v = (int)floorf((p[c] - gi.lo[c]) * gi.inv_h);
-        cc[c] = v < 0 ? 0 : (v >= gi.g[c] ? gi.g[c] - 1 : v);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // (constant indices: the three-element arrays stay in registers, not in scratch)
+        if (c < d) {
+            int v = (int)floorf((p[c] - gi.lo[c]) * gi.inv_h);
+            cc[c] = v < 0 ? 0 : (v >= gi.g[c] ? gi.g[c] - 1 : v);
+        }
     }
 }
 __device__ __forceinline__ int64_t cell_linear(const GridInfo &gi, int x, int y, int z) {
@@ -180,7 +183,18 @@ __global__ __launch_bounds__(256) void grid_query(const T *__restrict__ Q, int64
     const GridInfo gi = *gip;
     const int64_t io = rowmap ? (int64_t)rowmap[i] : i;
     float q[3] = {0, 0, 0};
-    for (int c = 0; c < d; ++c) q[c] = (float)Q[io * d + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < d) q[c] = (float)Q[io * d + c];
+    // squared distance to stored point p, coordinates in order (unrolled over the at most three dimensions: `q` indexed by a
+    // run-time c lived in scratch memory, 40 bytes per lane, and every point evaluation went through it)
+    auto dist2 = [&](int64_t p) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < d) { const float t = q[c] - sxyz[p * d + c]; s_ = fmaf(t, t, s_); }
+        return s_;
+    };
     int cc[3];
     cell_of_point(gi, q, d, cc);
     int *crow = cand + i * (int64_t)Kc;
@@ -213,9 +227,7 @@ __global__ __launch_bounds__(256) void grid_query(const T *__restrict__ Q, int64
             for (int y = y0; y <= y1; ++y) {
                 const int64_t p0 = cell_start[cell_linear(gi, x0, y, z)], p1 = cell_start[cell_linear(gi, x1, y, z) + 1];
                 for (int64_t p = p0 + lane; p < p1; p += 64) {
-                    float s = 0.f;
-                    for (int c = 0; c < d; ++c) { const float t = q[c] - sxyz[p * d + c]; s = fmaf(t, t, s); }
-                    s_v[w][base + (int)(p - p0)] = s;
+                    s_v[w][base + (int)(p - p0)] = dist2(p);
                 }
                 base += (int)(p1 - p0);
             }
@@ -239,10 +251,7 @@ __global__ __launch_bounds__(256) void grid_query(const T *__restrict__ Q, int64
                 for (int64_t pb = p0; pb < p1; pb += 64) {
                     const int64_t p = pb + lane;
                     float s = INFINITY;
-                    if (p < p1) {
-                        s = 0.f;
-                        for (int c = 0; c < d; ++c) { const float t = q[c] - sxyz[p * d + c]; s = fmaf(t, t, s); }
-                    }
+                    if (p < p1) s = dist2(p);
                     const bool in = s <= tau;
                     const unsigned long long b = __ballot(in);
                     const int pos = m + __popcll(b & ((1ull << lane) - 1ull));
@@ -261,11 +270,7 @@ __global__ __launch_bounds__(256) void grid_query(const T *__restrict__ Q, int64
                     for (int64_t pb = p0; pb < p1; pb += 64) {
                         const int64_t p = pb + lane;
                         bool in = false;
-                        if (p < p1) {
-                            float s = 0.f;
-                            for (int c = 0; c < d; ++c) { const float t = q[c] - sxyz[p * d + c]; s = fmaf(t, t, s); }
-                            in = s <= tau;
-                        }
+                        if (p < p1) in = dist2(p) <= tau;
                         const unsigned long long b = __ballot(in);
                         const int pos = ncand + __popcll(b & ((1ull << lane) - 1ull));
                         if (in && pos < Kc) crow[pos] = sidx[p];
