@@ -32,8 +32,11 @@
                        // sixteen: +5 % again; at three entries per lane -1 % at 1 M rows of config 5 but nothing at 4 M), 4 / 2 beyond
 #endif
 #ifndef CM_A3_OCC4
-#define CM_A3_OCC4 2   // narrow payloads (at most 16 chunks per wave slice = 8 192 columns) with at most this many entries per lane: the kernel is
+#define CM_A3_OCC4 2   // narrow payloads (at most CM_A3_OCCN chunks per wave slice) with at most this many entries per lane: the kernel is
                        // held to 128 registers so that TWO workgroups share a CU and overlap their phases (-24 ... -33 %); 0 = off
+#endif
+#ifndef CM_A3_OCCN
+#define CM_A3_OCCN 32   // ... up to this many 64-column chunks per wave slice (32: 16 384 output columns, 66 KB of LDS per workgroup)
 #endif
 #ifndef CM_A3_LBW
 #define CM_A3_LBW 4    // chained scan of the wave-sliced product: 64 x this many rows in front are read per look-back step
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(256) void payload_index_stats(int64_t n_ref, int nb
 // ARRAYS (b_nnz) sends its row to the general loop.  !X4 (CELLMAP_A3_GATHER=1): round 2's entry-per-lane gather, for A/B.
 // Narrow payloads (NCH <= 16) with at most two entries per lane are held to 128 registers: two workgroups per CU.
 template <int EPL, int NCH, bool X4>
-__global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= 16 && EPL <= CM_A3_OCC4 && X4) ? 4 : 2) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
+__global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= CM_A3_OCCN && EPL <= CM_A3_OCC4 && X4) ? 4 : 2) void spgemm_sliced(const int64_t *__restrict__ indptr, const int32_t *__restrict__ cols,
                                                       const float *__restrict__ vals, int64_t nq,
                                                       const int64_t *__restrict__ bptr, const int32_t *__restrict__ bcols,
                                                       const float *__restrict__ bvals, const int32_t *__restrict__ bidx_, int nb1,
@@ -1407,7 +1410,7 @@ __global__ __launch_bounds__(512, (CM_A3_OCC4 && NCH <= 16 && EPL <= CM_A3_OCC4 
             // per array) or two groups of 4.  The LDS updates are what the gather costs (bank conflicts of ~random columns),
             // one read and one write instruction per entry of a lane: three entries per lane cover config 5's slices (longest
             // 171) with 3 + 3 instead of 4 + 4 LDS instructions per neighbour.
-            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_OCC4 && NCH <= 16 && EPL >= 2 && EPL <= CM_A3_OCC4) ? 4 / EPG : ((CM_A3_NB8 && EPL <= 2) ? 8 : 4 / EPG);   // groups per lane, entries per group, neighbours per set
+            constexpr int EPG = (EPL + 3) / 4, GE = EPL / EPG, NB = (CM_A3_OCC4 && NCH <= CM_A3_OCCN && EPL >= 2 && EPL <= CM_A3_OCC4) ? 4 / EPG : ((CM_A3_NB8 && EPL <= 2) ? 8 : 4 / EPG);   // groups per lane, entries per group, neighbours per set
             static_assert(GE * EPG == EPL && GE >= 1 && GE <= 4, "entries per lane: 1, 2, 3, 4 or 8");
             typedef int ivu_t __attribute__((ext_vector_type(GE), aligned(4)));
             typedef float fvu_t __attribute__((ext_vector_type(GE), aligned(4)));
