@@ -243,7 +243,7 @@ def test_spgemm_sliced_kernel_shapes(oracle):
     for seed, (n_ref, nq, k, n_out, density) in enumerate([(120, 300, 7, 3000, 0.6), (400, 150, 200, 900, 0.05), (60, 200, 4, 90, 0.3),
                                                             (80, 100, 3, 1000, 0.2), (100, 200, 5, 4000, 0.35), (50, 120, 4, 8000, 0.7),
                                                             (90, 150, 6, 4000, 0.17), (90, 150, 6, 4000, 0.29), (70, 130, 9, 2000, 0.1),
-                                                            (64, 90, 5, 30000, 0.03)]):
+                                                            (64, 90, 5, 30000, 0.03), (64, 90, 5, 12000, 0.05), (64, 90, 5, 16000, 0.012)]):
         rng = np.random.default_rng(90 + seed)
         indptr, cols, vals = mapping(rng, nq, n_ref, k, ragged=True)
         B = sp.random(n_ref, n_out, density=density, format="lil", dtype=np.float32, random_state=rng)
