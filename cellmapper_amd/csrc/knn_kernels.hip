@@ -1627,13 +1627,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int *q_lab = nullptr, *flag_s = nullptr, *fl_tmp = nullptr, *fl_cnt = nullptr;   // bucket of every query; sorted flag list
     // The sort only pays on data with cluster structure (bursts of candidates, bucket pruning).  When the pruning plan of an
     // earlier call on the SAME problem found the bucket balls overlapping for practically every (block, tile) pair, the sort
-    // is left out together with the pruning attempt for the next calls (3.5 ms of 243 at config 2: bucketing, the two
+    // is left out together with the pruning attempt for the next 15 calls (3.5 ms of 243 at config 2: bucketing, the two
     // permutations, the re-rank's row map); the first call of a problem always sorts (`first_call_ms` of the bench line).
     const bool same_problem = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
                               h->staged_ivf_nref == n_ref && h->staged_ivf_nq == nq;
-    if (!same_problem) h->staged_sort_skip = 0;
-    const bool sort_skip = h->staged_sort_skip > 0 && !cm_get_knobs().no_hint;
-    if (sort_skip) --h->staged_sort_skip;
+    if (!same_problem) h->staged_no_structure = false;
+    const bool sort_skip = h->staged_no_structure && h->staged_ivf_skip > 0 && !cm_get_knobs().no_hint;
+    if (sort_skip) --h->staged_ivf_skip;   // (the countdown of the suspended pruning attempt: without the sort it is not reached below)
     if (!lowp && n_ref >= 65536 && nq >= 4096 && !cm_get_knobs().no_sort && !sort_skip) {
         const int C = LS_CMAX;
         int *lab = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(n_ref, nq));
@@ -1914,7 +1914,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (ov * 8ull > full0) {   // (see the threshold after the plan)
                     ivf_try = false;
                     if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
-                    if (marks && ov * 16ull > full0 * 15ull) h->staged_sort_skip = 15;   // no structure at all: see the locality sort
+                    if (marks) h->staged_no_structure = ov * 16ull > full0 * 15ull;   // no structure at all: see the locality sort
                 }
             }
             if (ivf_try) {
