@@ -227,8 +227,7 @@ class Handle:
         dt = np.float32 if (ref.dtype == np.float32 and qry.dtype == np.float32) else np.float64
         ref = ref.astype(dt, copy=False)
         qry = qry.astype(dt, copy=False)
-        if not (np.isfinite(ref).all() and np.isfinite(qry).all()):
-            raise ValueError("Input contains NaN or infinity.")
+        # (NaN / infinity: screened by the library on the device copies -> CM_E_INVALID -> ValueError, like sklearn's check_array)
         n_ref, d = ref.shape
         nq = qry.shape[0]
         k = int(k)
@@ -425,8 +424,7 @@ class DeviceRep:
             raise ValueError(f"Representation must be 2-D (got shape {X.shape}).")
         if X.dtype not in (np.float32, np.float64):
             X = X.astype(np.float64)
-        if not np.isfinite(X).all():
-            raise ValueError("Input contains NaN or infinity.")
+        # (NaN / infinity: screened by cm_rep_create on the device copy -> ValueError; numpy's isfinite cost more than the upload)
         self.h, self.shape, self.dtype = handle, X.shape, X.dtype
         r = C.c_void_p()
         handle.call("cm_rep_create", _ptr(X), X.shape[0], X.shape[1], CM_F64 if X.dtype == np.float64 else CM_F32, C.byref(r))

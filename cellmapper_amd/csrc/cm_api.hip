@@ -10,6 +10,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sched.h>
+
 namespace {
 cm_knobs g_knobs;
 void latch_knobs() {
@@ -32,11 +34,15 @@ void latch_knobs() {
     k.no_sort = on("CELLMAP_NO_SORT"); k.no_chain = on("CELLMAP_NO_CHAIN"); k.no_centre = on("CELLMAP_NO_CENTRE");
     k.no_ivf = on("CELLMAP_NO_IVF"); k.no_hint = on("CELLMAP_NO_HINT"); k.no_perm = on("CELLMAP_NO_PERM");
     k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
+    if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
+    k.xfer_threads = (int)num("CELLMAP_XFER_THREADS", 0); k.xfer_slot_kb = (int)num("CELLMAP_XFER_SLOT_KB", 0);
+    k.xfer_min_kb = (int)num("CELLMAP_XFER_MIN_KB", 0);
     g_knobs = k;
 }
 std::mutex g_err_mu;
 std::string g_create_err;
 void a3_session_drop(cm_handle_t h);
+void xfer_drop(cm_handle_t h);
 
 // Device allocation pool of the host tier.  A released block is kept on the handle and handed to the next request it
 // fits (no more than twice the requested size); the pool is capped per handle (pool_cap, set by cm_create from the handle's
@@ -110,11 +116,149 @@ cm_status begin_call(cm_handle_t h, size_t ws_bytes) {
     return cm_ws_reserve(h, ws_bytes);
 }
 
+// ---- pinned staging ring of the host / graph tiers (round 4; OPT-IN: CELLMAP_XFER=1 | d2h) -----------------------------
+// Built on the round-3 review's reading that the host-in -> host-out gap of config 2 (0.33 s against 0.24 s) was pageable
+// PCIe traffic.  Measured (scripts/h2d_probe.hip, scripts/host_leg_probe.py, profiles/r04_host_leg.md): it was not.
+// hipMemcpy from pageable memory moves 53-56 GB/s on this platform once the driver has seen the pages (15-24 GB/s the
+// first time), the link's rate; the gap was numpy's single-threaded isfinite over both inputs (2 x 17 ms: now a device
+// kernel, nonfinite_flag) plus the copies themselves (2 x 5.5 ms).  The ring -- T host threads, each with two pinned slots
+// and a stream: memcpy chunk c into a slot, hand it to the DMA engine, fill the other slot meanwhile; D2H backwards --
+// reaches the same 54 GB/s for uploads, needs ~60 ms to set up and three uses to warm up, so uploads never go through it
+// by default.  Downloads into FRESH host arrays are where it pays (the threads fault the pages in parallel: 720 MB of
+// k-NN lists 39.6 -> 15.6 ms, the mapping matrix 16.9 -> 8.8 ms), but not enough to cover the set-up in a one-shot
+// `CellMapper.map()`: it is therefore opt-in, for processes that pull large results repeatedly.  Both directions are
+// SYNCHRONOUS: they first wait for the handle's stream (the destination may be produced or still be in use by queued
+// work) and return when the bytes have arrived -- a stronger promise than the plain asynchronous copy, so every call
+// site stays correct.  Nothing of the caller's is retained.
+struct Xfer {
+    int T = 0;
+    size_t slot = 0;
+    char *pinned = nullptr;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev;   // two per thread
+};
+static inline size_t xfer_min() { const int kb = cm_get_knobs().xfer_min_kb; return kb > 0 ? ((size_t)kb << 10) : ((size_t)8 << 20); }   // below this the plain asynchronous copy is as fast
+
+void xfer_drop(cm_handle_t h) {
+    Xfer *x = static_cast<Xfer *>(h->xfer);
+    if (!x) return;
+    for (auto s : x->st) (void)hipStreamDestroy(s);
+    for (auto e : x->ev) (void)hipEventDestroy(e);
+    if (x->pinned) (void)hipHostFree(x->pinned);
+    delete x;
+    h->xfer = nullptr;
+}
+cm_status xfer_get(cm_handle_t h, Xfer **out) {
+    if (h->xfer) { *out = static_cast<Xfer *>(h->xfer); return CM_OK; }
+    const cm_knobs &kn = cm_get_knobs();
+    int T = kn.xfer_threads > 0 ? kn.xfer_threads : 8;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) T = std::min(T, std::max(1, CPU_COUNT(&set)));
+    T = std::max(1, std::min(T, 32));
+    Xfer *x = new (std::nothrow) Xfer();
+    if (!x) CM_FAIL(h, CM_E_NOMEM, "staging ring: out of host memory");
+    x->T = T;
+    x->slot = kn.xfer_slot_kb > 0 ? ((size_t)kn.xfer_slot_kb << 10) : ((size_t)4 << 20);
+    h->xfer = x;
+    hipError_t e = hipHostMalloc((void **)&x->pinned, x->slot * 2 * (size_t)T, hipHostMallocDefault);
+    if (e != hipSuccess) { x->pinned = nullptr; xfer_drop(h); CM_FAIL(h, CM_E_NOMEM, "hipHostMalloc(staging ring) failed: %s", hipGetErrorString(e)); }
+    x->st.assign(T, nullptr); x->ev.assign(2 * T, nullptr);
+    for (auto &s : x->st) if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
+    if (e == hipSuccess) for (auto &v : x->ev) if ((e = hipEventCreateWithFlags(&v, hipEventDisableTiming)) != hipSuccess) break;
+    if (e != hipSuccess) {
+        x->st.erase(std::remove(x->st.begin(), x->st.end(), (hipStream_t) nullptr), x->st.end());
+        x->ev.erase(std::remove(x->ev.begin(), x->ev.end(), (hipEvent_t) nullptr), x->ev.end());
+        xfer_drop(h);
+        CM_FAIL(h, CM_E_HIP, "staging ring: %s", hipGetErrorString(e));
+    }
+    *out = x;
+    return CM_OK;
+}
+// rows x width bytes between a host array (row pitch hpitch) and a device array (row pitch dpitch); one chunk = whole rows
+// that fit a slot, packed densely in the slot.  to_device = false runs the pipeline backwards.
+cm_status xfer_run(cm_handle_t h, void *dev, size_t dpitch, void *host, size_t hpitch, size_t width, size_t rows, bool to_device) {
+    Xfer *x = nullptr;
+    CM_TRY(xfer_get(h, &x));
+    CM_HIP(h, hipStreamSynchronize(h->stream));
+    size_t rpc, nch;   // rows per chunk, chunks
+    const bool flat = dpitch == width && hpitch == width;
+    size_t total = rows * width;
+    if (flat) { rpc = 0; nch = (total + x->slot - 1) / x->slot; }
+    else {
+        if (width > x->slot) CM_FAIL(h, CM_E_INTERNAL, "staging ring: a row of %zu bytes does not fit a slot", width);
+        rpc = x->slot / width;
+        nch = (rows + rpc - 1) / rpc;
+    }
+    const int T = (int)std::min<size_t>((size_t)x->T, nch);
+    std::vector<hipError_t> err((size_t)T, hipSuccess);
+    auto chunk_of = [&](size_t c, size_t *r0, size_t *nr, size_t *off, size_t *len) {
+        if (flat) { *off = c * x->slot; *len = std::min(x->slot, total - *off); *r0 = 0; *nr = 1; }
+        else { *r0 = c * rpc; *nr = std::min(rpc, rows - *r0); *off = 0; *len = *nr * width; }
+    };
+    auto worker = [&](int t) {
+        hipError_t e = hipSetDevice(h->device);
+        hipStream_t st = x->st[t];
+        auto slot_of = [&](size_t i) { return x->pinned + (size_t)(2 * t + (int)(i & 1)) * x->slot; };
+        auto ev_of = [&](size_t i) { return x->ev[2 * t + (int)(i & 1)]; };
+        auto dma = [&](size_t c, size_t i) -> hipError_t {   // slot <-> device for chunk c
+            size_t r0, nr, off, len;
+            chunk_of(c, &r0, &nr, &off, &len);
+            char *p = slot_of(i);
+            hipError_t q;
+            if (flat) q = to_device ? hipMemcpyAsync((char *)dev + off, p, len, hipMemcpyHostToDevice, st)
+                                    : hipMemcpyAsync(p, (const char *)dev + off, len, hipMemcpyDeviceToHost, st);
+            else if (dpitch == width) q = to_device ? hipMemcpyAsync((char *)dev + r0 * dpitch, p, len, hipMemcpyHostToDevice, st)
+                                                    : hipMemcpyAsync(p, (const char *)dev + r0 * dpitch, len, hipMemcpyDeviceToHost, st);
+            else q = to_device ? hipMemcpy2DAsync((char *)dev + r0 * dpitch, dpitch, p, width, width, nr, hipMemcpyHostToDevice, st)
+                               : hipMemcpy2DAsync(p, width, (const char *)dev + r0 * dpitch, dpitch, width, nr, hipMemcpyDeviceToHost, st);
+            if (q == hipSuccess) q = hipEventRecord(ev_of(i), st);
+            return q;
+        };
+        auto host_copy = [&](size_t c, size_t i) {   // caller's array <-> slot for chunk c
+            size_t r0, nr, off, len;
+            chunk_of(c, &r0, &nr, &off, &len);
+            char *p = slot_of(i);
+            if (flat) { if (to_device) memcpy(p, (const char *)host + off, len); else memcpy((char *)host + off, p, len); }
+            else for (size_t r = 0; r < nr; ++r) {
+                if (to_device) memcpy(p + r * width, (const char *)host + (r0 + r) * hpitch, width);
+                else memcpy((char *)host + (r0 + r) * hpitch, p + r * width, width);
+            }
+        };
+        size_t i = 0;
+        if (to_device) {
+            for (size_t c = (size_t)t; c < nch && e == hipSuccess; c += (size_t)T, ++i) {
+                if (i >= 2) e = hipEventSynchronize(ev_of(i));   // the DMA that last read this slot
+                if (e != hipSuccess) break;
+                host_copy(c, i);
+                e = dma(c, i);
+            }
+        } else {
+            if ((size_t)t < nch && e == hipSuccess) e = dma((size_t)t, 0);
+            for (size_t c = (size_t)t; c < nch && e == hipSuccess; c += (size_t)T, ++i) {
+                if (c + (size_t)T < nch) e = dma(c + (size_t)T, i + 1);   // next chunk into the other slot
+                if (e == hipSuccess) e = hipEventSynchronize(ev_of(i));
+                if (e == hipSuccess) host_copy(c, i);
+            }
+        }
+        const hipError_t e2 = hipStreamSynchronize(st);
+        err[(size_t)t] = e != hipSuccess ? e : e2;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &w : th) w.join();
+    for (int t = 0; t < T; ++t)
+        if (err[(size_t)t] != hipSuccess) CM_FAIL(h, CM_E_HIP, "staged %s copy failed: %s", to_device ? "host-to-device" : "device-to-host", hipGetErrorString(err[(size_t)t]));
+    return CM_OK;
+}
+
 cm_status h2d(cm_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (bytes >= xfer_min() && cm_get_knobs().xfer_mode >= 2) return xfer_run(h, dst, bytes, const_cast<void *>(src), bytes, bytes, 1, true);
     if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     return CM_OK;
 }
 cm_status d2h(cm_handle_t h, void *dst, const void *src, size_t bytes) {
+    if (bytes >= xfer_min() && cm_get_knobs().xfer_mode >= 1) return xfer_run(h, const_cast<void *>(src), bytes, dst, bytes, bytes, 1, false);
     if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     return CM_OK;
 }
@@ -161,6 +305,40 @@ size_t device_budget(cm_handle_t h, long long knob_mb) {
     (void)h;
     return budget;
 }
+
+// NaN / infinity screen of an uploaded array (sklearn's check_array raises ValueError on such input before any search,
+// knn.py:429-440 -> sklearn:utils/validation.py): one pass over the device copy (16-byte loads; 300 MB in ~0.1 ms) instead of
+// numpy's single-threaded isfinite over the host array (17 ms per 300 MB: it was a third of the host-tier overhead).
+__global__ __launch_bounds__(256) void nonfinite_flag(const uint4 *__restrict__ x, size_t n16, const unsigned char *__restrict__ tail,
+                                                      int n_tail_elems, int is_f64, int *__restrict__ flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = x[i];
+        if (is_f64) bad |= ((v.y & 0x7ff00000u) == 0x7ff00000u) | ((v.w & 0x7ff00000u) == 0x7ff00000u);
+        else bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+                    ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail_elems) {   // the last < 16 bytes
+        if (is_f64) bad |= (reinterpret_cast<const uint2 *>(tail)[threadIdx.x].y & 0x7ff00000u) == 0x7ff00000u;
+        else bad |= (reinterpret_cast<const unsigned *>(tail)[threadIdx.x] & 0x7f800000u) == 0x7f800000u;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+// enqueue the screen of `bytes` of device memory at d_x (16-byte aligned) on the handle's stream; the verdict lands in
+// pinned word `slot` of the handle (read it after the next synchronisation)
+cm_status nonfinite_enqueue(cm_handle_t h, const void *d_x, size_t bytes, int dtype, int *d_flag, int slot) {
+    const size_t es = dtype == CM_F64 ? 8 : 4;
+    const size_t n16 = bytes / 16;
+    const int n_tail = (int)((bytes - 16 * n16) / es);
+    CM_HIP(h, hipMemsetAsync(d_flag, 0, 4, h->stream));
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 4096);
+    hipLaunchKernelGGL(nonfinite_flag, dim3(grid), dim3(256), 0, h->stream, (const uint4 *)d_x, n16, (const unsigned char *)d_x + 16 * n16, n_tail,
+                       dtype == CM_F64 ? 1 : 0, d_flag);
+    CM_HIP(h, hipGetLastError());
+    CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + slot, d_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    return CM_OK;
+}
+#define CM_NONFINITE_MSG "Input contains NaN or infinity."
 
 // param for the graph kernel from the distances (device), honouring the reference's global statistics
 cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, int kernel, double *d_m3,
@@ -273,6 +451,7 @@ cm_status cm_destroy(cm_handle_t h) {
     if (h->ws) (void)hipFree(h->ws);
     a3_session_drop(h);
     pool_drop(h);
+    xfer_drop(h);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     for (int i = 0; i < 2; ++i) if (h->tile_ev[i]) (void)hipEventDestroy(h->tile_ev[i]);
     if (h->d_nflag_pinned) (void)hipHostFree(h->d_nflag_pinned);
@@ -519,11 +698,19 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     CM_TRY(dd.alloc(h, des * chunk * k));
     CM_TRY(di.alloc(h, 8 * (size_t)chunk * k));
     CM_TRY(h2d(h, dref.p, ref, es * n_ref * d));
+    // NaN / infinity screen of both inputs on their device copies (ValueError upstream: sklearn's check_array)
+    DevBuf dflag;
+    CM_TRY(dflag.alloc(h, 256));
+    h->d_nflag_pinned[12] = h->d_nflag_pinned[13] = 0;
+    CM_TRY(nonfinite_enqueue(h, dref.p, es * n_ref * d, dtype, dflag.as<int>(), 12));
     int64_t nflag = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         int64_t nqc = std::min<int64_t>(chunk, nq - q0);
         h->ws_off = 0;
         CM_TRY(h2d(h, dq.p, (const char *)qry + es * q0 * d, es * nqc * d));
+        CM_TRY(nonfinite_enqueue(h, dq.p, es * nqc * d, dtype, dflag.as<int>() + 1, 13));
+        CM_TRY(sync(h));
+        if (h->d_nflag_pinned[12] || h->d_nflag_pinned[13]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
         CM_TRY(cm_knn_run(h, dref.p, n_ref, dq.p, nqc, d, dtype, k, metric, form, 0, 0, dd.p, di.as<int64_t>()));
         CM_TRY(d2h(h, (char *)out_dist + des * q0 * k, dd.p, des * nqc * k));
         CM_TRY(d2h(h, out_idx + q0 * k, di.p, 8 * (size_t)nqc * k));
@@ -1037,9 +1224,22 @@ cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int3
         CM_TRY(begin_call(hs[i], 0));
         CM_TRY(r->bufs[i].alloc(hs[i], bytes));
         CM_TRY(h2d(hs[i], r->bufs[i].p, X, bytes));
-        return sync(hs[i]);
+        if (i == 0) {   // NaN / infinity screen on the device copy (the host-side check it replaces cost more than the upload)
+            int *d_flag = (int *)cm_ws_alloc(hs[i], 256);
+            if (!d_flag) CM_FAIL(hs[i], CM_E_NOMEM, "rep: device workspace exhausted");
+            hs[i]->d_nflag_pinned[12] = 0;
+            CM_TRY(nonfinite_enqueue(hs[i], r->bufs[i].p, bytes, dtype, d_flag, 12));
+        }
+        CM_TRY(sync(hs[i]));
+        if (i == 0 && hs[i]->d_nflag_pinned[12]) CM_FAIL(hs[i], CM_E_INVALID, CM_NONFINITE_MSG);
+        return CM_OK;
     });
-    if (rc != CM_OK) { delete r; return rc; }
+    if (rc != CM_OK) {
+        for (auto &b : r->bufs) { if (b.owner) (void)hipSetDevice(b.owner->device); b.release(); }
+        (void)hipSetDevice(h->device);
+        delete r;
+        return rc;
+    }
     *out = r;
     return CM_OK;
 }

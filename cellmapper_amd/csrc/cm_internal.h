@@ -22,6 +22,8 @@ struct cm_knobs {
     long long pool_mb = -1;      // CELLMAP_POOL_MB: cap of the per-handle device allocation pool
     bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,
          no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false;
+    int xfer_mode = 0;           // CELLMAP_XFER: 0 / unset = plain hipMemcpyAsync, "d2h" = large downloads through the pinned staging ring, 1 = both directions
+    int xfer_threads = 0, xfer_slot_kb = 0, xfer_min_kb = 0;   // CELLMAP_XFER_THREADS / _SLOT_KB / _MIN_KB: staging ring geometry and the size from which it is used (0 = default: 8 threads, 4 MB slots, 8 MB)
 };
 const cm_knobs &cm_get_knobs();
 
@@ -56,6 +58,7 @@ struct cm_handle_s {
     std::vector<std::pair<size_t, void *>> pool;
     size_t pool_bytes = 0;
     size_t pool_cap = 0;   // bytes the pool may keep: min(an eighth of THIS device's memory, 32 GB), or CELLMAP_POOL_MB (cm_create)
+    void *xfer = nullptr;   // pinned staging ring for large host <-> device copies (opaque: cm_api.hip, created on first use)
     hipStream_t copy_stream = nullptr;   // D2H of finished output tiles while the next tile is computed (host tier)
     hipEvent_t tile_ev[2] = {nullptr, nullptr};
     // multi-device handle (cm_create_multi): the OTHER GPUs' contexts, owned by this handle.  The handle itself is the

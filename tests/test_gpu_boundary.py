@@ -556,3 +556,66 @@ def test_shared_device_graph_is_not_silently_remapped(oracle):
     np.testing.assert_allclose(query.obsm["X_umap_pred"], o["obsm_pred"], rtol=1e-5, atol=1e-6)   # gaussian weights, not equal
     after = cm.mapping_matrix
     assert np.array_equal(after.indices, before.indices) and np.array_equal(after.data, before.data)
+
+
+# ---- round 4: NaN / infinity screen on the device copies, pinned staging ring of the host tier -------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_input_raises_value_error_like_sklearn(dtype, bad):
+    """sklearn's check_array rejects NaN / infinity before any search (knn.py:429-440); here the screen runs on the
+    uploaded copy (cm_rep_create / cm_knn), first, last (sub-16-byte tail) and middle elements, either side."""
+    from cellmapper_amd import Neighbors, _native
+
+    rng = np.random.default_rng(5)
+    ref = rng.standard_normal((301, 7)).astype(dtype)   # 301 * 7 elements: not a multiple of 16 bytes in float32
+    qry = rng.standard_normal((33, 7)).astype(dtype)
+    h = _native.default_handle()
+    d0, i0 = h.knn(ref, qry, 5)
+    assert np.isfinite(d0).all()
+    for side in ("ref", "qry"):
+        for pos in ((0, 0), (-1, -1), (17, 3)):
+            r, q = ref.copy(), qry.copy()
+            (r if side == "ref" else q)[pos] = bad
+            with pytest.raises(ValueError, match="NaN or infinity"):
+                h.knn(r, q, 5)
+            with pytest.raises(ValueError, match="NaN or infinity"):
+                Neighbors(r, q).compute_neighbors(n_neighbors=5, only_yx=True)
+    d1, i1 = h.knn(ref, qry, 5)   # the handle keeps working after a rejected call
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+
+
+def test_staging_ring_moves_the_same_bytes(monkeypatch, oracle):
+    """Opt-in (CELLMAP_XFER=1) large host <-> device copies go through the pinned staging ring (cm_api.hip: xfer_run); forced here for small
+    arrays with several chunks per thread, odd sizes and both directions: results equal the plain-copy path bit for bit."""
+    from cellmapper_amd import _native
+
+    rng = np.random.default_rng(11)
+    ref = rng.standard_normal((20011, 50)).astype(np.float32)
+    qry = rng.standard_normal((3001, 50)).astype(np.float32)
+    codes = rng.integers(0, 9, ref.shape[0]).astype(np.int32)
+    B = rng.random((ref.shape[0], 37), dtype=np.float32)
+    outs = []
+    for ring in (False, True):
+        if ring:
+            monkeypatch.setenv("CELLMAP_XFER", "1")
+            monkeypatch.setenv("CELLMAP_XFER_MIN_KB", "1"); monkeypatch.setenv("CELLMAP_XFER_SLOT_KB", "96")
+            monkeypatch.setenv("CELLMAP_XFER_THREADS", "3")
+        else:
+            monkeypatch.delenv("CELLMAP_XFER", raising=False)
+        _native.reload_knobs()
+        h = _native.Handle(0)
+        xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
+        g = _native.DeviceGraph(h, xr, yr, 15)
+        dist, idx = g.fetch_knn()
+        g.mapping("gaussian")
+        ip, cc, vv = g.fetch_mapping()
+        code, conf = g.label_vote(codes, 9)
+        lay = g.spmm_dense(B)
+        d2, i2 = h.knn(ref, qry, 15)
+        outs.append((dist, idx, ip, cc, vv, code, conf, lay, d2, i2))
+        g.close(); xr.close(); yr.close(); h.close()
+        monkeypatch.delenv("CELLMAP_XFER", raising=False)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    o = oracle.knn_euclidean(ref, qry, 15)
+    assert np.array_equal(outs[1][1], o[1]) and np.array_equal(outs[1][0], o[0])
