@@ -34,6 +34,7 @@ void latch_knobs() {
     k.no_sort = on("CELLMAP_NO_SORT"); k.no_chain = on("CELLMAP_NO_CHAIN"); k.no_centre = on("CELLMAP_NO_CENTRE");
     k.no_ivf = on("CELLMAP_NO_IVF"); k.no_hint = on("CELLMAP_NO_HINT"); k.no_perm = on("CELLMAP_NO_PERM");
     k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
+    k.no_pretest = on("CELLMAP_NO_PRETEST"); k.no_preload = on("CELLMAP_NO_PRELOAD");
     if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
     k.xfer_threads = (int)num("CELLMAP_XFER_THREADS", 0); k.xfer_slot_kb = (int)num("CELLMAP_XFER_SLOT_KB", 0);
     k.xfer_min_kb = (int)num("CELLMAP_XFER_MIN_KB", 0);
@@ -359,6 +360,7 @@ cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d
 }  // namespace
 
 const cm_knobs &cm_get_knobs() { return g_knobs; }
+static __global__ void add_offset_i64_touch() {}   // (preload of this translation unit's kernels: cm_create)
 
 void cm_mark(cm_handle_t h, int which) {
     if (!h->profiling || which < 0 || which >= CM_N_STAGE_EVENTS) return;
@@ -427,6 +429,12 @@ cm_status cm_create(int device, cm_handle_t *out) {
         size_t free_b = 0, total_b = 0;
         h->pool_cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? std::min<size_t>(total_b / 8, (size_t)32 << 30) : ((size_t)8 << 30);
         if (cm_get_knobs().pool_mb >= 0) h->pool_cap = (size_t)cm_get_knobs().pool_mb << 20;
+    }
+    if (!cm_get_knobs().no_preload) {   // load the hot path's code objects now, not inside the first call
+        cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_graph(h->stream);
+        hipLaunchKernelGGL(add_offset_i64_touch, dim3(1), dim3(64), 0, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGetLastError();
     }
     *out = h;
     return CM_OK;

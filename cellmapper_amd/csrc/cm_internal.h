@@ -21,7 +21,9 @@ struct cm_knobs {
     long long spmm_budget_mb = -1, spgemm_budget_mb = -1;   // CELLMAP_SPMM_BUDGET_MB / CELLMAP_SPGEMM_BUDGET_MB: device budget of the streaming host tiers
     long long pool_mb = -1;      // CELLMAP_POOL_MB: cap of the per-handle device allocation pool
     bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,
-         no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false;
+         no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false,
+         no_pretest = false,     // CELLMAP_NO_PRETEST: skip the structure pre-test of the staged search (always sort, gate and pilot)
+         no_preload = false;     // CELLMAP_NO_PRELOAD: cm_create does not load the hot path's code objects ahead of the first call
     int xfer_mode = 0;           // CELLMAP_XFER: 0 / unset = plain hipMemcpyAsync, "d2h" = large downloads through the pinned staging ring, 1 = both directions
     int xfer_threads = 0, xfer_slot_kb = 0, xfer_min_kb = 0;   // CELLMAP_XFER_THREADS / _SLOT_KB / _MIN_KB: staging ring geometry and the size from which it is used (0 = default: 8 threads, 4 MB slots, 8 MB)
 };
@@ -45,8 +47,6 @@ struct cm_handle_s {
     // staged search: the filter level that certified most queries on the previous call with this (d, k, metric); lets
     // repeated calls on similar data skip the pilot (a stale hint only costs time: the ladder still escalates)
     int staged_hint_level = 0, staged_hint_d = 0, staged_hint_k = 0, staged_hint_metric = 0;
-    bool staged_no_structure = false;  // the last pruning plan of this problem found no cluster structure at all: while the pruning
-                                       // attempt is suspended (staged_ivf_skip) the locality sort is left out too
     int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay ...
     int64_t staged_ivf_nref = 0, staged_ivf_nq = 0;   // ... on a problem of these sizes
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)
@@ -93,6 +93,12 @@ void cm_mark(cm_handle_t h, int which);
         cm_status _s = (expr);           \
         if (_s != CM_OK) return _s;      \
     } while (0)
+
+// ---- code-object preload: one empty launch per hot-path translation unit (cm_create) ----
+void cm_preload_knn(hipStream_t st);
+void cm_preload_q4(hipStream_t st);
+void cm_preload_f16(hipStream_t st);
+void cm_preload_graph(hipStream_t st);
 
 // ---- workspace ----
 cm_status cm_ws_reserve(cm_handle_t h, size_t bytes);  // may reallocate: call BEFORE launching work that uses ws

@@ -2019,3 +2019,8 @@ cm_status cm_expr_metrics_run(cm_handle_t h, const float *d_a, const float *d_b,
 size_t cm_expr_metrics_ws_bytes(int64_t n, int64_t G) {
     return cm_align(sizeof(double) * (size_t)expr_chunks(n) * G * EX_N1) + 2 * cm_align(sizeof(double) * (size_t)G * EX_N1) + 4096;
 }
+
+// code-object preload (cm_create): one empty launch makes the runtime load this translation unit's kernels onto the
+// device ahead of the first real call (the load used to land inside the first call's stage times)
+static __global__ void cm_touch_graph() {}
+void cm_preload_graph(hipStream_t st) { hipLaunchKernelGGL(cm_touch_graph, dim3(1), dim3(64), 0, st); }

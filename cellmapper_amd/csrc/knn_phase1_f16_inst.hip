@@ -84,3 +84,8 @@ cm_status cm_p1f16w_launch(cm_handle_t h, int grid, size_t lds, const cmk2::P1Ar
     if (a.nprod < 3) CM_FAIL(h, CM_E_INTERNAL, "phase1/f16w: only the three-product level is instantiated");
     return launch_f16w<true>(h, grid, lds, a);
 }
+
+// code-object preload (cm_create): one empty launch makes the runtime load this translation unit's kernels onto the
+// device ahead of the first real call (the load used to land inside the first call's stage times)
+static __global__ void cm_touch_f16() {}
+void cm_preload_f16(hipStream_t st) { hipLaunchKernelGGL(cm_touch_f16, dim3(1), dim3(64), 0, st); }

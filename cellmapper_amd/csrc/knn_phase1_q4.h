@@ -217,6 +217,15 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             float T_[5], U_[2], tot_ = INFINITY;                                                               \
             const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
             _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s) {                                               \
+                if (CM2Q_EXP & 128) {   /* timing probe: the same flops as two 16x16x32 (four 16x16 tiles x two k-steps per chain) */ \
+                    const int ta_ = (s & 1) * 2; const bool first_ = s < 2;                                          \
+                    f32x4 u0_ = {acc[j][4 * ta_], acc[j][4 * ta_ + 1], acc[j][4 * ta_ + 2], acc[j][4 * ta_ + 3]}; \
+                    f32x4 u1_ = {acc[j][4 * ta_ + 4], acc[j][4 * ta_ + 5], acc[j][4 * ta_ + 6], acc[j][4 * ta_ + 7]}; \
+                    const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                    \
+                    u0_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[s], qh[j][s], first_ ? z4_ : u0_, 0, 0, 0); \
+                    u1_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[s ^ 1], qh[j][s], first_ ? z4_ : u1_, 0, 0, 0); \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { acc[j][4 * ta_ + e_] = u0_[e_]; acc[j][4 * ta_ + 4 + e_] = u1_[e_]; } \
+                } else                                                                                         \
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CUR[s], qh[j][s], s == 0 ? zero_ : acc[j], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
                 if (j == 0 && !(CM2Q_EXP & 4)) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \

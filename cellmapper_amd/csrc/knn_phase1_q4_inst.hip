@@ -19,3 +19,8 @@ cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, cons
     if (a.dbg) return KSTEPS == 4 ? launch_q4<4, true>(h, grid, lds, a) : launch_q4<2, true>(h, grid, lds, a);
     return KSTEPS == 4 ? launch_q4<4, false>(h, grid, lds, a) : launch_q4<2, false>(h, grid, lds, a);
 }
+
+// code-object preload (cm_create): one empty launch makes the runtime load this translation unit's kernels onto the
+// device ahead of the first real call (the load used to land inside the first call's stage times)
+static __global__ void cm_touch_q4() {}
+void cm_preload_q4(hipStream_t st) { hipLaunchKernelGGL(cm_touch_q4, dim3(1), dim3(64), 0, st); }
