@@ -38,7 +38,7 @@ EXPORTS = [
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
-    "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16",
+    "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16", "cm_debug_mfma_f16_k32",
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
     "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
     "cm_graph_mapping", "cm_graph_mapping_fetch", "cm_graph_label_vote", "cm_graph_spmm_dense", "cm_graph_spmm_csr_nnz",
@@ -103,6 +103,7 @@ def load_library():
         lib.cm_expression_metrics.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
         lib.cm_expression_metrics_dev.argtypes = [vp, vp, vp, i64, i64, vp, i32, i32, vp]
         lib.cm_debug_mfma_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+        lib.cm_debug_mfma_f16_k32.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         lib.cm_rep_create.argtypes = [vp, vp, i64, i32, i32, C.POINTER(vp)]
         lib.cm_rep_destroy.argtypes = [vp, vp]
         lib.cm_graph_knn.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]

@@ -21,6 +21,7 @@ void latch_knobs() {
     k.dbg = (int)num("CELLMAP_DBG", 0);
     k.filter_products = (int)num("CELLMAP_FILTER_PRODUCTS", 0);
     k.q4 = (int)num("CELLMAP_Q4", 1);
+    k.r16 = (int)num("CELLMAP_R16", 0);
     k.slack = (int)num("CELLMAP_SLACK", -1);
     if (const char *e = getenv("CELLMAP_PHASE1")) k.phase1 = !strcmp(e, "f32") ? 1 : (!strcmp(e, "f16") ? 2 : (!strcmp(e, "direct") ? 3 : 0));
     k.spgemm_ct = (int)num("CELLMAP_SPGEMM_CT", 0);
@@ -431,7 +432,7 @@ cm_status cm_create(int device, cm_handle_t *out) {
         if (cm_get_knobs().pool_mb >= 0) h->pool_cap = (size_t)cm_get_knobs().pool_mb << 20;
     }
     if (!cm_get_knobs().no_preload) {   // load the hot path's code objects now, not inside the first call
-        cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_graph(h->stream);
+        cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_r16(h->stream); cm_preload_graph(h->stream);
         hipLaunchKernelGGL(add_offset_i64_touch, dim3(1), dim3(64), 0, h->stream);
         (void)hipStreamSynchronize(h->stream);
         (void)hipGetLastError();
@@ -1295,6 +1296,9 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
     size_t P = std::min(hs.size(), std::min(ref->bufs.size(), qry->bufs.size()));
     // reference shards need room for k neighbours and enough rows to be worth a launch; float32 cosine keeps the one-device
     // arithmetic (sklearn's float32 distances)
+    // ... and the merge ranks at most CM_MERGE_NCMAX = parts x k entries per query: a large k uses fewer devices (k = 97 on an
+    // 8-GPU node: 7; k > 384: one) instead of failing after every shard has been searched
+    P = std::min<size_t>(P, (size_t)std::max(1, CM_MERGE_NCMAX / k));
     if (g->dist_is_f32 || ref->n < (int64_t)P * 4096 || ref->n < (int64_t)P * k || qry->n < 1024) P = 1;
     cm_status rc = CM_OK;
     if (P == 1) {
@@ -1696,6 +1700,46 @@ __global__ __launch_bounds__(64) void debug_mfma_f16(const _Float16 *__restrict_
     for (int r = 0; r < 16; ++r) D[p * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + c] = acc[r];
 }
 }  // namespace
+
+// the same for v_mfma_f32_16x16x32_f16 (knn_cand_f16r): D = A(16x32) * B(32x16) + C(16x16) per problem and chain step
+namespace {
+typedef float dbg_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void debug_mfma_f16_k32(const _Float16 *__restrict__ A, const _Float16 *__restrict__ B,
+                                                         const float *__restrict__ C, float *__restrict__ D, int chain) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const int64_t p = blockIdx.x;
+    dbg_f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = C[p * 256 + (4 * g + r) * 16 + c];
+    for (int s = 0; s < chain; ++s) {
+        dbg_half8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[e] = A[((p * chain + s) * 16 + c) * 32 + 8 * g + e];      // A[row c][k = 8 g + e]
+            b[e] = B[((p * chain + s) * 32 + 8 * g + e) * 16 + c];      // B[k = 8 g + e][col c]
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[p * 256 + (4 * g + r) * 16 + c] = acc[r];
+}
+}  // namespace
+
+cm_status cm_debug_mfma_f16_k32(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
+                                int32_t chain) {
+    if (!h) return CM_E_INVALID;
+    if (n < 1 || chain < 1) CM_FAIL(h, CM_E_INVALID, "debug mfma: bad shape");
+    CM_TRY(begin_call(h, 0));
+    DevBuf da, db, dc, dd;
+    const size_t na = (size_t)n * chain * 512 * 2, nc = (size_t)n * 256 * 4;
+    CM_TRY(da.alloc(h, na)); CM_TRY(db.alloc(h, na)); CM_TRY(dc.alloc(h, nc)); CM_TRY(dd.alloc(h, nc));
+    CM_TRY(h2d(h, da.p, a, na)); CM_TRY(h2d(h, db.p, b, na)); CM_TRY(h2d(h, dc.p, c, nc));
+    hipLaunchKernelGGL(debug_mfma_f16_k32, dim3((unsigned)n), dim3(64), 0, h->stream, da.as<_Float16>(), db.as<_Float16>(),
+                       dc.as<float>(), dd.as<float>(), (int)chain);
+    CM_HIP(h, hipGetLastError());
+    CM_TRY(d2h(h, d, dd.p, nc));
+    return sync(h);
+}
 
 cm_status cm_debug_mfma_f16(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
                             int32_t chain) {

@@ -12,6 +12,8 @@
 struct cm_knobs {
     int dbg = 0;                 // CELLMAP_DBG: in-kernel timing modes / counters of the filter kernels
     int filter_products = 0;     // CELLMAP_FILTER_PRODUCTS: pin the filter level (no escalation)
+    int r16 = 0;                 // CELLMAP_R16: 1 = the 128-queries-per-wave stage at K = 64 runs on the 16x16x32 re-tile (knn_cand_f16r) instead of the 32x32x16 kernel
+                                 // (knn_cand_f16q); measured level to 1 % slower in production form (profiles/r04_mfma_shape_probe.md), so off by default
     int q4 = 1;                  // CELLMAP_Q4: 0 never / 1 by size / 2 wherever instantiated: the four-accumulator filter
     int slack = -1;              // CELLMAP_SLACK: candidate slack override
     int phase1 = 0;              // CELLMAP_PHASE1: 1 f32, 2 f16, 3 direct
@@ -98,6 +100,7 @@ void cm_mark(cm_handle_t h, int which);
 void cm_preload_knn(hipStream_t st);
 void cm_preload_q4(hipStream_t st);
 void cm_preload_f16(hipStream_t st);
+void cm_preload_r16(hipStream_t st);
 void cm_preload_graph(hipStream_t st);
 
 // ---- workspace ----
@@ -106,6 +109,7 @@ void *cm_ws_alloc(cm_handle_t h, size_t bytes);         // 256-B aligned carve; 
 static inline size_t cm_align(size_t b) { return (b + 255) & ~size_t(255); }
 
 // ---- k-NN (knn_kernels.hip) ----
+constexpr int CM_MERGE_NCMAX = 768;   // most (parts x k) entries the shard merge ranks per query (knn_merge's LDS lists)
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric = CM_METRIC_EUCLIDEAN);
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,

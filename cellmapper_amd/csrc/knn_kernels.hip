@@ -16,6 +16,7 @@
 cm_status cm_p1_wide_launch(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds, const float *Q, const float *R, int tps, int n_tiles,
                             int Kc, int C, int *cand, float *cthr);   // knn_phase1_inst.hip (group 3): K-chunked kernel, d >= 260
 cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1f16r_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);   // 16x16x32 re-tile (knn_phase1_r16.h)
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
@@ -45,7 +46,7 @@ constexpr int RR_NCMAX = 1024;  // max candidates per query handled by the re-ra
 constexpr int RR_DMAX = 260;   // LDS stride (doubles) of a staged query row for d <= 259; wider rows: q_stride(d)
 constexpr int KNN_DMAX = 2047;  // widest embedding (round 3: the K-chunked f32 filter, knn_cand_mfma_wide)
 __host__ __device__ constexpr int q_stride(int d) { return d < RR_DMAX ? RR_DMAX : ((d + 4) & ~3); }
-constexpr int MG_NCMAX = 768;   // max nparts*k in the shard merge
+constexpr int MG_NCMAX = CM_MERGE_NCMAX;   // max nparts*k in the shard merge
 constexpr int FB_CAP = 4096;    // fallback collection capacity per query (a query with more rows inside its bound goes to knn_fallback_select)
 constexpr int OVF_CAP = 16384;  // queries the selection kernel takes per call (more: the call fails loudly)
 constexpr int FB_BLOCKS = 1024;
@@ -1941,6 +1942,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps;
             }
         }
+        // Round 4: under CELLMAP_R16=1 the 128-queries-per-wave stage at K = 64 runs on the 16x16x32 MFMA shape
+        // (knn_phase1_r16.h: built, exact, measured level with the 32x32x16 kernel -- profiles/r04_mfma_shape_probe.md -- and
+        // therefore not the default).  Its chains are 2 instructions of 32 products each: see c_eps below.
+        const bool r16 = q4 && p2.KSTEPS == 4 && cm_get_knobs().r16 != 0;
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
         if (img != want) {
@@ -1994,6 +1999,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             c_split = (level == 1 ? 2.0f : (level == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f;
             // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
             c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
+            // 16x16x32 shape: 32 products per instruction, K / 32 instructions per chain -- the same device-validated model
+            // with 32 in place of 16 (tests/test_gpu_parity.py::test_mfma_f16_accumulation_bound checks both shapes), doubled
+            if (r16) c_eps = 2.0f * (float)(32 + 2 * (p2.KSTEPS / 2)) * 5.9604645e-8f + 8.4e-7f;
         }
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
@@ -2013,6 +2021,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 y.nqb = (int)(p2.nq_pad / cmk2::QBQ);
                 const int res = h->n_cu > 0 ? h->n_cu : 256;
                 const int64_t nw = (int64_t)y.nqb * y.S;
+                if (r16) return cm_p1f16r_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
                 return cm_p1f16q_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
             }
             return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);

@@ -391,6 +391,10 @@ cm_status cm_project(cm_handle_t h, const void *X, const int64_t *indptr, const 
  * accumulation arithmetic the phase-1 error bound assumes (no reference counterpart). */
 cm_status cm_debug_mfma_f16(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
                             int32_t chain);
+/* the same for v_mfma_f32_16x16x32_f16 (the 16x16x32 re-tile of the hi*hi filter): n problems D = A(16x32) * B(32x16) + C(16x16),
+ * `chain` k-steps accumulated; a: [n][chain][16][32] fp16 bits, b: [n][chain][32][16], c / d: [n][16][16] float32 */
+cm_status cm_debug_mfma_f16_k32(cm_handle_t h, const uint16_t *a, const uint16_t *b, const float *c, float *d, int32_t n,
+                                int32_t chain);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,11 @@
+#!/bin/bash
+# build_r16_variant.sh NAME "-DCM2R_EXP=.. ..."  ->  build_ab/lib_NAME.so: the library with only the 16x16x32 filter kernel
+# (knn_phase1_r16_inst.hip) compiled under extra defines; every other object is linked from csrc/build (make first).
+set -e
+name=$1; flags=$2
+cd "$(dirname "$0")/../cellmapper_amd/csrc"
+mkdir -p ../../build_ab /tmp/cm_r16var
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I. -I../../include $flags -c knn_phase1_r16_inst.hip -o /tmp/cm_r16var/r16_$name.o
+objs=$(ls build/*.o | grep -v knn_phase1_r16_inst.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o ../../build_ab/lib_$name.so $objs /tmp/cm_r16var/r16_$name.o
+echo built build_ab/lib_$name.so

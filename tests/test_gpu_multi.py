@@ -113,3 +113,22 @@ def test_drop_in_class_on_a_multi_device_handle(problem, monkeypatch):
     assert np.array_equal(res[0][0], res[1][0])
     assert (res[0][1] == res[1][1]).mean() > 0.9995
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6)
+
+
+def test_large_k_uses_fewer_devices_instead_of_failing(problem, oracle):
+    """The shard merge ranks at most 768 = parts x k entries per query (round-3 advisor finding: n_neighbors >= 97 on an
+    8-GPU node failed AFTER every shard had been searched).  The graph now spreads over min(devices, 768 // k) parts."""
+    from cellmapper_amd import _native
+
+    ref, qry = problem
+    h = _native.Handle(devices=[0] * 4)
+    xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
+    for k, parts in ((15, 4), (192, 4), (193, 3), (300, 2), (400, 1)):
+        g = _native.DeviceGraph(h, xr, yr, k)
+        assert g.n_devices == parts, (k, g.n_devices)
+        dist, idx = g.fetch_knn()
+        if k in (193, 400):
+            o = oracle.knn_euclidean(ref, qry[:64], k)
+            assert np.array_equal(idx[:64], o[1]) and np.array_equal(dist[:64], o[0])
+        g.close()
+    xr.close(); yr.close(); h.close()

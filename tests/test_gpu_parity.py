@@ -481,15 +481,18 @@ def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtyp
     (150000, 3000, 20, 10, np.float32),     # K = 32 instantiation
     (30000, 40000, 33, 50, np.float32),     # many blocks, wide lists (K' = 75)
 ])
-def test_four_accumulator_filter_is_exact(hip, oracle, monkeypatch, n_ref, nq, d, k, dtype):
-    """knn_cand_f16q (128 queries per wave, accumulator-major chains, in-place filtering two accumulators behind the MFMAs;
-    the default for large full-set scans) forced on small problems: identical to the oracle and to the two-accumulator
-    kernel, bit for bit."""
+@pytest.mark.parametrize("r16", ["1", "0"])
+def test_four_accumulator_filter_is_exact(hip, oracle, monkeypatch, n_ref, nq, d, k, dtype, r16):
+    """The 128-queries-per-wave kernels of the hi*hi level -- knn_cand_f16r (round 4: v_mfma_f32_16x16x32_f16, four lanes and
+    four logs per query, K = 64; the default for large full-set scans) and knn_cand_f16q (32x32x16, accumulator-major
+    chains; K = 32, and K = 64 under CELLMAP_R16=0) -- forced on small problems: identical to the oracle and to the
+    two-accumulator kernel, bit for bit."""
     rng = np.random.default_rng(n_ref + d)
     ref = rng.standard_normal((n_ref, d)).astype(dtype)
     qry = rng.standard_normal((nq, d)).astype(dtype)
     monkeypatch.setenv("CELLMAP_NO_HINT", "1")
     monkeypatch.setenv("CELLMAP_Q4", "2")
+    monkeypatch.setenv("CELLMAP_R16", r16)
     dist, idx = hip.knn(ref, qry, k)
     st = hip.knn_stats()
     assert st["fallback_queries"] <= 64 and st["filter_products"] == 1, st
@@ -499,6 +502,24 @@ def test_four_accumulator_filter_is_exact(hip, oracle, monkeypatch, n_ref, nq, d
     monkeypatch.setenv("CELLMAP_Q4", "0")
     dist2, idx2 = hip.knn(ref, qry, k)
     assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+
+
+def test_r16_filter_with_long_logs_and_clusters(hip, oracle, monkeypatch):
+    """knn_cand_f16r on inputs that stress its candidate machinery: rows sorted by cluster without the scattered tile order
+    (bursts of passing values: logs fill within a tile and merge on the spot), unseeded thresholds, k large enough for
+    eight entries per lane in the merges."""
+    rng = np.random.default_rng(404)
+    d, k, n_ref, nq = 50, 60, 60000, 6000
+    cen = rng.standard_normal((12, d)) * 3.0
+    lab = np.sort(rng.integers(0, 12, n_ref))
+    ref = (cen[lab] + rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 12, nq)] + rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1"); monkeypatch.setenv("CELLMAP_Q4", "2"); monkeypatch.setenv("CELLMAP_R16", "1")
+    monkeypatch.setenv("CELLMAP_NO_PERM", "1"); monkeypatch.setenv("CELLMAP_NO_SORT", "1"); monkeypatch.setenv("CELLMAP_NO_SEED", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    od, oi = oracle.knn_euclidean(ref, qry[:800], k)
+    assert np.array_equal(idx[:800], oi) and np.array_equal(dist[:800], od), st
 
 
 def test_bucket_pruning_large_k_on_the_last_level(hip, oracle, monkeypatch):
@@ -537,13 +558,13 @@ def test_bucket_pruning_backs_off_on_unclustered_sets(hip, oracle, monkeypatch):
 def test_mfma_f16_accumulation_bound(hip):
     """The phase-1 certificate assumes that a chain of n v_mfma_f32_32x32x16_f16 instructions returns C + sum(a*b) with
     an absolute error of at most (16 + 2n) * 2^-24 * (|C| + sum|a*b|) (the library uses twice
-    that).  Check the model on this device: random operands over a wide exponent range and designed cases (tiny addends
+    that), and (round 4, knn_cand_f16r) a chain of n v_mfma_f32_16x16x32_f16 with at most (32 + 2n) * 2^-24 * the same.  Check the model on this device: random operands over a wide exponent range and designed cases (tiny addends
     next to a large one, cancellation)."""
     import ctypes as C
 
     def run(a, b, c, chain):
         d = np.empty_like(c)
-        hip.call("cm_debug_mfma_f16", a.view(np.uint16).ctypes.data_as(C.c_void_p),
+        hip.call("cm_debug_mfma_f16" if c.shape[1] == 32 else "cm_debug_mfma_f16_k32", a.view(np.uint16).ctypes.data_as(C.c_void_p),
                  b.view(np.uint16).ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
                  d.ctypes.data_as(C.c_void_p), c.shape[0], chain)
         return d
@@ -554,10 +575,20 @@ def test_mfma_f16_accumulation_bound(hip):
         exact = c64 + np.einsum("nsik,nskj->nij", a64, b64)  # products of fp16 are exact in float64
         mag = np.abs(c64) + np.einsum("nsik,nskj->nij", np.abs(a64), np.abs(b64))
         err = np.abs(d.astype(np.float64) - exact)
-        ok = err <= (16 + 2 * chain) * 2.0 ** -24 * mag + 1e-300
-        assert ok.all(), (chain, float((err / np.maximum(mag, 1e-300)).max() / 2.0 ** -24))
+        per = a.shape[3]   # products per instruction: 16 (32x32x16) or 32 (16x16x32, knn_cand_f16r: the same model with 32)
+        ok = err <= (per + 2 * chain) * 2.0 ** -24 * mag + 1e-300
+        worst[per] = max(worst.get(per, 0.0), float((err / np.maximum(mag, 1e-300)).max() / 2.0 ** -24))
+        assert ok.all(), (per, chain, float((err / np.maximum(mag, 1e-300)).max() / 2.0 ** -24))
 
+    worst = {}
     rng = np.random.default_rng(7)
+    for chain in (1, 2, 4, 6, 13):   # 16x16x32: 2 instructions per chain in knn_cand_f16r (K = 64)
+        for spread in (0, 3, 8):
+            n = 128
+            a = (rng.standard_normal((n, chain, 16, 32)) * np.exp2(rng.integers(-spread, spread + 1, (n, chain, 16, 32)))).astype(np.float16)
+            b = (rng.standard_normal((n, chain, 32, 16)) * np.exp2(rng.integers(-spread, spread + 1, (n, chain, 32, 16)))).astype(np.float16)
+            c = (rng.standard_normal((n, 16, 16)) * np.exp2(rng.integers(-4, 8, (n, 16, 16)))).astype(np.float32)
+            check(a, b, c, chain)
     for chain in (1, 4, 8, 12, 25):
         for spread in (0, 3, 8):
             n = 64
@@ -576,6 +607,16 @@ def test_mfma_f16_accumulation_bound(hip):
     a2[:, 0, :, 0] = 1.0; b2[:, 0, 0, :] = 1.0
     check(a2, b2, np.zeros((n, 32, 32), np.float32), 1)
     check(a2, b2, -np.ones((n, 32, 32), np.float32), 1)
+    # the same designed cases on the 16x16x32 shape: thirty-one / thirty-two addends of 2^-s next to one of 1.0
+    a = np.zeros((n, 1, 16, 32), np.float16); b = np.zeros((n, 1, 32, 16), np.float16)
+    for t, s in enumerate(S):
+        a[t, 0] = np.float16(2.0 ** -(s // 2)); b[t, 0] = np.float16(2.0 ** -(s - s // 2))
+    check(a, b, np.ones((n, 16, 16), np.float32), 1)
+    a2, b2 = a.copy(), b.copy()
+    a2[:, 0, :, 0] = 1.0; b2[:, 0, 0, :] = 1.0
+    check(a2, b2, np.zeros((n, 16, 16), np.float32), 1)
+    check(a2, b2, -np.ones((n, 16, 16), np.float32), 1)
+    print("worst observed error / (2^-24 * sum|terms|) per instruction shape:", worst)
 
 
 def test_cosine_matches_oracle(hip, oracle):
