@@ -265,6 +265,55 @@ def git_rev(path):
         return None
 
 
+def sha16(path):
+    import hashlib
+
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def provenance_commit(rel_path, sha):
+    """The commit profiles/PROVENANCE.json (written in the build container, committed) records for a file -- only if the
+    file on this box still has the recorded content hash; the GPU box has no git."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "PROVENANCE.json")))["files"].get(rel_path)
+        return rec["commit"] if rec and rec["sha256_16"] == sha else None
+    except Exception:
+        return None
+
+
+class StreamTimer:
+    """HIP events on the current stream at named points of every step (sharded_knn marks "search", "exchange", "merged"):
+    mean milliseconds between consecutive marks over the recorded steps."""
+
+    def __init__(self, torch):
+        self.torch, self.steps, self.cur, self.on = torch, [], None, False
+
+    def begin_step(self):
+        if self.on:
+            self.cur = []
+            self.steps.append(self.cur)
+
+    def mark(self, name):
+        if self.on and self.cur is not None:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.cur.append((name, ev))
+
+    def means(self):
+        acc, n = {}, 0
+        for st in self.steps:
+            if len(st) < 2:
+                continue
+            n += 1
+            for (na, ea), (nb, eb) in zip(st[:-1], st[1:]):
+                acc[f"{na}_to_{nb}_ms"] = acc.get(f"{na}_to_{nb}_ms", 0.0) + ea.elapsed_time(eb)
+        return {k: v / n for k, v in acc.items()} if n else {}
+
+
 # ------------------------------------------------------------------------------------- one rank -------------------
 class RunCtx:
     """What one rank knows about the run: torch / torch.distributed, its place in the 2-D layout, the exchange state."""
@@ -333,7 +382,7 @@ def parity_gate(ctx, dist_t, idx_t, code_t, conf_t, my_lo, my_hi, want_cpu_basel
     if a.metric != "euclidean":
         ns_total = min(ns_total, 256 if a.metric == "cosine" else 32)   # numpy restatements of the oracle: small samples
     elif ns_total > 256:
-        ns_total = max(256, int(ns_total * scale))
+        ns_total = max(1024 if a.config == 4 else 256, int(ns_total * scale))   # (config 4: >= 1 024 rows over all ranks)
     per = max(1, -(-ns_total // ctx.world))
     rows = sample_rows(my_lo, my_hi, per)                          # global query ids of this rank's sample
     sel = torch.from_numpy(rows - my_lo).to(dev)
@@ -464,7 +513,11 @@ def main_rank(a):
     torch.cuda.set_stream(pipe.stream)  # library kernels, torch ops and RCCL collectives share one stream
     ops = ctx.ops
 
+    timer = StreamTimer(torch)
+    ctx.state.timer = timer
+
     def step(want_graph=False):
+        timer.begin_step()
         if not use_dist:
             return pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel, want_graph=want_graph)
         r = sharded_mapping_rows(ops, dist, ref, lo, a.nref, qry, a.k, metric=a.metric, kernel=a.kernel, exchange=a.exchange,
@@ -493,6 +546,7 @@ def main_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     p1_ms, stage_acc = [], {}
+    timer.on = use_dist
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
@@ -505,13 +559,27 @@ def main_rank(a):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timer.on = False
     check_overflow()
     stages = {kk: vv / max(a.steps, 1) for kk, vv in stage_acc.items()}
+    elapsed_local = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     fb = pipe.h.knn_stats()
+    # every rank's own clocks (N > 1): filter kernel, local search, exchange collective, merge + everything behind it -- one
+    # small all-gather, so that the first multi-GPU line shows where a slow rank or a slow link sits
+    per_rank = None
+    if use_dist:
+        tm = timer.means()
+        mine = torch.tensor([float(np.mean(p1_ms)) if p1_ms else 0.0, tm.get("search_to_exchange_ms", 0.0),
+                             tm.get("exchange_to_merged_ms", 0.0), elapsed_local / max(a.steps, 1) * 1e3,
+                             float(ctx.state.sent_words) * 8.0], dtype=torch.float64, device=dev)
+        allr = ctx.gather_rows(mine.view(1, -1)) if world > 1 else mine.view(1, -1)
+        per_rank = [{"rank": r, "filter_kernel_ms": float(v[0]), "local_search_ms": float(v[1]),
+                     "exchange_and_merge_ms": float(v[2]), "ms_per_step_local": float(v[3]),
+                     "exchange_bytes_handed_to_the_collective": float(v[4])} for r, v in enumerate(allr.cpu().numpy())]
 
     result = None
     if rank == 0:
@@ -543,9 +611,17 @@ def main_rank(a):
             try:
                 tj = json.load(open(tfile))
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = {"file": "profiles/phase1_hbm_traffic.json", "file_commit": git_rev(tfile),
-                               "kernel_source_commit": git_rev(os.path.join(ROOT, "cellmapper_amd", "csrc", "knn_phase1_q4.h")),
-                               "measured_on_commit": tj.get("measured_on_commit")}
+                ksrc = tj.get("kernel_source", "cellmapper_amd/csrc/knn_phase1_q4.h")
+                ksha = sha16(os.path.join(ROOT, ksrc))
+                # content hashes, not commits: git is not installed on the GPU box.  `stale` = the counter pass was taken
+                # on a different version of the kernel's source than the one that just ran.
+                traffic_src = {"file": "profiles/phase1_hbm_traffic.json", "file_sha256_16": sha16(tfile),
+                               "file_commit": git_rev(tfile) or provenance_commit("profiles/phase1_hbm_traffic.json", sha16(tfile)),
+                               "kernel_source": ksrc, "kernel_source_sha256_16": ksha,
+                               "kernel_source_commit": git_rev(os.path.join(ROOT, ksrc)) or provenance_commit(ksrc, ksha),
+                               "measured_on_kernel_sha256_16": tj.get("measured_on_kernel_sha256_16"),
+                               "measured_on_commit": tj.get("measured_on_commit"),
+                               "stale": bool(tj.get("measured_on_kernel_sha256_16") and tj.get("measured_on_kernel_sha256_16") != ksha)}
             except Exception:
                 traffic = None
         result = {
@@ -584,6 +660,12 @@ def main_rank(a):
                          "f32_mfma_equivalent_frac": achieved / PEAK_F32_MFMA_TFLOPS},
             "stage_ms_mean": stages,
         }
+        if per_rank is not None:
+            result["per_rank"] = per_rank
+            result["per_rank_note"] = ("HIP events on each rank's stream, mean over the timed steps: local_search = the shard's "
+                                       "exact top-k (filter + re-rank), exchange_and_merge = the packed collective + the strided "
+                                       "merge; bytes = what the rank hands to the collective per step (all-to-all: its whole "
+                                       "packed buffer, own chunk included; all-gather: that x the ranks that receive it)")
     # rehearsal of the N > 1 path on a one-GPU box (--share-gpu): every rank also checks its slice of the sharded result
     # against the same queries mapped onto the FULL reference by the single-GPU pipeline (identical labels, confidences to 1e-5)
     if use_dist and (a.share_gpu or a.force_dist):

@@ -38,7 +38,7 @@ EXPORTS = [
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
-    "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16", "cm_debug_mfma_f16_k32",
+    "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16", "cm_debug_mfma_f16_k32", "cm_graph_part_info",
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
     "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
     "cm_graph_mapping", "cm_graph_mapping_fetch", "cm_graph_label_vote", "cm_graph_spmm_dense", "cm_graph_spmm_csr_nnz",
@@ -109,6 +109,7 @@ def load_library():
         lib.cm_graph_knn.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
         lib.cm_graph_destroy.argtypes = [vp, vp]
         lib.cm_graph_info.argtypes = [vp, vp, vp]
+        lib.cm_graph_part_info.argtypes = [vp, vp, i32, vp]
         lib.cm_graph_knn_fetch.argtypes = [vp, vp, vp, vp]
         lib.cm_graph_mapping.argtypes = [vp, vp, i32, dbl, vp, vp]
         lib.cm_graph_mapping_fetch.argtypes = [vp, vp, vp, vp, vp]
@@ -480,6 +481,18 @@ class DeviceGraph:
         out = np.zeros(8, np.int64)
         self.h.call("cm_graph_info", self._g, _ptr(out))
         return int(out[7])
+
+    def parts(self):
+        """One record per part (multi-device handle: the query slice a device owns): which reference rows that device
+        searched, how many bytes of either representation it holds, how the per-shard lists were exchanged."""
+        out = []
+        for p in range(self.n_devices):
+            v = np.zeros(8, np.int64)
+            self.h.call("cm_graph_part_info", self._g, int(p), _ptr(v))
+            out.append(dict(device=int(v[0]), q_lo=int(v[1]), nq=int(v[2]), ref_lo=int(v[3]), ref_rows=int(v[4]),
+                            ref_bytes=int(v[5]), qry_bytes=int(v[6]), exchange=("peer copies", "host-staged")[int(v[7]) % 10],
+                            self_check=("not run", "passed", "FAILED")[int(v[7]) // 10]))
+        return out
 
     def fetch_knn(self):
         dist = np.empty((self.nq, self.k), self.dist_dtype)

@@ -35,6 +35,7 @@ void latch_knobs() {
     k.no_sort = on("CELLMAP_NO_SORT"); k.no_chain = on("CELLMAP_NO_CHAIN"); k.no_centre = on("CELLMAP_NO_CENTRE");
     k.no_ivf = on("CELLMAP_NO_IVF"); k.no_hint = on("CELLMAP_NO_HINT"); k.no_perm = on("CELLMAP_NO_PERM");
     k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
+    k.multi_staged = on("CELLMAP_MULTI_STAGED"); k.multi_check_fail = on("CELLMAP_MULTI_CHECK_FAIL");
     k.no_pretest = on("CELLMAP_NO_PRETEST"); k.no_preload = on("CELLMAP_NO_PRELOAD");
     if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
     k.xfer_threads = (int)num("CELLMAP_XFER_THREADS", 0); k.xfer_slot_kb = (int)num("CELLMAP_XFER_SLOT_KB", 0);
@@ -1092,13 +1093,21 @@ cm_status cm_spmm_csr(cm_handle_t h, const int64_t *indptr, const int32_t *cols,
 // a graph is a list of PARTS, part p = the query rows [q_lo, q_lo + nq) whose merged lists, mapping-matrix rows and transfers
 // device p owns.  A single-device graph is one part on the handle itself and runs exactly the code it always ran.
 struct cm_rep_s {
-    std::vector<DevBuf> bufs;   // one copy per device of the handle (index 0: the handle's own device)
+    // bufs[0]: the WHOLE representation on the handle's own device (the one PCIe upload).  bufs[i], i > 0 (multi-device
+    // handle): rows [lo[i], lo[i] + rows[i]) on peer device i, copied from bufs[0] over xGMI when a graph first needs them --
+    // a reference shard for a rep used as the reference, every row for one that is queried (round 4; round 3 uploaded the
+    // whole array to every device over PCIe whether or not the graph sharded at all)
+    std::vector<DevBuf> bufs;
+    std::vector<int64_t> lo, rows;
     int64_t n = 0;
     int32_t d = 0, dtype = 0;
+    size_t row_bytes() const { return (size_t)d * (dtype == CM_F64 ? 8 : 4); }
 };
 struct GraphPart {
     cm_handle_t h = nullptr;
     int64_t q_lo = 0, nq = 0;
+    int64_t ref_lo = 0, ref_rows = 0;              // reference rows this part's device searched (multi-device: its shard)
+    int64_t ref_bytes = 0, qry_bytes = 0;          // bytes of the two representations resident on the part's device for the search
     DevBuf dist, idx;              // k-NN result as the reference returns it: float64 (float32: cosine on float32 input), int64
     DevBuf indptr, cols, vals;     // row-normalised mapping matrix rows of the part, canonical CSR (indptr starts at 0)
     int64_t nnz = 0;
@@ -1108,6 +1117,8 @@ struct GraphPart {
 struct cm_graph_s {
     int64_t nq = 0, n_ref = 0;
     int32_t k = 0, metric = 0, dist_is_f32 = 0;
+    int32_t exchange_route = 0;   // multi-device: 0 = peer copies (hipMemcpyPeerAsync), 1 = staged through host memory
+    int32_t self_check = 0;       // multi-device: 0 = not run for this graph, 1 = passed, 2 = FAILED (the graph was re-exchanged through host memory)
     std::vector<GraphPart> parts;
     bool has_map = false;
     int64_t nnz = 0;
@@ -1190,6 +1201,30 @@ cm_status part_dist64(GraphPart &p, const cm_graph_s *g, const double **out) {
     *out = w;
     return CM_OK;
 }
+// rows [lo, lo + rows) of a representation on device index i of the handle (0 = the handle's own device, which holds
+// everything); a peer gets them from device 0 by ONE peer copy (xGMI where the platform has it) the first time a graph
+// needs them, and keeps them for the following graphs (the four-graph mode searches a representation several times)
+cm_status rep_ensure(cm_handle_t h, const std::vector<cm_handle_t> &hs, cm_rep_s *r, size_t i, int64_t lo, int64_t rows, const void **out,
+                     int64_t *resident_bytes) {
+    if (i == 0) { *out = (const char *)r->bufs[0].p + (size_t)lo * r->row_bytes(); *resident_bytes = (int64_t)((size_t)r->n * r->row_bytes()); return CM_OK; }
+    cm_handle_t hp = hs[i];
+    if (!(r->bufs[i].p && r->lo[i] <= lo && lo + rows <= r->lo[i] + r->rows[i])) {
+        CM_HIP(hp, hipSetDevice(hp->device));
+        // a range that does not cover the request is replaced by the union with what the device already holds when the two
+        // touch (a shard growing into "everything"), otherwise by the request
+        int64_t nlo = lo, nhi = lo + rows;
+        if (r->bufs[i].p && r->rows[i] > 0) { nlo = std::min(nlo, r->lo[i]); nhi = std::max(nhi, r->lo[i] + r->rows[i]); }
+        r->bufs[i].release();
+        CM_TRY(r->bufs[i].alloc(hp, (size_t)(nhi - nlo) * r->row_bytes()));
+        CM_HIP(hp, hipMemcpyPeerAsync(r->bufs[i].p, hp->device, (const char *)r->bufs[0].p + (size_t)nlo * r->row_bytes(), h->device,
+                                      (size_t)(nhi - nlo) * r->row_bytes(), hp->stream));
+        CM_TRY(sync(hp));
+        r->lo[i] = nlo; r->rows[i] = nhi - nlo;
+    }
+    *out = (const char *)r->bufs[i].p + (size_t)(lo - r->lo[i]) * r->row_bytes();
+    *resident_bytes = (int64_t)((size_t)r->rows[i] * r->row_bytes());
+    return CM_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1226,29 +1261,30 @@ cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int3
     cm_rep_s *r = new (std::nothrow) cm_rep_s();
     if (!r) CM_FAIL(h, CM_E_NOMEM, "rep: out of host memory");
     r->n = n; r->d = d; r->dtype = dtype;
-    const auto hs = handle_devices(h);
-    r->bufs = std::vector<DevBuf>(hs.size());
-    const size_t bytes = (size_t)n * d * (dtype == CM_F64 ? 8 : 4);
-    cm_status rc = for_parts(h, hs.size(), hs, [&](size_t i) -> cm_status {   // every device over its own PCIe link
-        CM_TRY(begin_call(hs[i], 0));
-        CM_TRY(r->bufs[i].alloc(hs[i], bytes));
-        CM_TRY(h2d(hs[i], r->bufs[i].p, X, bytes));
-        if (i == 0) {   // NaN / infinity screen on the device copy (the host-side check it replaces cost more than the upload)
-            int *d_flag = (int *)cm_ws_alloc(hs[i], 256);
-            if (!d_flag) CM_FAIL(hs[i], CM_E_NOMEM, "rep: device workspace exhausted");
-            hs[i]->d_nflag_pinned[12] = 0;
-            CM_TRY(nonfinite_enqueue(hs[i], r->bufs[i].p, bytes, dtype, d_flag, 12));
-        }
-        CM_TRY(sync(hs[i]));
-        if (i == 0 && hs[i]->d_nflag_pinned[12]) CM_FAIL(hs[i], CM_E_INVALID, CM_NONFINITE_MSG);
+    const size_t ndev = 1 + h->peers.size();
+    r->bufs = std::vector<DevBuf>(ndev);
+    r->lo.assign(ndev, 0); r->rows.assign(ndev, 0);
+    const size_t bytes = (size_t)n * r->row_bytes();
+    // ONE upload, to the handle's own device; peers get what a graph needs from there (rep_ensure)
+    cm_status rc = [&]() -> cm_status {
+        CM_TRY(begin_call(h, 0));
+        CM_TRY(r->bufs[0].alloc(h, bytes));
+        CM_TRY(h2d(h, r->bufs[0].p, X, bytes));
+        // NaN / infinity screen on the device copy (the host-side check it replaces cost more than the upload)
+        int *d_flag = (int *)cm_ws_alloc(h, 256);
+        if (!d_flag) CM_FAIL(h, CM_E_NOMEM, "rep: device workspace exhausted");
+        h->d_nflag_pinned[12] = 0;
+        CM_TRY(nonfinite_enqueue(h, r->bufs[0].p, bytes, dtype, d_flag, 12));
+        CM_TRY(sync(h));
+        if (h->d_nflag_pinned[12]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
         return CM_OK;
-    });
+    }();
     if (rc != CM_OK) {
-        for (auto &b : r->bufs) { if (b.owner) (void)hipSetDevice(b.owner->device); b.release(); }
-        (void)hipSetDevice(h->device);
+        r->bufs[0].release();
         delete r;
         return rc;
     }
+    r->rows[0] = n;
     *out = r;
     return CM_OK;
 }
@@ -1262,8 +1298,9 @@ cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r) {
     return CM_OK;
 }
 
-// one device's search of the queries [0, nq) against reference rows [r_lo, r_lo + n_rows) of its copy of the representation
-static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const DevBuf &refbuf, const cm_rep_s *qry, const DevBuf &qbuf, int64_t r_lo,
+// one device's search of the queries [0, nq) against reference rows [r_lo, r_lo + n_rows): d_refrows points at row r_lo on
+// the device, d_qry at query 0
+static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const void *d_refrows, const cm_rep_s *qry, const void *d_qry, int64_t r_lo,
                           int64_t n_rows, int32_t k, int32_t metric, int32_t form, int32_t flags, void *d_dist, size_t des, int64_t *d_idx,
                           int64_t *nflag_out) {
     const int64_t QCH = 1 << 21;   // queries in chunks of 2^21 rows like the host tier (bounds the workspace)
@@ -1272,7 +1309,7 @@ static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const DevBuf &ref
     for (int64_t q0 = 0; q0 < qry->n; q0 += QCH) {
         const int64_t nqc = std::min<int64_t>(QCH, qry->n - q0);
         CM_TRY(begin_call(hp, cm_knn_ws_bytes(n_rows, nqc, ref->d, k, ref->dtype, metric)));
-        CM_TRY(cm_knn_run(hp, (const char *)refbuf.p + es * r_lo * ref->d, n_rows, (const char *)qbuf.p + es * q0 * ref->d, nqc, ref->d,
+        CM_TRY(cm_knn_run(hp, d_refrows, n_rows, (const char *)d_qry + es * q0 * ref->d, nqc, ref->d,
                           ref->dtype, k, metric, form, r_lo, flags, (char *)d_dist + des * q0 * k, d_idx + q0 * k));
         CM_TRY(sync(hp));
         CM_TRY(check_fallback_overflow(hp));
@@ -1281,6 +1318,40 @@ static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const DevBuf &ref
     *nflag_out = nflag;
     return CM_OK;
 }
+
+namespace {
+// Exchange + merge of one part (query slice p.q_lo .. + p.nq) of a multi-device graph: the slice's two planes of every
+// device's packed buffer are brought to the part's device -- by peer copies (route 0: xGMI where peer access exists), or
+// staged through host memory (route 1: platforms without peer access, and the fall-back of the self-check) -- and merged
+// by (value, global index), the rule of a single search.
+cm_status part_exchange_merge(cm_handle_t hp_i, const std::vector<cm_handle_t> &hp, const std::vector<DevBuf> &packed, size_t nk, int route,
+                              const cm_graph_s *g, int64_t q_lo, int64_t nq_p, double *d_out_dist, int64_t *d_out_idx) {
+    const size_t P = hp.size(), pk = (size_t)nq_p * g->k;
+    CM_TRY(begin_call(hp_i, 0));
+    DevBuf recv;
+    CM_TRY(recv.alloc(hp_i, 16 * pk * P));
+    std::vector<char> stage;
+    if (route == 1) stage.resize(16 * pk);
+    for (size_t r = 0; r < P; ++r) {
+        char *dst = (char *)recv.p + 16 * pk * r;
+        const char *src = (const char *)packed[r].p + 8 * (size_t)q_lo * g->k;
+        if (route == 0) {
+            CM_HIP(hp_i, hipMemcpyPeerAsync(dst, hp_i->device, src, hp[r]->device, 8 * pk, hp_i->stream));
+            CM_HIP(hp_i, hipMemcpyPeerAsync(dst + 8 * pk, hp_i->device, src + 8 * nk, hp[r]->device, 8 * pk, hp_i->stream));
+        } else {
+            // (plain synchronous copies on the owning devices: this route is the exception)
+            CM_HIP(hp_i, hipSetDevice(hp[r]->device));
+            CM_HIP(hp_i, hipMemcpy(stage.data(), src, 8 * pk, hipMemcpyDeviceToHost));
+            CM_HIP(hp_i, hipMemcpy(stage.data() + 8 * pk, src + 8 * nk, 8 * pk, hipMemcpyDeviceToHost));
+            CM_HIP(hp_i, hipSetDevice(hp_i->device));
+            CM_HIP(hp_i, hipMemcpy(dst, stage.data(), 16 * pk, hipMemcpyHostToDevice));
+        }
+    }
+    CM_TRY(cm_knn_merge_run(hp_i, recv.as<double>(), recv.as<int64_t>() + pk, (int)P, (int64_t)(2 * pk), nq_p, g->k,
+                            g->metric == CM_METRIC_EUCLIDEAN ? 1 : 0, d_out_dist, d_out_idx));
+    return sync(hp_i);
+}
+}  // namespace
 
 cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int32_t metric, int32_t form, cm_graph_t *out) {
     if (!h) return CM_E_INVALID;
@@ -1305,32 +1376,55 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
         g->parts.resize(1);
         GraphPart &p = g->parts[0];
         p.h = h; p.q_lo = 0; p.nq = g->nq;
+        p.ref_lo = 0; p.ref_rows = ref->n;
+        p.ref_bytes = (int64_t)((size_t)ref->n * ref->row_bytes()); p.qry_bytes = (int64_t)((size_t)qry->n * qry->row_bytes());
         const size_t nk = (size_t)g->nq * k, des = g->dist_is_f32 ? 4 : 8;
         rc = p.dist.alloc(h, des * nk);
         if (rc == CM_OK) rc = p.idx.alloc(h, 8 * nk);
         int64_t nflag = 0;
-        if (rc == CM_OK) rc = part_knn(h, ref, ref->bufs[0], qry, qry->bufs[0], 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag);
+        if (rc == CM_OK) rc = part_knn(h, ref, ref->bufs[0].p, qry, qry->bufs[0].p, 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag);
         h->knn_stats[0] = nflag;
     } else {
         // 1. every device: all queries against its reference shard, GLOBAL indices, float64 ranking values (squared for
-        //    euclidean) into a packed buffer [2][nq][k] of 8-byte words -- the layout of the RCCL path's exchange buffer
+        //    euclidean) into a packed buffer [2][nq][k] of 8-byte words -- the layout of the RCCL path's exchange buffer.
+        //    Device i holds reference rows [lo_i, hi_i) only (+ every query): rep_ensure
         g->parts.resize(P);
         std::vector<DevBuf> packed(P);
         std::vector<int64_t> nflag(P, 0);
         const size_t nk = (size_t)g->nq * k;
         const std::vector<cm_handle_t> hp(hs.begin(), hs.begin() + P);
         rc = for_parts(h, P, hp, [&](size_t i) -> cm_status {
+            GraphPart &p = g->parts[i];
             const int64_t base = ref->n / (int64_t)P, extra = ref->n % (int64_t)P;
             const int64_t lo = (int64_t)i * base + std::min<int64_t>((int64_t)i, extra), rows = base + ((int64_t)i < extra ? 1 : 0);
             CM_TRY(begin_call(hp[i], 0));
+            const void *d_refrows = nullptr, *d_q = nullptr;
+            // (a representation searched against itself -- the reference's xx / yy graphs -- needs every row on every device)
+            if (ref == qry) {
+                CM_TRY(rep_ensure(h, hs, qry, i, 0, qry->n, &d_q, &p.qry_bytes));
+                d_refrows = (const char *)d_q + (size_t)lo * ref->row_bytes();
+                p.ref_bytes = p.qry_bytes;
+            } else {
+                CM_TRY(rep_ensure(h, hs, ref, i, lo, rows, &d_refrows, &p.ref_bytes));
+                CM_TRY(rep_ensure(h, hs, qry, i, 0, qry->n, &d_q, &p.qry_bytes));
+            }
+            p.ref_lo = lo; p.ref_rows = rows;
             CM_TRY(packed[i].alloc(hp[i], 16 * nk));
-            return part_knn(hp[i], ref, ref->bufs[i], qry, qry->bufs[i], lo, rows, k, metric, form, CM_KNN_SQUARED | CM_KNN_F64_OUT,
+            return part_knn(hp[i], ref, d_refrows, qry, d_q, lo, rows, k, metric, form, CM_KNN_SQUARED | CM_KNN_F64_OUT,
                             packed[i].p, 8, packed[i].as<int64_t>() + nk, &nflag[i]);
         });
-        // 2. + 3. device p owns query slice p: it pulls that slice of every device's two planes with peer copies (xGMI) and
-        //    merges the P lists per query by (value, global index) -- the rule of a single search, so the result is exact
-        if (rc == CM_OK)
-            rc = for_parts(h, P, hp, [&](size_t i) -> cm_status {
+        // 2. + 3. device p owns query slice p: it brings that slice of every device's two planes over (peer copies, or
+        //    staged through the host where the platform has no peer access) and merges the P lists per query by
+        //    (value, global index) -- the rule of a single search, so the result is exact
+        int route = cm_get_knobs().multi_staged ? 1 : 0;
+        for (size_t a = 0; a < P && !route; ++a)
+            for (size_t b = 0; b < P && !route; ++b) {
+                int can = 1;
+                if (hp[a]->device != hp[b]->device && (hipDeviceCanAccessPeer(&can, hp[a]->device, hp[b]->device) != hipSuccess || !can)) route = 1;
+            }
+        (void)hipGetLastError();
+        auto exchange_all = [&](int rt) {
+            return for_parts(h, P, hp, [&](size_t i) -> cm_status {
                 GraphPart &p = g->parts[i];
                 const int64_t base = g->nq / (int64_t)P, extra = g->nq % (int64_t)P;
                 p.h = hp[i];
@@ -1338,20 +1432,46 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
                 p.nq = base + ((int64_t)i < extra ? 1 : 0);
                 const size_t pk = (size_t)p.nq * k;
                 CM_TRY(begin_call(hp[i], 0));
-                DevBuf recv;
-                CM_TRY(recv.alloc(hp[i], 16 * pk * P));
                 CM_TRY(p.dist.alloc(hp[i], 8 * pk));
                 CM_TRY(p.idx.alloc(hp[i], 8 * pk));
-                for (size_t r = 0; r < P; ++r) {
-                    char *dst = (char *)recv.p + 16 * pk * r;
-                    const char *src = (const char *)packed[r].p + 8 * (size_t)p.q_lo * k;
-                    CM_HIP(hp[i], hipMemcpyPeerAsync(dst, hp[i]->device, src, hp[r]->device, 8 * pk, hp[i]->stream));
-                    CM_HIP(hp[i], hipMemcpyPeerAsync(dst + 8 * pk, hp[i]->device, src + 8 * nk, hp[r]->device, 8 * pk, hp[i]->stream));
-                }
-                CM_TRY(cm_knn_merge_run(hp[i], recv.as<double>(), recv.as<int64_t>() + pk, (int)P, (int64_t)(2 * pk), p.nq, k,
-                                        metric == CM_METRIC_EUCLIDEAN ? 1 : 0, p.dist.as<double>(), p.idx.as<int64_t>()));
-                return sync(hp[i]);
+                return part_exchange_merge(hp[i], hp, packed, nk, rt, g, p.q_lo, p.nq, p.dist.as<double>(), p.idx.as<int64_t>());
             });
+        };
+        if (rc == CM_OK) rc = exchange_all(route);
+        // Self-check of the peer-copy route, once per handle (the first graph that shards): query slice 0 is exchanged a
+        // second time through host memory and merged again on devices[0]; the two results must agree bit for bit.  A
+        // mismatch (or the test knob) re-runs the whole exchange through the host and keeps the handle on that route.
+        if (rc == CM_OK && route == 0 && !h->multi_checked) {
+            GraphPart &p0 = g->parts[0];
+            const size_t pk = (size_t)p0.nq * k;
+            DevBuf cd, ci;
+            std::vector<char> a1(16 * pk), a2(16 * pk);
+            rc = begin_call(h, 0);
+            if (rc == CM_OK) rc = cd.alloc(h, 8 * pk);
+            if (rc == CM_OK) rc = ci.alloc(h, 8 * pk);
+            if (rc == CM_OK) rc = part_exchange_merge(h, hp, packed, nk, 1, g, p0.q_lo, p0.nq, cd.as<double>(), ci.as<int64_t>());
+            if (rc == CM_OK) {
+                rc = d2h(h, a1.data(), p0.dist.p, 8 * pk);
+                if (rc == CM_OK) rc = d2h(h, a1.data() + 8 * pk, p0.idx.p, 8 * pk);
+                if (rc == CM_OK) rc = d2h(h, a2.data(), cd.p, 8 * pk);
+                if (rc == CM_OK) rc = d2h(h, a2.data() + 8 * pk, ci.p, 8 * pk);
+                if (rc == CM_OK) rc = sync(h);
+            }
+            if (rc == CM_OK) {
+                const bool same = memcmp(a1.data(), a2.data(), 16 * pk) == 0 && !cm_get_knobs().multi_check_fail;
+                h->multi_checked = true;
+                g->self_check = same ? 1 : 2;
+                if (!same) {
+                    h->multi_route_staged = true;
+                    route = 1;
+                    rc = exchange_all(1);
+                }
+            }
+        } else if (h->multi_route_staged && route == 0 && rc == CM_OK) {
+            route = 1;   // (an earlier graph's self-check failed: this handle stays on the host-staged route)
+            rc = exchange_all(1);
+        }
+        g->exchange_route = route;
         for (size_t i = 0; i < P; ++i) { (void)hipSetDevice(hp[i]->device); packed[i].release(); }
         (void)hipSetDevice(h->device);
         int64_t tot = 0;
@@ -1601,6 +1721,16 @@ cm_status cm_graph_spmm_csr(cm_handle_t h, cm_graph_t g, const int64_t *b_indptr
         return spmm_csr_fill_impl(p.h, nullptr, nullptr, nullptr, p.indptr.as<int64_t>(), p.cols.as<int32_t>(), p.vals.as<float>(), p.nq, b_indptr,
                                   b_cols, b_vals, n_ref, n_out, loc.data(), out_cols + base, out_vals + base);
     });
+}
+
+cm_status cm_graph_part_info(cm_handle_t h, cm_graph_t g, int32_t part, int64_t out[8]) {
+    if (!h) return CM_E_INVALID;
+    if (!g || !out || part < 0 || (size_t)part >= g->parts.size()) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
+    const GraphPart &p = g->parts[(size_t)part];
+    out[0] = p.h ? p.h->device : -1; out[1] = p.q_lo; out[2] = p.nq; out[3] = p.ref_lo; out[4] = p.ref_rows;
+    out[5] = p.ref_bytes; out[6] = p.qry_bytes;
+    out[7] = g->exchange_route + 10 * g->self_check;   // route (0 peer copies, 1 host-staged) + 10 x self-check (0 not run, 1 passed, 2 failed)
+    return CM_OK;
 }
 
 cm_status cm_graph_info(cm_handle_t h, cm_graph_t g, int64_t out[8]) {

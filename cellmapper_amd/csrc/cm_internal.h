@@ -24,6 +24,8 @@ struct cm_knobs {
     long long pool_mb = -1;      // CELLMAP_POOL_MB: cap of the per-handle device allocation pool
     bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,
          no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false,
+         multi_staged = false,       // CELLMAP_MULTI_STAGED: multi-device graphs exchange their lists through host memory (the route of platforms without peer access)
+         multi_check_fail = false,   // CELLMAP_MULTI_CHECK_FAIL: the exchange self-check of a multi-device handle reports a mismatch (tests the fall-back)
          no_pretest = false,     // CELLMAP_NO_PRETEST: skip the structure pre-test of the staged search (always sort, gate and pilot)
          no_preload = false;     // CELLMAP_NO_PRELOAD: cm_create does not load the hot path's code objects ahead of the first call
     int xfer_mode = 0;           // CELLMAP_XFER: 0 / unset = plain hipMemcpyAsync, "d2h" = large downloads through the pinned staging ring, 1 = both directions
@@ -67,6 +69,8 @@ struct cm_handle_s {
     // first device's context, so every single-device entry point keeps working on it unchanged; the graph tier
     // (cm_rep_* / cm_graph_*) and cm_knn spread over all of them (cm_api.hip, "multi-device").
     std::vector<cm_handle_s *> peers;
+    bool multi_checked = false;        // the peer-copy exchange of this handle has been checked against the host-staged route (first sharded graph)
+    bool multi_route_staged = false;   // ... and failed: every later graph exchanges through host memory
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;
     hipEvent_t ev[CM_N_STAGE_EVENTS] = {};

@@ -205,6 +205,12 @@ class ExchangeState:
         self.checked = False
         self.note = None                 # why the run left the requested exchange (None = it did not)
         self.pad_words = None            # world all-gather: words per rank (max over the query groups)
+        self.timer = None                # optional: an object with .mark(name) (bench.py: stream events around the exchange)
+        self.sent_words = 0              # 8-byte words this rank handed to the last exchange collective (own chunk included)
+
+    def mark(self, name: str):
+        if self.timer is not None:
+            self.timer.mark(name)
 
     def describe(self):
         return {"requested": self.requested, "used": self.mode, "self_check": ("passed" if self.checked and self.note is None
@@ -247,7 +253,12 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
     nq = qry.shape[0]
     per = (nq + world - 1) // world
     nq_pad = per * world
+    if state is not None:
+        state.mark("search")
     send = ops.local_knn_packed(ref_shard, qry, k, metric, shard_lo, nq_pad)   # [2, nq_pad, k] 8-byte words
+    if state is not None:
+        state.mark("exchange")
+        state.sent_words = 2 * nq_pad * k * (world if (state.mode != "alltoall") else 1)
     pk = per * k
     if world == 1:
         dist, idx = ops.merge_packed(send, 1, 2 * nq_pad * k, 0, nq_pad * k, nq, k, metric)
@@ -302,6 +313,8 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
         dist, idx = _world_allgather_merge(ops, dist_mod, send, group, world, rank, nq_pad, k, n_mine, metric, st)
     else:
         raise ValueError(f"unknown exchange '{mode}'")
+    if state is not None:
+        state.mark("merged")
     return dist, idx, (q_lo, q_hi)
 
 

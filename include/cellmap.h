@@ -298,6 +298,15 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
 cm_status cm_graph_destroy(cm_handle_t h, cm_graph_t g);
 /* out[0] = query rows, [1] = reference rows, [2] = k, [3] = metric, [4] = 1 if distances are float32 (cosine on float32
  * input), [5] = 1 once the mapping matrix exists, [6] = its nnz, [7] = 0 */
+/* One part of a graph (multi-device handle: part p = the query slice device p owns; single device: part 0):
+ * out = { device, first query row, query rows, first reference row searched on that device, reference rows searched,
+ *         bytes of the reference representation resident on the device, bytes of the query representation resident,
+ *         exchange route (0 peer copies, 1 staged through host memory) + 10 x self-check (0 not run for this graph, 1 passed,
+ *         2 failed: the lists were re-exchanged through host memory) }.
+ * Round 4: a representation is uploaded ONCE (to devices[0], cm_rep_create); device p > 0 receives reference rows
+ * [lo_p, hi_p) and every query row by a peer copy when a graph first shards ("partition reference rows
+ * contiguously across G GPUs"; the reference itself is pinned to one device, knn.py:412,420). */
+cm_status cm_graph_part_info(cm_handle_t h, cm_graph_t g, int32_t part, int64_t out[8]);
 cm_status cm_graph_info(cm_handle_t h, cm_graph_t g, int64_t out[8]);
 /* distances float64 [nq,k] (float32 when info[4]), indices int64 [nq,k] */
 cm_status cm_graph_knn_fetch(cm_handle_t h, cm_graph_t g, void *out_dist, int64_t *out_idx);

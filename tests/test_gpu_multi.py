@@ -132,3 +132,49 @@ def test_large_k_uses_fewer_devices_instead_of_failing(problem, oracle):
             assert np.array_equal(idx[:64], o[1]) and np.array_equal(dist[:64], o[0])
         g.close()
     xr.close(); yr.close(); h.close()
+
+
+def test_reference_rows_are_sharded_over_the_devices_and_the_exchange_checks_itself(problem, oracle, monkeypatch):
+    """Round 4 (review item 5): a representation goes up ONCE; peer device p receives reference rows [lo_p, hi_p) + every
+    query by a peer copy when the graph shards; the first sharded graph of a handle re-exchanges query slice 0 through
+    host memory and compares; a failed check (test knob) or a platform without peer access (test knob) takes the
+    host-staged route -- with the same results."""
+    from cellmapper_amd import _native
+
+    ref, qry = problem
+    k = 15
+    o = oracle.knn_euclidean(ref, qry, k)
+    rb, qb = ref.shape[1] * 4, qry.shape[1] * 4
+    for knob, route, check in ((None, "peer copies", "passed"), ("CELLMAP_MULTI_STAGED", "host-staged", "not run"),
+                               ("CELLMAP_MULTI_CHECK_FAIL", "host-staged", "FAILED")):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        _native.reload_knobs()
+        h = _native.Handle(devices=[0, 0, 0])
+        xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
+        g = _native.DeviceGraph(h, xr, yr, k)
+        parts = g.parts()
+        assert len(parts) == 3 and [p["exchange"] for p in parts] == [route] * 3 and parts[0]["self_check"] == check, parts
+        assert sum(p["ref_rows"] for p in parts) == ref.shape[0] and [p["ref_lo"] for p in parts] == [0, 6667, 13334]
+        assert parts[0]["ref_bytes"] == ref.shape[0] * rb                       # devices[0] holds the one upload
+        assert [p["ref_bytes"] for p in parts[1:]] == [p["ref_rows"] * rb for p in parts[1:]]   # peers: their shard only
+        assert all(p["qry_bytes"] == qry.shape[0] * qb for p in parts)
+        dist, idx = g.fetch_knn()
+        assert np.array_equal(idx, o[1]) and np.array_equal(dist, o[0])
+        g2 = _native.DeviceGraph(h, xr, yr, k)                                   # the check runs once per handle
+        assert g2.parts()[0]["self_check"] == "not run" and g2.parts()[0]["exchange"] == route
+        d2, i2 = g2.fetch_knn()
+        assert np.array_equal(i2, idx) and np.array_equal(d2, dist)
+        gs = _native.DeviceGraph(h, xr, xr, k)                                   # a self-join needs every row on every device
+        assert all(p["ref_bytes"] == ref.shape[0] * rb for p in gs.parts())
+        os_ = oracle.knn_euclidean(ref, ref[:200], k)
+        ds, is_ = gs.fetch_knn()
+        assert np.array_equal(is_[:200], os_[1]) and np.array_equal(ds[:200], os_[0])
+        small = _native.DeviceGraph(h, _native.DeviceRep(h, ref[:3000]), yr, k)  # too small to shard: devices[0] alone, no peer copies
+        assert small.n_devices == 1
+        for x in (g, g2, gs, small):
+            x.close()
+        xr.close(); yr.close(); h.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    _native.reload_knobs()
