@@ -433,7 +433,7 @@ cm_status cm_create(int device, cm_handle_t *out) {
         if (cm_get_knobs().pool_mb >= 0) h->pool_cap = (size_t)cm_get_knobs().pool_mb << 20;
     }
     if (!cm_get_knobs().no_preload) {   // load the hot path's code objects now, not inside the first call
-        cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_r16(h->stream); cm_preload_graph(h->stream);
+        cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_graph(h->stream);   // (the opt-in / K = 128 kernels load on first use)
         hipLaunchKernelGGL(add_offset_i64_touch, dim3(1), dim3(64), 0, h->stream);
         (void)hipStreamSynchronize(h->stream);
         (void)hipGetLastError();
