@@ -7,13 +7,21 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
 #include <sched.h>
 
 namespace {
-cm_knobs g_knobs;
+// The CELLMAP_* knobs: an immutable record behind an atomic pointer.  Latched ONCE by the first cm_create of the process
+// (std::call_once) and replaced as a whole by cm_reload_knobs (tests): a reader on another thread -- the per-device worker
+// threads of a multi-device handle among them -- sees the old record or the new one, never a half-written one, and creating
+// a second handle no longer changes the behaviour of a live one (round-3 advisor finding).  Superseded records are kept
+// (a few hundred bytes per reload; readers may still hold a reference).
+std::atomic<const cm_knobs *> g_knobs_ptr{nullptr};
+std::once_flag g_knobs_once;
+const cm_knobs g_knobs_default{};
 void latch_knobs() {
     cm_knobs k;
     auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return (e && *e) ? atoll(e) : dflt; };
@@ -40,7 +48,7 @@ void latch_knobs() {
     if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
     k.xfer_threads = (int)num("CELLMAP_XFER_THREADS", 0); k.xfer_slot_kb = (int)num("CELLMAP_XFER_SLOT_KB", 0);
     k.xfer_min_kb = (int)num("CELLMAP_XFER_MIN_KB", 0);
-    g_knobs = k;
+    g_knobs_ptr.store(new cm_knobs(k), std::memory_order_release);
 }
 std::mutex g_err_mu;
 std::string g_create_err;
@@ -361,7 +369,10 @@ cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d
 }
 }  // namespace
 
-const cm_knobs &cm_get_knobs() { return g_knobs; }
+const cm_knobs &cm_get_knobs() {
+    const cm_knobs *p = g_knobs_ptr.load(std::memory_order_acquire);
+    return p ? *p : g_knobs_default;
+}
 static __global__ void add_offset_i64_touch() {}   // (preload of this translation unit's kernels: cm_create)
 
 void cm_mark(cm_handle_t h, int which) {
@@ -409,7 +420,7 @@ cm_status cm_reload_knobs(void) {
 cm_status cm_create(int device, cm_handle_t *out) {
     if (!out) return CM_E_INVALID;
     *out = nullptr;
-    latch_knobs();   // the CELLMAP_* knobs are read here, never on a call path
+    std::call_once(g_knobs_once, latch_knobs);   // the CELLMAP_* knobs are read by the FIRST cm_create (and by cm_reload_knobs), never on a call path
     auto fail = [&](const char *what, hipError_t e) {
         std::lock_guard<std::mutex> g(g_err_mu);
         g_create_err = std::string(what) + ": " + hipGetErrorString(e);

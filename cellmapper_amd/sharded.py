@@ -107,6 +107,9 @@ class HipOps:
     def empty_i32(self, n, like):
         return self.t.empty((n,), dtype=self.t.int32, device=like.device)
 
+    def synchronize(self):
+        self.t.cuda.synchronize()
+
     def cat(self, parts):
         return self.t.cat(parts)
 
@@ -287,10 +290,20 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
     if mode == "alltoall":
         if state is not None and state.selfcheck and not state.checked:
             ok, err, got = True, None, None
+            # What this catches: an exchange that RETURNS wrong lists, and a call the backend REJECTS (argument validation
+            # raises synchronously and identically on every rank: the arguments are symmetric -- that is what gloo's
+            # "not implemented" and RCCL's invalid-argument checks do).  It does not make an asynchronous RCCL failure
+            # survivable: that surfaces at the synchronisation below (or in the watchdog) with the communicator already
+            # unusable, so the run then ends with the error instead of limping on -- see the timeout in bench.py.
             try:
                 got = run_alltoall()
-            except Exception as e:   # (RCCL rejects the call on every rank alike: the arguments are symmetric)
+                sync = getattr(ops, "synchronize", None)
+                if sync is not None:
+                    sync()   # surface asynchronous errors of the collective HERE, inside the try
+            except Exception as e:
                 ok, err = False, f"{type(e).__name__}: {e}"
+                if "NCCL" in str(e) or "RCCL" in str(e) or "ncclInternalError" in str(e) or "unhandled" in str(e).lower():
+                    raise   # a failed communicator cannot carry the fall-back either
             want = _world_allgather_merge(ops, dist_mod, send, group, world, rank, nq_pad, k, n_mine, metric, state)
             if ok:
                 ok = ops.equal(got[0], want[0]) and ops.equal(got[1], want[1])

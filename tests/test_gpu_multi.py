@@ -178,3 +178,29 @@ def test_reference_rows_are_sharded_over_the_devices_and_the_exchange_checks_its
         if knob:
             monkeypatch.delenv(knob)
     _native.reload_knobs()
+
+
+@pytest.mark.parametrize("metric,d", [("sqeuclidean", 24), ("manhattan", 24), ("chebyshev", 24), ("correlation", 24), ("euclidean", 2),
+                                      ("cosine", 24)])
+def test_metrics_and_the_low_d_path_through_the_sharded_merge(metric, d, oracle):
+    """The sharded merge ranks by each metric's own float64 value (no square root except euclidean); d = 2 takes the uniform
+    grid on every shard; float32 cosine keeps the one-device arithmetic (sklearn's float32 distances): one part."""
+    from cellmapper_amd import _native
+    from parity import assert_knn_parity
+
+    rng = np.random.default_rng(77 + d)
+    dtype = np.float64 if metric == "correlation" else np.float32
+    ref = (rng.standard_normal((24000, d)) + (rng.standard_normal((24000, 1)) if metric == "correlation" else 0)).astype(dtype)
+    qry = rng.standard_normal((2500, d)).astype(dtype)
+    k = 12
+    h1, hm = _native.Handle(0), _native.Handle(devices=[0, 0, 0])
+    d1, i1 = h1.knn(ref, qry, k, metric=metric)
+    xr, yr = _native.DeviceRep(hm, ref), _native.DeviceRep(hm, qry)
+    g = _native.DeviceGraph(hm, xr, yr, k, metric)
+    assert g.n_devices == (1 if metric == "cosine" else 3)
+    dm, im = g.fetch_knn()
+    if metric == "correlation":   # (stated tolerance of this metric: tests/parity.py)
+        assert_knn_parity(dm, im, d1, i1, ref, qry, metric)
+    else:
+        assert np.array_equal(im, i1) and np.array_equal(dm, d1)
+    g.close(); xr.close(); yr.close(); h1.close(); hm.close()
