@@ -86,7 +86,7 @@ def mfma_block(f, tag, kernel, what):
     t_ms = sum(kernel_ms(f"pmc_mfma_{tag}", kernel))
     gui = mf["GRBM_GUI_ACTIVE"] / 8.0
     f.write(f"## {kernel} -- {what} ({n1} launches of kernels of that family in the pass, summed: warm-up step + timed step, each a "
-            f"seed scan (`knn_cand_f16<.,1,false,4>`) + a main scan (`knn_cand_f16q` at K <= 64 / `knn_cand_f16<8,1>` at K = 128), plus the pilot)\n\n")
+            f"seed scan (`knn_cand_f16<.,1,false,4>`) + a main scan (`knn_cand_f16q` at K <= 64 / `knn_cand_f16<8,1>` at K = 128); round 4: no pilot, no sort on structure-free data)\n\n")
     f.write(f"Pass `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` (kernel time in the pass {t_ms:.1f} ms):\n\n")
     for k in sorted(mf):
         f.write(f"- {k} = {mf[k]:.6g}\n")
