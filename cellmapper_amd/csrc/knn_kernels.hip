@@ -389,6 +389,21 @@ __device__ __forceinline__ double pair_value(const double *__restrict__ q, doubl
         }
         return f32 ? (double)(float)acc : acc;
     }
+    if (metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS) {
+        // sklearn's CanberraDistance / BrayCurtisDistance `dist` (metrics/_dist_metrics.pyx.tp): float64 accumulators in
+        // coordinate order; |x_j| + |y_j| in float64; the difference in the INPUT dtype under brute force on float32 data
+        // (DistanceMetric32), whose result is rounded to float32 once more; everything float64 on the tree path (DIRECT form)
+        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double t = f32 ? (double)fabsf(__fsub_rn((float)q[c], (float)y[c])) : fabs(q[c] - (double)y[c]);
+            const double dn = __dadd_rn(fabs(q[c]), fabs((double)y[c]));
+            if (metric == CM_METRIC_CANBERRA) { if (dn > 0.0) num = __dadd_rn(num, __ddiv_rn(t, dn)); }
+            else { num = __dadd_rn(num, t); den = __dadd_rn(den, dn); }
+        }
+        const double r = metric == CM_METRIC_CANBERRA ? num : (den > 0.0 ? __ddiv_rn(num, den) : 0.0);
+        return f32 ? (double)(float)r : r;
+    }
     if (form == CM_FORM_DIRECT) {
         double acc = 0.0;
         for (int c = 0; c < d; ++c) { double t = q[c] - (double)y[c]; acc = __dadd_rn(acc, __dmul_rn(t, t)); }
@@ -567,6 +582,13 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             // the float32 rounding of the reported value (DistanceMetric32) is inside crel
             if (metric == CM_METRIC_MANHATTAN) eps = crel * big + 2.0 * dlt * (double)d;
             if (metric == CM_METRIC_CHEBYSHEV) eps = crel * big + 2.0 * dlt;
+            // Canberra: every term is a ratio in [0, 1]; float32 subtract, add and approximate divide cost <= 4 ulp per term and
+            // the running sum d more: covered by crel = (d + 4) 2^-23 relative to the value (terms are non-negative).  A float64
+            // coordinate rounded to float32 (relative 2^-24; magnitudes below 2^-100 are refused by the host) moves a term by at
+            // most ~2^-23 ABSOLUTE: d 2^-22 in all.  Bray-Curtis: numerator and denominator each move by 2^-24 of the denominator
+            // under that rounding, the ratio by <= 2^-22 absolute; the two float32 sums are inside crel.
+            if (metric == CM_METRIC_CANBERRA) eps = crel * big + (sizeof(T) == 8 ? (double)d * 2.4e-7 : 0.0);
+            if (metric == CM_METRIC_BRAYCURTIS) eps = crel * big + (sizeof(T) == 8 ? 2.4e-7 : 0.0);
             certified = sk + eps < (double)tau - eps;
         }
         if (!certified || over || (flags & CM_KNN_FORCE_FALLBACK)) {
@@ -1669,7 +1691,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                          int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
     const int bs = 256;
-    const bool lp_metric = metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV;
+    const bool lp_metric = metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
     const int path = lp_metric ? 2 : phase1_path(d, k);   // (Manhattan / Chebyshev: the VALU direct kernel is the only filter)
     // dynamic LDS of prep_rows_f16 when a block's source rows fit (64 KB without opting in): coalesced staging
     const size_t prep_lds = (size_t)bs * (d + 1) * sizeof(T) <= 64 * 1024 ? (size_t)bs * (d + 1) * sizeof(T) : 0;
@@ -2011,7 +2033,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         bool pruned = false;
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
-            const int op = lp_metric ? (metric == CM_METRIC_MANHATTAN ? 1 : 2) : 0;
+            const int op = lp_metric ? (metric == CM_METRIC_MANHATTAN ? 1 : (metric == CM_METRIC_CHEBYSHEV ? 2 : (metric == CM_METRIC_CANBERRA ? 3 : 4))) : 0;
             if (level == 4 && dl > 64) return cm_p1direct_wide_launch(h, dl, op, p2.grid, p2.lds, x);
             if (level == 4 && lp_metric) return cm_p1lowd_metric_launch(h, dl, op, p2.grid, p2.lds, x);
             if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
@@ -2401,7 +2423,7 @@ template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
-    if (phase1_path(d, k) != 0 || metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV)
+    if (phase1_path(d, k) != 0 || metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS)
         return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     KnnPlan p;
     CM_TRY(make_plan(h, n_ref, nq, d, k, &p));
@@ -2477,6 +2499,16 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
 }
 
 }  // namespace
+
+// float64 inputs of the ratio metrics: is there a non-zero magnitude below 2^-100 (see cm_knn_run)?
+static __global__ void tiny_nonzero_f64(const double *__restrict__ x, int64_t n, unsigned *__restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = fabs(x[i]);
+        bad |= a > 0.0 && a < 7.888609052210118e-31;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
 
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric) {
     if (metric == CM_METRIC_CORRELATION)   // float64 centred copies of both sides, then the cosine search over them
@@ -2569,13 +2601,27 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         form = CM_FORM_GEMM;
         flags |= CM_KNN_SQUARED;
     }
-    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV)
+    const bool ratio_metric = metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
+    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
-    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
+    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || ratio_metric) {
         if (lowd_dpad(d) > 128)
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev metrics are provided for up to 128 dimensions (got %d)", d);
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev / canberra / braycurtis metrics are provided for up to 128 dimensions (got %d)", d);
         if (k + knn_slack(k) + 2 * cmk2::CL > 512)
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors = %d is too large for the manhattan / chebyshev metrics", k);
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors = %d is too large for the manhattan / chebyshev / canberra / braycurtis metrics", k);
+    }
+    if (ratio_metric && dtype == CM_F64) {
+        // the fp32 filter image flushes magnitudes below float32's normal range: a ratio term |x - y| / (|x| + |y|) of such
+        // coordinates would lose all its bits.  One pass over both inputs (read by every later kernel anyway).
+        unsigned *tiny = (unsigned *)cm_ws_alloc(h, 256);
+        if (!tiny) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        CM_HIP(h, hipMemsetAsync(tiny, 0, 4, h->stream));
+        hipLaunchKernelGGL(tiny_nonzero_f64, dim3(1024), dim3(256), 0, h->stream, (const double *)d_ref, n_ref * (int64_t)d, tiny);
+        hipLaunchKernelGGL(tiny_nonzero_f64, dim3(1024), dim3(256), 0, h->stream, (const double *)d_qry, nq * (int64_t)d, tiny);
+        CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 14, tiny, 4, hipMemcpyDeviceToHost, h->stream));
+        CM_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_nflag_pinned[14])
+            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: canberra / braycurtis on float64 data with non-zero magnitudes below 2^-100 is not supported");
     }
     if (form == CM_FORM_AUTO) form = (d > 15 || k >= n_ref / 2) ? CM_FORM_GEMM : CM_FORM_DIRECT;
     if (nq == 0) return CM_OK;

@@ -935,7 +935,8 @@ constexpr int BRL = 512;  // reference rows per tile of the low-d kernel (d <= 1
 __host__ __device__ constexpr int lowd_rows(int D) { return D <= 15 ? BRL : 128; }
 __host__ __device__ constexpr int lowd_tile_bytes(int D) { return lowd_rows(D) * D * 4; }
 
-// OP: 0 = sum (q - y)^2 (Euclidean), 1 = sum |q - y| (Manhattan), 2 = max |q - y| (Chebyshev: exact in fp32 for fp32 rows).
+// OP: 0 = sum (q - y)^2 (Euclidean), 1 = sum |q - y| (Manhattan), 2 = max |q - y| (Chebyshev: exact in fp32 for fp32 rows),
+// 3 = Canberra, 4 = Bray-Curtis (round 4).
 // Rows wider than 64 floats (65 <= d <= 128: the direct level of the K = 128 family, and the other metrics at those widths):
 // ONE query per lane instead of two (128 VGPRs of coordinates), 32 queries per wave, 256 per workgroup (LOWD_QB).
 __host__ __device__ constexpr int lowd_nj(int D) { return D <= 64 ? 2 : 1; }
@@ -1016,15 +1017,25 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_lowd(P1Args a) {
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
                     const float *y = tile + (st * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh) * D;  // half-wave broadcast
-                    float s0 = 0.f, s1 = 0.f;
+                    float s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;   // (e0 / e1: Bray-Curtis denominators)
 #pragma unroll
                     for (int e = 0; e < D; ++e) {
                         const float ye = y[e];
                         const float d0 = q0[e] - ye, d1 = (NJ_ == 2 ? q1[e] : 0.f) - ye;
                         if (OP == 0) { s0 = fmaf(d0, d0, s0); if (NJ_ == 2) s1 = fmaf(d1, d1, s1); }
                         else if (OP == 1) { s0 += fabsf(d0); if (NJ_ == 2) s1 += fabsf(d1); }
-                        else { s0 = fmaxf(s0, fabsf(d0)); if (NJ_ == 2) s1 = fmaxf(s1, fabsf(d1)); }
+                        else if (OP == 2) { s0 = fmaxf(s0, fabsf(d0)); if (NJ_ == 2) s1 = fmaxf(s1, fabsf(d1)); }
+                        else if (OP == 3) {   // Canberra: |q - y| / (|q| + |y|), a 0 / 0 term counts 0 (padded columns are 0 on both sides)
+                            const float n0 = fabsf(q0[e]) + fabsf(ye);
+                            s0 += n0 > 0.f ? __fdividef(fabsf(d0), n0) : 0.f;
+                            if (NJ_ == 2) { const float n1 = fabsf(q1[e]) + fabsf(ye); s1 += n1 > 0.f ? __fdividef(fabsf(d1), n1) : 0.f; }
+                        } else {              // Bray-Curtis: numerator and denominator summed separately
+                            s0 += fabsf(d0); e0 += fabsf(q0[e]) + fabsf(ye);
+                            if (NJ_ == 2) { s1 += fabsf(d1); e1 += fabsf(q1[e]) + fabsf(ye); }
+                        }
                     }
+                    // (a padded reference row is +inf in its real columns: inf / inf = NaN, which no comparison passes)
+                    if (OP == 4) { s0 = e0 > 0.f ? __fdividef(s0, e0) : 0.f; if (NJ_ == 2) s1 = e1 > 0.f ? __fdividef(s1, e1) : 0.f; }
                     acc0[rr] = s0;
                     acc1[rr] = NJ_ == 2 ? s1 : INFINITY;   // (one query per lane: the second accumulator never passes)
                 }

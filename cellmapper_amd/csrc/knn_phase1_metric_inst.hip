@@ -26,9 +26,11 @@ static cm_status launch_metric_d(cm_handle_t h, int D, int grid, size_t lds, con
     CM_FAIL(h, CM_E_INTERNAL, "phase1/metric: no instantiation for D=%d", D);
 }
 
-// op: 1 = Manhattan, 2 = Chebyshev
+// op: 1 = Manhattan, 2 = Chebyshev, 3 = Canberra, 4 = Bray-Curtis
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a) {
     if (op == 1) return launch_metric_d<1>(h, D, grid, lds, a);
     if (op == 2) return launch_metric_d<2>(h, D, grid, lds, a);
+    if (op == 3) return launch_metric_d<3>(h, D, grid, lds, a);
+    if (op == 4) return launch_metric_d<4>(h, D, grid, lds, a);
     CM_FAIL(h, CM_E_INTERNAL, "phase1/metric: unknown op %d", op);
 }

@@ -66,6 +66,14 @@ typedef enum {
  * ties at that level) -- tests/parity.py states the tolerance.  A constant row has no correlation distance (scipy: nan);
  * here it behaves like a zero row under cosine (distance 1 to everything). */
 #define CM_METRIC_CORRELATION 5
+/* Round 4: sklearn's own DistanceMetric implementations of "canberra" (sum_j |x_j - y_j| / (|x_j| + |y_j|), a 0 / 0 term counts 0)
+ * and "braycurtis" (sum_j |x_j - y_j| / sum_j (|x_j| + |y_j|), 0 when the denominator is 0): ArgKmin brute force at d > 15
+ * (float32 data: the coordinate difference is a float32, everything else float64, the RESULT rounded to float32 once:
+ * DistanceMetric32), ball_tree on float64 copies below.  Same exact machinery and limits as manhattan / chebyshev (fp32
+ * VALU direct filter, d <= 128); float64 inputs must not hold non-zero magnitudes below 2^-100 (the filter's float32 copy
+ * would flush them: CM_E_UNSUPPORTED).  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
+#define CM_METRIC_CANBERRA 6
+#define CM_METRIC_BRAYCURTIS 7
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt

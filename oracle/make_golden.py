@@ -258,6 +258,10 @@ def main():
         xr64, yr64 = synth_(21, 1024, 128, 50, np.float64)
         xr10, yr10 = synth_(22, 1500, 100, 10, np.float32)
         coords = np.random.default_rng(23).uniform(0, 2000, (1500, 2)).astype(np.float32)
+        xrz, yrz = xr.copy(), yr.copy()   # (sparse-ish rows: a fifth of the coordinates exactly zero)
+        rz = np.random.default_rng(24)
+        xrz[rz.random(xrz.shape) < 0.2] = 0.0
+        yrz[rz.random(yrz.shape) < 0.2] = 0.0
         cases = {
             "synth_f32_manhattan_k15": (xr, yr, 15, "manhattan", "X_emb"),
             "synth_f64_manhattan_k30": (xr64, yr64, 30, "manhattan", "X_emb"),
@@ -274,6 +278,14 @@ def main():
             "synth_f32_correlation_k15": (xr, yr, 15, "correlation", "X_emb"),
             "synth_f64_correlation_k30": (xr64, yr64, 30, "correlation", "X_emb"),
             "synth_d10_correlation_k15": (xr10, yr10, 15, "correlation", "X_emb"),
+            # round 4: canberra and braycurtis (sklearn's own DistanceMetric: brute force / ArgKmin at d > 15, ball_tree below;
+            # rows with zeros and sign changes so that the 0 / 0 rule and |x| + |y| are exercised)
+            "synth_f32_canberra_k15": (xrz, yrz, 15, "canberra", "X_emb"),
+            "synth_f64_canberra_k30": (xr64, yr64, 30, "canberra", "X_emb"),
+            "synth_d10_canberra_k15": (xr10, yr10, 15, "canberra", "X_emb"),
+            "synth_f32_braycurtis_k15": (xrz, yrz, 15, "braycurtis", "X_emb"),
+            "synth_f64_braycurtis_k30": (xr64, yr64, 30, "braycurtis", "X_emb"),
+            "synth_d10_braycurtis_k15": (xr10, yr10, 15, "braycurtis", "X_emb"),
         }
         only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. `--only metrics sqeuclidean`: just the cases of one metric
         for name, (a_, b_, k_, m_, key_) in cases.items():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised cross-check of the metric pass-through (run on the GPU box): manhattan and chebyshev neighbours and distances
+"""Randomised cross-check of the metric pass-through (run on the GPU box): manhattan, chebyshev, canberra and braycurtis neighbours and distances
 of the GPU search against the CPU oracle (sklearn's DistanceMetric arithmetic, pinned on goldens) over random widths 1..128,
 k, dtypes, scales, offsets and duplicated rows -- bit for bit.  Prints one line per case; exits non-zero on a mismatch."""
 import argparse, json, os, sys, time
@@ -17,7 +17,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        metric = "manhattan" if rng.random() < 0.5 else "chebyshev"
+        metric = str(rng.choice(["manhattan", "chebyshev", "canberra", "braycurtis"]))   # (round 4: sklearn's two ratio metrics)
         d = int(rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 24, 33, 50, 61, 64, 65, 100, 128]))
         n_ref = int(rng.choice([40, 700, 4097, 9000]))
         nq = int(rng.choice([1, 33, 500]))
@@ -30,6 +30,10 @@ def main():
         if n_ref >= 100 and rng.random() < 0.5:      # duplicated reference rows: exact ties
             ref[10:10 + int(rng.integers(2, 60))] = ref[10]
             qry[0] = ref[10]
+        if metric in ("canberra", "braycurtis") and rng.random() < 0.5:   # exact zeros: the 0 / 0 rule, zero rows
+            ref[rng.random(ref.shape) < 0.2] = 0; qry[rng.random(qry.shape) < 0.2] = 0
+            if n_ref > 5: ref[3] = 0
+            qry[-1] = 0
         if rng.random() < 0.3:                         # integer-valued coordinates: masses of tied distances
             ref = np.round(ref / scale * 2).astype(dt); qry = np.round(qry / scale * 2).astype(dt)
         t0 = time.perf_counter()

@@ -44,6 +44,12 @@ def exact_dist(ref, qry_row, cols, metric):
         return np.abs(r - q).sum(1)
     if metric == "chebyshev":
         return np.abs(r - q).max(1)
+    if metric == "canberra":
+        den = np.abs(r) + np.abs(q)
+        return np.divide(np.abs(r - q), den, out=np.zeros_like(den), where=den > 0).sum(1)
+    if metric == "braycurtis":
+        den = (np.abs(r) + np.abs(q)).sum(1)
+        return np.divide(np.abs(r - q).sum(1), den, out=np.zeros_like(den), where=den > 0)
     if metric == "sqeuclidean":
         return ((r - q) ** 2).sum(1)
     return np.sqrt(((r - q) ** 2).sum(1))

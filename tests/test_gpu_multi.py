@@ -181,7 +181,7 @@ def test_reference_rows_are_sharded_over_the_devices_and_the_exchange_checks_its
 
 
 @pytest.mark.parametrize("metric,d", [("sqeuclidean", 24), ("manhattan", 24), ("chebyshev", 24), ("correlation", 24), ("euclidean", 2),
-                                      ("cosine", 24)])
+                                      ("cosine", 24), ("canberra", 24), ("braycurtis", 24)])
 def test_metrics_and_the_low_d_path_through_the_sharded_merge(metric, d, oracle):
     """The sharded merge ranks by each metric's own float64 value (no square root except euclidean); d = 2 takes the uniform
     grid on every shard; float32 cosine keeps the one-device arithmetic (sklearn's float32 distances): one part."""

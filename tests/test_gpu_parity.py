@@ -815,6 +815,14 @@ def test_weights_and_vote_row_groupings(hip, oracle, monkeypatch, k):
     ("manhattan", np.float64, 65, 5000, 300, 10),
     ("manhattan", np.float32, 3, 6000, 6000, 20),       # kd-tree arithmetic: float64 copies of the coordinates
     ("chebyshev", np.float32, 10, 12000, 800, 8),
+    ("canberra", np.float32, 50, 12000, 700, 30),       # round 4: sklearn's ratio metrics through the same machinery
+    ("canberra", np.float64, 33, 9000, 500, 15),
+    ("canberra", np.float32, 100, 9000, 500, 15),
+    ("canberra", np.float32, 10, 12000, 800, 8),        # ball-tree arithmetic: float64 copies
+    ("braycurtis", np.float32, 50, 12000, 700, 30),
+    ("braycurtis", np.float64, 64, 6000, 400, 10),
+    ("braycurtis", np.float32, 128, 6000, 300, 30),
+    ("braycurtis", np.float32, 3, 6000, 6000, 20),
 ])
 def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, nq, k):
     """knn.py:343,429 hand `metric` to sklearn: manhattan / chebyshev through the VALU direct filter + float64 re-rank must
@@ -825,12 +833,18 @@ def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, n
     ref[100:140] = ref[100]
     qry = ref.copy() if nq == n_ref else (rng.standard_normal((nq, d)) * (50.0 if d <= 3 else 1.0)).astype(dtype)
     qry[3] = ref[100]
+    if metric in ("canberra", "braycurtis"):   # zeros and sign changes: the 0 / 0 rule and |x| + |y|
+        ref[rng.random(ref.shape) < 0.15] = 0.0
+        qry[rng.random(qry.shape) < 0.15] = 0.0
+        ref[100:140] = ref[100]
+        qry[3] = ref[100]
+        qry[4] = 0.0                            # an all-zero query: Canberra terms |y| / |y| = 1, Bray-Curtis 1 (0 against a zero row)
     dist, idx = hip.knn(ref, qry, k, metric=metric)
     od, oi = oracle.knn_minkowski_family(ref, qry, k, metric)
     assert dist.dtype == np.float64 and np.array_equal(idx, oi) and np.array_equal(dist, od)
     assert idx[3, 0] == 100 and np.all(dist[3, :min(k, 40)] == 0)
     # aliases as sklearn spells them
-    alias = {"manhattan": "cityblock", "chebyshev": "infinity"}[metric]
+    alias = {"manhattan": "cityblock", "chebyshev": "infinity", "canberra": "canberra", "braycurtis": "braycurtis"}[metric]
     d2, i2 = hip.knn(ref[:5000], qry[:200], k, metric=alias)
     d3, i3 = hip.knn(ref[:5000], qry[:200], k, metric=metric)
     assert np.array_equal(d2, d3) and np.array_equal(i2, i3)
@@ -900,8 +914,14 @@ def test_metric_passthrough_limits_and_names(hip):
     x = rng.standard_normal((500, 130)).astype(np.float32)
     with pytest.raises(NotImplementedError, match="128 dimensions"):
         hip.knn(x, x[:10], 5, metric="manhattan")
+    with pytest.raises(NotImplementedError, match="128 dimensions"):
+        hip.knn(x, x[:10], 5, metric="braycurtis")          # (built in round 4, same width limit)
     with pytest.raises(ValueError, match="not supported"):
-        hip.knn(x, x[:10], 5, metric="braycurtis")
+        hip.knn(x, x[:10], 5, metric="mahalanobis")
+    tiny = rng.standard_normal((300, 20))
+    tiny[7, 3] = 1e-40                                        # float64 magnitudes the filter's float32 copy would flush
+    with pytest.raises(NotImplementedError, match="2\\^-100"):
+        hip.knn(tiny, tiny[:10], 5, metric="canberra")
     d0, i0 = hip.knn(x, x[:10], 5, metric="minkowski")     # sklearn's default p = 2
     d1, i1 = hip.knn(x, x[:10], 5, metric="euclidean")
     assert np.array_equal(d0, d1) and np.array_equal(i0, i1)

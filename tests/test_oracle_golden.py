@@ -24,8 +24,10 @@ def test_oracle_matches_reference(name, oracle):
     xrep, yrep = rep(g)
     if metric == "cosine":
         dist, idx = oracle.knn_cosine(xrep, yrep, k)
-    elif metric in ("manhattan", "chebyshev"):
+    elif metric in ("manhattan", "chebyshev", "canberra", "braycurtis"):
         dist, idx = oracle.knn_minkowski_family(xrep, yrep, k, metric)
+        if metric in ("canberra", "braycurtis"):
+            assert np.array_equal(dist, g["yx_dist"])   # distances bit for bit (neighbours: tie groups, below)
     elif metric == "correlation":
         dist, idx = oracle.knn_correlation(xrep, yrep, k)
     elif metric == "sqeuclidean":
