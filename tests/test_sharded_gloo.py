@@ -153,7 +153,7 @@ def test_sharded_rejects_unsupported_metric():
     from cellmapper_amd.sharded import sharded_map_labels
 
     with pytest.raises(ValueError, match="not supported"):
-        sharded_map_labels(None, None, None, 0, 10, None, 3, None, 2, metric="braycurtis")
+        sharded_map_labels(None, None, None, 0, 10, None, 3, None, 2, metric="mahalanobis")
 
 
 @pytest.mark.parametrize("world,ref_shards,exchange,kernel,metric", [
