@@ -18,9 +18,9 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean", "correlation"]))
+        metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean", "correlation", "canberra", "braycurtis"]))
         d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259, 260, 300, 512, 777, 1024, 2047]))
-        if metric in ("manhattan", "chebyshev") and d > 128:
+        if metric in ("manhattan", "chebyshev", "canberra", "braycurtis") and d > 128:
             d = 128
         n_ref = int(rng.choice([1, 2, 31, 129, 513, 2000, 6000]))
         nq = int(rng.choice([1, 2, 63, 700, 1500]))
