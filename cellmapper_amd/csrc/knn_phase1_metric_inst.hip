@@ -26,11 +26,23 @@ static cm_status launch_metric_d(cm_handle_t h, int D, int grid, size_t lds, con
     CM_FAIL(h, CM_E_INTERNAL, "phase1/metric: no instantiation for D=%d", D);
 }
 
-// op: 1 = Manhattan, 2 = Chebyshev, 3 = Canberra, 4 = Bray-Curtis
+// op: 1 = Manhattan, 2 = Chebyshev, 3 = Canberra, 4 = Bray-Curtis.  Compiled twice (Makefile: -DCM_METRIC_GROUP=0 -> ops 1, 2;
+// =1 -> ops 3, 4) so that the 4 x 28 instantiations build in parallel.
+#ifndef CM_METRIC_GROUP
+#define CM_METRIC_GROUP 0
+#endif
+#if CM_METRIC_GROUP == 0
+cm_status cm_p1lowd_metric_launch_g1(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a) {
     if (op == 1) return launch_metric_d<1>(h, D, grid, lds, a);
     if (op == 2) return launch_metric_d<2>(h, D, grid, lds, a);
+    if (op == 3 || op == 4) return cm_p1lowd_metric_launch_g1(h, D, op, grid, lds, a);
+    CM_FAIL(h, CM_E_INTERNAL, "phase1/metric: unknown op %d", op);
+}
+#else
+cm_status cm_p1lowd_metric_launch_g1(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a) {
     if (op == 3) return launch_metric_d<3>(h, D, grid, lds, a);
     if (op == 4) return launch_metric_d<4>(h, D, grid, lds, a);
     CM_FAIL(h, CM_E_INTERNAL, "phase1/metric: unknown op %d", op);
 }
+#endif
