@@ -1776,6 +1776,14 @@ cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_
     if (n == 0 || km == 0) return CM_OK;
     CM_TRY(dv.alloc(h, 8 * (size_t)nnz)); CM_TRY(oi.alloc(h, 8 * (size_t)n * km)); CM_TRY(od.alloc(h, 8 * (size_t)n * km));
     CM_TRY(h2d(h, dv.p, data, 8 * (size_t)nnz));
+    if (km + 1 > CM_INGEST_LDS_MAX) {   // rows beyond the in-LDS sorts: staged stable radix sort (round 4; no row limit any more)
+        DevBuf ws;
+        const size_t wsb = cm_ingest_huge_ws_bytes(n, km);
+        CM_TRY(ws.alloc(h, wsb));
+        CM_TRY(cm_ingest_fill_huge_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<double>(), n, include_self, km, ws.p, wsb, oi.as<int64_t>(),
+                                       od.as<double>()));
+        CM_TRY(sync(h));
+    } else
     CM_TRY(cm_ingest_fill_run(h, dp.as<int64_t>(), dc.as<int32_t>(), dv.as<double>(), n, include_self, km, oi.as<int64_t>(),
                               od.as<double>()));
     CM_TRY(d2h(h, out_idx, oi.p, 8 * (size_t)n * km));

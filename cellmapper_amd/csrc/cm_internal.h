@@ -137,6 +137,11 @@ cm_status cm_ingest_count_run(cm_handle_t h, const int64_t *d_indptr, const int3
                               int *d_rowlen, int *d_kmax);
 cm_status cm_ingest_fill_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
                              int include_self, int kmax, int64_t *d_out_idx, double *d_out_dist);
+// rows longer than the in-LDS sorts of cm_ingest_fill_run hold (rank_kernels.hip: segmented radix sort)
+constexpr int CM_INGEST_LDS_MAX = 12288;
+size_t cm_ingest_huge_ws_bytes(int64_t n, int kmax);
+cm_status cm_ingest_fill_huge_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
+                                  int include_self, int kmax, void *d_ws, size_t ws_bytes, int64_t *d_out_idx, double *d_out_dist);
 cm_status cm_expr_metrics_run(cm_handle_t h, const float *d_a, const float *d_b, int64_t n, int64_t G, const int32_t *d_group,
                               int n_groups, int method, float *d_out);
 size_t cm_expr_metrics_ws_bytes(int64_t n, int64_t G);

@@ -1802,7 +1802,7 @@ __global__ __launch_bounds__(256) void ingest_fill(const int64_t *__restrict__ i
 }
 // Rows with 1 024 or more stored neighbours (no limit upstream, utils.py:129-219): one WORKGROUP per row, the row in
 // dynamic LDS (up to IG_LONG_MAX entries), wave 0 gathers (stable compaction as above), all 256 threads rank.
-constexpr int IG_LONG_MAX = 12288;
+constexpr int IG_LONG_MAX = CM_INGEST_LDS_MAX;
 __global__ __launch_bounds__(256) void ingest_fill_long(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                         const double *__restrict__ data, int64_t n, int include_self, int kmax,
                                                         int cap, int64_t *__restrict__ out_idx, double *__restrict__ out_dist) {

@@ -228,3 +228,101 @@ cm_status cm_expr_spearman_run(cm_handle_t h, const float *d_a, const float *d_b
     CM_HIP(h, hipGetLastError());
     return CM_OK;
 }
+
+
+// ------------------------------------------------------------------ precomputed-distance ingest: rows beyond the in-LDS sorts
+// utils.py:129-219 sets no limit on the stored neighbours of a cell (a dense distance matrix has n of them); rows of up to
+// 12 287 entries are rank-sorted in LDS (graph_kernels.hip: ingest_fill / ingest_fill_long).  Longer rows (round 4): the kept
+// entries of every row are compacted in stored order into staging arrays (value, column), a STABLE segmented radix sort by
+// value (rocPRIM; ties keep their stored order, an already non-decreasing row comes out as stored -- the rule of the LDS
+// kernels) writes them straight into the output arrays, a last kernel pads the tails with -1 / inf.  Row batches keep the
+// sort below 2^31 elements.
+namespace {
+__global__ __launch_bounds__(256) void ig_gather(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                 const double *__restrict__ data, int64_t row0, int rows, int64_t n_total, int include_self,
+                                                 int kmax, double *__restrict__ k_in, int64_t *__restrict__ v_in, unsigned *__restrict__ ends) {
+    // one wave per row (rows are long: the loop over 64-entry pieces is the work)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= rows) return;
+    const int64_t i = row0 + r;
+    (void)n_total;
+    const int64_t lo = indptr[i], hi = indptr[i + 1];
+    double *kd = k_in + (size_t)r * kmax;
+    int64_t *vd = v_in + (size_t)r * kmax;
+    int m = 0;
+    bool has = false;
+    for (int64_t base = lo; base < hi; base += 64) {
+        const int64_t p = base + lane;
+        const bool in = p < hi;
+        const int c = in ? indices[p] : -1;
+        has = has || (in && c == (int32_t)i);
+        const bool keep = in && !(include_self == 0 && c == (int32_t)i);
+        const unsigned long long b = __ballot(keep);
+        if (keep) {
+            const int pos = m + __popcll(b & ((1ull << lane) - 1ull));
+            kd[pos] = data[p];
+            vd[pos] = c;
+        }
+        m += __popcll(b);
+    }
+    if (include_self == 1 && __ballot(has) == 0ull) {
+        if (lane == 0) { kd[m] = 0.0; vd[m] = i; }
+        ++m;
+    }
+    if (lane == 0) { ends[r] = (unsigned)((size_t)r * kmax + m); ends[rows + r] = (unsigned)((size_t)r * kmax); }   // [0, rows): ends, [rows, 2 rows): begins
+}
+__global__ void ig_pad(const unsigned *__restrict__ ends, int rows, int kmax, int64_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+    const int r = blockIdx.y;
+    const unsigned m = ends[r] - (unsigned)((size_t)r * kmax);
+    for (unsigned s_ = m + blockIdx.x * blockDim.x + threadIdx.x; s_ < (unsigned)kmax; s_ += gridDim.x * blockDim.x) {
+        out_idx[(size_t)r * kmax + s_] = -1;
+        out_dist[(size_t)r * kmax + s_] = INFINITY;
+    }
+}
+inline int64_t ig_batch_rows(int64_t n, int kmax) {   // (fewer than 2^31 elements per sort, at most 32 768 rows per launch: grid y)
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(n, 32768), ((int64_t)1 << 31) / std::max(kmax, 1) - 1));
+}
+inline size_t ig_sort_temp(unsigned size, unsigned segments, unsigned m) {
+    size_t bytes = 0;
+    (void)m;
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (const double *)nullptr, (double *)nullptr, (const int64_t *)nullptr,
+                                              (int64_t *)nullptr, size, segments, (const unsigned *)nullptr, (const unsigned *)nullptr);
+    return bytes;
+}
+}  // namespace
+
+// device bytes the long-row ingest needs besides its outputs: staging (value + column per output slot of a batch), the
+// batch's segment ends, the sort's temporary storage
+size_t cm_ingest_huge_ws_bytes(int64_t n, int kmax) {
+    const int64_t B = ig_batch_rows(n, kmax);
+    const size_t E = (size_t)B * (size_t)kmax;
+    return 2 * cm_align(8 * E) + cm_align(8 * (size_t)B) + cm_align(ig_sort_temp((unsigned)E, (unsigned)B, (unsigned)kmax)) + 4096;
+}
+
+cm_status cm_ingest_fill_huge_run(cm_handle_t h, const int64_t *d_indptr, const int32_t *d_indices, const double *d_data, int64_t n,
+                                  int include_self, int kmax, void *d_ws, size_t ws_bytes, int64_t *d_out_idx, double *d_out_dist) {
+    if (n < 1 || kmax < 1) return CM_OK;
+    if (ws_bytes < cm_ingest_huge_ws_bytes(n, kmax)) CM_FAIL(h, CM_E_INTERNAL, "precomputed distances: workspace too small");
+    const int64_t B = ig_batch_rows(n, kmax);
+    const size_t E = (size_t)B * (size_t)kmax;
+    char *p = (char *)d_ws;
+    double *k_in = (double *)p; p += cm_align(8 * E);
+    int64_t *v_in = (int64_t *)p; p += cm_align(8 * E);
+    unsigned *ends = (unsigned *)p; p += cm_align(8 * (size_t)B);   // ends + begins of the batch's segments
+    void *temp = p;
+    const size_t temp_cap = ig_sort_temp((unsigned)E, (unsigned)B, (unsigned)kmax);
+    for (int64_t r0 = 0; r0 < n; r0 += B) {
+        const int rows = (int)std::min<int64_t>(B, n - r0);
+        hipLaunchKernelGGL(ig_gather, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, d_indptr, d_indices, d_data, r0, rows, n, include_self,
+                           kmax, k_in, v_in, ends);
+        size_t tb = temp_cap;
+        CM_HIP(h, rocprim::segmented_radix_sort_pairs(temp, tb, (const double *)k_in, d_out_dist + (size_t)r0 * kmax, (const int64_t *)v_in,
+                                                      d_out_idx + (size_t)r0 * kmax, (unsigned)((size_t)rows * kmax), (unsigned)rows,
+                                                      (const unsigned *)(ends + rows), (const unsigned *)ends, 0, 64, h->stream));
+        hipLaunchKernelGGL(ig_pad, dim3(8, (unsigned)rows), dim3(256), 0, h->stream, (const unsigned *)ends, rows, kmax,
+                           d_out_idx + (size_t)r0 * kmax, d_out_dist + (size_t)r0 * kmax);
+    }
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}

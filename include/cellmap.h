@@ -364,8 +364,9 @@ cm_status cm_map_labels_dev(cm_handle_t h, const void *d_ref, int64_t n_ref, con
  * include_self: -1 = None (keep rows as stored), 0 = False (drop diagonal entries), 1 = True (append (i, 0.0) to rows
  * without a diagonal entry).  Rows whose distances are non-decreasing keep their stored order, others are sorted by
  * distance (ties by stored position).  Call once with out_idx = out_dist = NULL to obtain *out_kmax (the longest row
- * after the include_self rule), then with buffers of kmax = *out_kmax columns.  Rows longer than 12 287 entries:
- * CM_E_UNSUPPORTED (up to 1 023: one wave per row; longer: one workgroup per row). */
+ * after the include_self rule), then with buffers of kmax = *out_kmax columns.  Any row length (utils.py:129-219 sets no limit):
+ * up to 1 023 entries one wave per row, up to 12 287 one workgroup per row (rank sort in LDS), beyond that a staged stable
+ * segmented radix sort (round 4; device memory: 2 x n x kmax x 16 bytes). */
 cm_status cm_ingest_distances(cm_handle_t h, const int64_t *indptr, const int32_t *indices, const double *data, int64_t n,
                               int32_t include_self, int32_t kmax, int64_t *out_idx, double *out_dist, int32_t *out_kmax);
 

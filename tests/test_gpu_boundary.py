@@ -189,7 +189,7 @@ def test_mapping_matrix_setter_and_errors():
     with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
         cm.compute_neighbors(n_neighbors=10**6, use_rep="X_emb")
     with pytest.raises(ValueError, match="not supported"):
-        cm.compute_neighbors(n_neighbors=5, use_rep="X_emb", metric="braycurtis")
+        cm.compute_neighbors(n_neighbors=5, use_rep="X_emb", metric="mahalanobis")
     cm.map(use_rep="X_emb", n_neighbors=5)  # no keys: warning only
 
 
@@ -337,7 +337,7 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
         assert np.array_equal(gi, oi) and np.array_equal(gd, od), inc
     gi, gd = extract_neighbors_from_distances(sp.csr_matrix((4, 4)))
     assert gi.shape == (4, 0) and gd.shape == (4, 0)
-    # rows with 1 024+ stored neighbours: one workgroup per row (no limit upstream; here up to 12 287 entries)
+    # rows with 1 024+ stored neighbours: one workgroup per row, the row in LDS (up to 12 287 entries)
     n2 = 5000
     lens2 = rng.integers(0, 30, n2)
     lens2[3], lens2[4], lens2[77] = 1500, 4200, 1024
@@ -353,9 +353,23 @@ def test_precomputed_distance_ingest_random_graphs_and_edges(oracle):
         gi, gd = extract_neighbors_from_distances(m2, include_self=inc)
         oi, od = oracle.extract_neighbors_from_distances(m2, include_self=inc)
         assert np.array_equal(gi, oi) and np.array_equal(gd, od), inc
-    big = sp.csr_matrix((np.ones(13000), (np.zeros(13000, int), np.arange(13000))), shape=(13000, 13000))
-    with pytest.raises(NotImplementedError):
-        extract_neighbors_from_distances(big)
+    # rows beyond the in-LDS sorts (round 4: no row limit any more -- staged stable radix sort): two rows of 12 400 / 12 900
+    # stored neighbours with many tied distances, one of them stored sorted, next to short rows; both include_self rules
+    n3 = 13000
+    lens3 = rng.integers(0, 6, n3)
+    lens3[5], lens3[9000] = 12400, 12900
+    rows3 = np.repeat(np.arange(n3), lens3)
+    cols3 = np.concatenate([rng.choice(n3, l, replace=False) for l in lens3])
+    m3 = sp.csr_matrix((np.round(rng.random(len(rows3)) * 512) / 64, (rows3, cols3)), shape=(n3, n3))
+    m3.sort_indices()
+    lo, hi = m3.indptr[9000], m3.indptr[9001]
+    o = np.argsort(m3.data[lo:hi], kind="stable")
+    m3.data[lo:hi], m3.indices[lo:hi] = m3.data[lo:hi][o], m3.indices[lo:hi][o]
+    m3.has_sorted_indices = False
+    for inc in (None, True, False):
+        gi, gd = extract_neighbors_from_distances(m3, include_self=inc)
+        oi, od = oracle.extract_neighbors_from_distances(m3, include_self=inc)
+        assert gi.shape[1] >= 12890 and np.array_equal(gi, oi) and np.array_equal(gd, od), inc
 
 
 @pytest.mark.parametrize("method", ["pearson", "rmse", "js", "spearman"])
