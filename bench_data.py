@@ -16,6 +16,7 @@ The same function on CPU tensors gives the gloo tests their inputs.  Nothing her
 from __future__ import annotations
 
 import math
+import os
 
 _C1 = 0x7FEB352D
 _C2 = 0x846CA68B - (1 << 32)     # as a wrapped int32
@@ -121,6 +122,22 @@ def sparse_rows(torch, r0: int, r1: int, n_genes: int, density: float, device, s
         rows = torch.arange(r0 + a, r0 + b, dtype=torch.int32, device=device)
         h = hash_grid(torch, STREAM_SPCOL, rows, strata)
         cols[a:b] = base + (_lsr(h, 8) % width).to(torch.int32)
+        if os.environ.get("CELLMAP_BENCH_BANKFRIENDLY") and width >= 32:
+            # EXPERIMENT (profiles/r04_a3_bank_probe.md): what would the sparse product gain if the entries of a (payload row,
+            # column bucket) slice sat in LDS banks that never collide within one update instruction?  Columns are re-drawn
+            # inside their strata so that slice position p lands in bank (p // EPL) % 32 (EPL = 3 entries per lane at config 5).
+            W = ((n_genes + 7) // 8 + 63) // 64 * 64                         # the kernel's bucket width (cm_a3_bucket_width)
+            t = strata.to(torch.int64)
+            lo_b, hi_b = (t * width) // W, (t * width + width - 1) // W
+            bucket = lo_b                                                      # (a stratum that straddles two buckets keeps column t * width)
+            first = torch.zeros(int(bucket.max().item()) + 2, dtype=torch.int64, device=device)
+            first.scatter_reduce_(0, bucket, t, reduce="amin", include_self=False)
+            pos = t - first[bucket]
+            rot = (_lsr(hash_grid(torch, STREAM_SPCOL, rows, strata[:1]), 9) % 32).to(torch.int64)   # [rows, 1]: a bank rotation per payload row
+            want = ((pos // 3)[None, :] + rot) % 32                           # keeps the rows' supports different (the product stays ~93 % dense)
+            r = (want - (t * width)[None, :]) % 32
+            r = torch.where((lo_b == hi_b)[None, :], r, torch.zeros_like(r))
+            cols[a:b] = ((t * width)[None, :] + r - s0 * width).to(torch.int32)
         h1 = hash_grid(torch, STREAM_SPVAL, rows, strata)
         h2 = _mix(h1 ^ 0x5BD1E995)
         u1 = ((h1 & 0xFFFFFF).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
