@@ -135,15 +135,16 @@ __global__ __launch_bounds__(256) void colmean_partial(const T *__restrict__ X, 
         }
     }
     for (; i < r1; i += 4) {
+        const double x0 = c < d ? (double)X[i * d + c] : 0.0, x1 = c + 64 < d ? (double)X[i * d + c + 64] : 0.0;
         double scale = 1.0;
-        if (metric == CM_METRIC_COSINE) {
-            double s = 0.0;
-            for (int e = 0; e < d; ++e) { double v = (double)X[i * d + e]; s = fma(v, v, s); }
-            double nrm = sqrt(s);
+        if (metric == CM_METRIC_COSINE) {   // (the row's norm by a wave reduction: every lane used to re-read the whole row)
+            double s = x0 * x0 + x1 * x1;
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const double nrm = sqrt(s);
             scale = nrm > 0.0 ? 1.0 / nrm : 1.0;
         }
-        if (c < d) acc0 += (double)X[i * d + c] * scale;
-        if (c + 64 < d) acc1 += (double)X[i * d + c + 64] * scale;
+        acc0 += x0 * scale;
+        acc1 += x1 * scale;
     }
     sh[w][c] = acc0;
     sh[w][c + 64] = acc1;
