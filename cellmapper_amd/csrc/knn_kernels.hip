@@ -4,6 +4,7 @@
 // Reference interface replaced: Neighbors.compute_neighbors, sklearn branch, /root/reference/src/cellmapper/model/
 // knn.py:428-440 (sklearn.neighbors.NearestNeighbors(...).fit(xrep).kneighbors(yrep)).
 #include <algorithm>
+#include <type_traits>
 #include "cm_internal.h"
 #include "knn_phase1.h"
 #include "knn_phase1_f16.h"
@@ -44,7 +45,7 @@ namespace {
 constexpr int kSupportedKP[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 84, 100, 132, 164, 196, 260};
 constexpr int RR_NCMAX = 1024;  // max candidates per query handled by the re-rank / merge kernels
 constexpr int RR_DMAX = 260;   // LDS stride (doubles) of a staged query row for d <= 259; wider rows: q_stride(d)
-constexpr int KNN_DMAX = 2047;  // widest embedding (round 3: the K-chunked f32 filter, knn_cand_mfma_wide)
+constexpr int KNN_DMAX = 2047;  // widest row whose float64 copy is staged in LDS by the re-rank / fallback kernels (wider: their GQ form)
 __host__ __device__ constexpr int q_stride(int d) { return d < RR_DMAX ? RR_DMAX : ((d + 4) & ~3); }
 constexpr int MG_NCMAX = CM_MERGE_NCMAX;   // max nparts*k in the shard merge
 constexpr int FB_CAP = 4096;    // fallback collection capacity per query (a query with more rows inside its bound goes to knn_fallback_select)
@@ -376,54 +377,107 @@ __global__ void prep_rows_lowd(const T *__restrict__ X, int64_t n, int d, int64_
 //   DIRECT form : sum_j (q_j - y_j)^2, multiply and add rounded separately        (KDTree rdist)
 //   cosine      : clip(1 - q.y / (|q| |y|), 0, 2)                                 (pairwise cosine_distances)
 //   manhattan / chebyshev : sum / max of |q_j - y_j| in coordinate order           (DistanceMetric dist, see below)
-template <typename T>
-__device__ __forceinline__ double pair_value(const double *__restrict__ q, double xn, const T *__restrict__ y, int d,
+// PairAcc: NQ query rows against one reference row at once -- the same chain per pair, in the same order; the pairs' chains
+// are independent, which is what lets the exact scan interleave them, and the state can be carried over column chunks (run is
+// called with consecutive column ranges; yat(i) is the reference row's coordinate c0 + i).  pair_value is the NQ = 1 case
+// over the whole row.
+template <typename T, typename TQ, int NQ>
+struct PairAcc {
+    double a[NQ], b[NQ], yn;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) { a[g] = 0.0; b[g] = 0.0; }
+        yn = 0.0;
+    }
+    // one loop per (metric family, float32-difference rule): MODE 0 q.y and |y|^2 (cosine, GEMM form), 1 direct squared
+    // differences, 2 manhattan, 3 chebyshev, 4 canberra, 5 braycurtis; F32: the difference is taken in float32 (below)
+    template <int MODE, bool F32, int UNR, typename YF>
+    __device__ __forceinline__ void run_mode(const TQ *const *q, int c0, int n, YF yat) {
+        auto step = [&](int i) {
+            const T yv = yat(i);
+#pragma unroll
+            for (int g = 0; g < NQ; ++g) {
+                const TQ qv = q[g][c0 + i];
+                if constexpr (MODE == 0) {
+                    a[g] = fma((double)qv, (double)yv, a[g]);
+                } else if constexpr (MODE == 1) {
+                    const double t = (double)qv - (double)yv;
+                    a[g] = __dadd_rn(a[g], __dmul_rn(t, t));
+                } else {
+                    double t;
+                    if constexpr (F32) t = (double)fabsf(__fsub_rn((float)qv, (float)yv));
+                    else t = fabs((double)qv - (double)yv);
+                    if constexpr (MODE == 2) a[g] = __dadd_rn(a[g], t);
+                    else if constexpr (MODE == 3) a[g] = fmax(a[g], t);
+                    else {
+                        const double dn = __dadd_rn(fabs((double)qv), fabs((double)yv));
+                        if constexpr (MODE == 4) { if (dn > 0.0) a[g] = __dadd_rn(a[g], __ddiv_rn(t, dn)); }
+                        else { a[g] = __dadd_rn(a[g], t); b[g] = __dadd_rn(b[g], dn); }
+                    }
+                }
+            }
+            if constexpr (MODE == 0) yn = fma((double)yv, (double)yv, yn);
+        };
+        if constexpr (UNR > 1) {
+#pragma unroll UNR
+            for (int i = 0; i < n; ++i) step(i);
+        } else {
+            for (int i = 0; i < n; ++i) step(i);   // (unrolling left to the compiler, as before the accumulator form)
+        }
+    }
+    // manhattan / chebyshev -- sklearn's DistanceMetric: |q_j - y_j| joins a float64 accumulator in coordinate order.  Brute
+    // force on float32 data (DistanceMetric32) takes the difference in float32 and returns a float32: one more rounding of the
+    // result.  The kd-tree (DIRECT form) works on float64 copies of the data: everything in float64.
+    // canberra / braycurtis -- sklearn's CanberraDistance / BrayCurtisDistance `dist` (metrics/_dist_metrics.pyx.tp): float64
+    // accumulators in coordinate order; |x_j| + |y_j| in float64; the difference in the INPUT dtype under brute force on
+    // float32 data (DistanceMetric32), whose result is rounded to float32 once more; everything float64 on the tree path.
+    template <int UNR = 1, typename YF>
+    __device__ __forceinline__ void run(const TQ *const *q, int c0, int n, YF yat, int metric, int form) {
+        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
+        switch (metric) {
+            case CM_METRIC_MANHATTAN: if (f32) run_mode<2, true, UNR>(q, c0, n, yat); else run_mode<2, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_CHEBYSHEV: if (f32) run_mode<3, true, UNR>(q, c0, n, yat); else run_mode<3, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_CANBERRA: if (f32) run_mode<4, true, UNR>(q, c0, n, yat); else run_mode<4, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_BRAYCURTIS: if (f32) run_mode<5, true, UNR>(q, c0, n, yat); else run_mode<5, false, UNR>(q, c0, n, yat); return;
+            default: break;
+        }
+        if (metric != CM_METRIC_COSINE && form == CM_FORM_DIRECT) run_mode<1, false, UNR>(q, c0, n, yat);
+        else run_mode<0, false, UNR>(q, c0, n, yat);   // cosine and the GEMM form: q.y per pair, |y|^2 once
+    }
+    __device__ __forceinline__ void finish(const double *xn, int metric, int form, double *out) const {
+        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) {
+            if (metric == CM_METRIC_COSINE) {
+                double nx = sqrt(xn[g]), ny = sqrt(yn);
+                if (!(nx > 0.0)) nx = 1.0;
+                if (!(ny > 0.0)) ny = 1.0;
+                const double s = 1.0 - a[g] / (nx * ny);
+                out[g] = s < 0.0 ? 0.0 : (s > 2.0 ? 2.0 : s);
+            } else if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
+                out[g] = f32 ? (double)(float)a[g] : a[g];
+            } else if (metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS) {
+                const double r = metric == CM_METRIC_CANBERRA ? a[g] : (b[g] > 0.0 ? __ddiv_rn(a[g], b[g]) : 0.0);
+                out[g] = f32 ? (double)(float)r : r;
+            } else if (form == CM_FORM_DIRECT) {
+                out[g] = a[g];
+            } else {
+                const double d2 = __dadd_rn(__dadd_rn(xn[g], __dmul_rn(-2.0, a[g])), yn);
+                out[g] = d2 > 0.0 ? d2 : 0.0;
+            }
+        }
+    }
+};
+template <typename T, typename TQ = double>
+__device__ __forceinline__ double pair_value(const TQ *__restrict__ q, double xn, const T *__restrict__ y, int d,
                                              int metric, int form) {
-    if (metric == CM_METRIC_COSINE) {
-        double dot = 0.0, yn = 0.0;
-        for (int c = 0; c < d; ++c) { double v = (double)y[c]; dot = fma(q[c], v, dot); yn = fma(v, v, yn); }
-        double nx = sqrt(xn), ny = sqrt(yn);
-        if (!(nx > 0.0)) nx = 1.0;
-        if (!(ny > 0.0)) ny = 1.0;
-        double s = 1.0 - dot / (nx * ny);
-        return s < 0.0 ? 0.0 : (s > 2.0 ? 2.0 : s);
-    }
-    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV) {
-        // sklearn's DistanceMetric: |q_j - y_j| joins a float64 accumulator in coordinate order.  Brute force on float32 data
-        // (DistanceMetric32) takes the difference in float32 and returns a float32: one more rounding of the result.  The
-        // kd-tree (DIRECT form) works on float64 copies of the data: everything in float64.
-        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
-        double acc = 0.0;
-        for (int c = 0; c < d; ++c) {
-            const double t = f32 ? (double)fabsf(__fsub_rn((float)q[c], (float)y[c])) : fabs(q[c] - (double)y[c]);
-            acc = metric == CM_METRIC_MANHATTAN ? __dadd_rn(acc, t) : fmax(acc, t);
-        }
-        return f32 ? (double)(float)acc : acc;
-    }
-    if (metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS) {
-        // sklearn's CanberraDistance / BrayCurtisDistance `dist` (metrics/_dist_metrics.pyx.tp): float64 accumulators in
-        // coordinate order; |x_j| + |y_j| in float64; the difference in the INPUT dtype under brute force on float32 data
-        // (DistanceMetric32), whose result is rounded to float32 once more; everything float64 on the tree path (DIRECT form)
-        const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
-        double num = 0.0, den = 0.0;
-        for (int c = 0; c < d; ++c) {
-            const double t = f32 ? (double)fabsf(__fsub_rn((float)q[c], (float)y[c])) : fabs(q[c] - (double)y[c]);
-            const double dn = __dadd_rn(fabs(q[c]), fabs((double)y[c]));
-            if (metric == CM_METRIC_CANBERRA) { if (dn > 0.0) num = __dadd_rn(num, __ddiv_rn(t, dn)); }
-            else { num = __dadd_rn(num, t); den = __dadd_rn(den, dn); }
-        }
-        const double r = metric == CM_METRIC_CANBERRA ? num : (den > 0.0 ? __ddiv_rn(num, den) : 0.0);
-        return f32 ? (double)(float)r : r;
-    }
-    if (form == CM_FORM_DIRECT) {
-        double acc = 0.0;
-        for (int c = 0; c < d; ++c) { double t = q[c] - (double)y[c]; acc = __dadd_rn(acc, __dmul_rn(t, t)); }
-        return acc;
-    }
-    double dot = 0.0, yn = 0.0;
-    for (int c = 0; c < d; ++c) { double v = (double)y[c]; dot = fma(q[c], v, dot); yn = fma(v, v, yn); }
-    double d2 = __dadd_rn(__dadd_rn(xn, __dmul_rn(-2.0, dot)), yn);
-    return d2 > 0.0 ? d2 : 0.0;
+    const TQ *const qa[1] = {q};
+    PairAcc<T, TQ, 1> acc;
+    acc.init();
+    acc.run(qa, 0, d, [&](int c) { return y[c]; }, metric, form);
+    double out[1];
+    acc.finish(&xn, metric, form, out);
+    return out[0];
 }
 
 __device__ __forceinline__ bool pair_before(double va, int64_t ia, double vb, int64_t ib) {
@@ -434,7 +488,9 @@ __device__ __forceinline__ bool pair_before(double va, int64_t ia, double vb, in
 // One wave per query.  Candidates of all reference splits are re-evaluated in float64, ranked by (value, index),
 // the first k are written out.  Certification: every non-candidate has fp32 ranking value >= tau; with the fp32
 // error bound eps_q, the float64 top-k is provably the exact one iff  s_k < tau - eps_q  (s = d^2 - |q|^2).
-template <typename T>
+// GQ (rows wider than KNN_DMAX, round 4): the query row is read from global memory in its own type instead of a float64 copy
+// in LDS (the conversion is exact, the arithmetic the same); the three kernels that stage query rows have this form.
+template <typename T, bool GQ = false>
 __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, const T *__restrict__ qry, int64_t nq,
                                                    int d, const int *__restrict__ cand, const float *__restrict__ cthr,
                                                    int S, int Kc, int k, int metric, int form,
@@ -468,7 +524,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     extern __shared__ __align__(16) unsigned char rr_smem[];
     const int cap = ncap > 0 ? ncap : S * Kc;
     const int ncp = (cap + 1) & ~1;
-    const int qs = q_stride(d);
+    const int qs = GQ ? 0 : q_stride(d);
     double *s_qb = reinterpret_cast<double *>(rr_smem);   // [4][qs]: the four waves' query rows
     double *s_vb = reinterpret_cast<double *>(rr_smem + sizeof(double) * 4 * qs);
     int *s_ib = reinterpret_cast<int *>(s_vb + 4 * ncp);
@@ -482,11 +538,18 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
     if (lane == 0) { s_kc[w] = INFINITY; s_kth[w] = INFINITY; }   // (fewer than k valid candidates: bound = inf)
     const int64_t io = qmap ? (int64_t)qmap[i] : i;
     if (io < 0) return;   // padding row of the bucket-aligned packing
-    double *q = s_qb + (size_t)w * qs;
-    for (int c = lane; c < d; c += 64) q[c] = (double)qry[io * d + c];
+    using TQ = typename std::conditional<GQ, T, double>::type;
+    const TQ *q;
+    if constexpr (GQ) {
+        q = qry + io * d;
+    } else {
+        double *ql = s_qb + (size_t)w * qs;
+        for (int c = lane; c < d; c += 64) ql[c] = (double)qry[io * d + c];
+        q = ql;
+    }
     __builtin_amdgcn_wave_barrier();
     double xn = 0.0;
-    for (int c = 0; c < d; ++c) xn = fma(q[c], q[c], xn);
+    for (int c = 0; c < d; ++c) xn = fma((double)q[c], (double)q[c], xn);
     const int nc_all = S * Kc;
     const int *cq = cand + i * nc_all;
     int nc = 0;   // valid candidates, compacted to the front
@@ -506,7 +569,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         int j = s_vw.i[s];
         if (rmap) j = rmap[j];   // candidate positions refer to the locality-sorted tile image
         double v = INFINITY;
-        if (j >= 0) v = pair_value<T>(q, xn, ref + (int64_t)j * d, d, metric, form);
+        if (j >= 0) v = pair_value<T, TQ>(q, xn, ref + (int64_t)j * d, d, metric, form);
         s_vw.v[s] = v;
         s_vw.i[s] = j >= 0 ? j : 0x7fffffff;
     }
@@ -542,7 +605,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                 double ns = 1.0;
                 if (metric == CM_METRIC_COSINE) { double nx = sqrt(xn); ns = nx > 0.0 ? 1.0 / nx : 1.0; }
                 qn2 = 0.0;
-                for (int c = 0; c < d; ++c) { double v = q[c] * ns - (mean ? mean[c] : 0.0); qn2 = fma(v, v, qn2); }
+                for (int c = 0; c < d; ++c) { double v = (double)q[c] * ns - (mean ? mean[c] : 0.0); qn2 = fma(v, v, qn2); }
             }
             double sk = ((metric == CM_METRIC_COSINE) ? 2.0 * kth : kth) - qn2;
             double ymax = (double)__uint_as_float(gmax[1]);
@@ -628,7 +691,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
 
 static inline size_t rerank_lds_bytes(int S, int Kc, int d = 0) {
     const int ncp = (S * Kc + 1) & ~1;
-    return sizeof(double) * 4 * q_stride(d) + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
+    return sizeof(double) * 4 * (d > KNN_DMAX ? 0 : q_stride(d)) + (size_t)4 * ncp * (sizeof(double) + sizeof(int)) + 64;
 }
 
 // a query whose collection overflowed FB_CAP: handed to knn_fallback_select (ovf = words + 3: ovf[0] = flag "list
@@ -644,7 +707,7 @@ __device__ __forceinline__ void push_overflow(int *ovf, int *ovf_list, int64_t i
 // For queries that could not be certified: one workgroup scans ALL reference rows in float64 (same arithmetic as
 // phase 2), collects every row whose value is <= the k-th candidate value (an upper bound of the true k-th),
 // ranks the collection and overwrites the query's output row.  Rare by construction.
-template <typename T>
+template <typename T, bool GQ = false>
 __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ ref, int64_t n_ref,
                                                            const T *__restrict__ qry, int d, int k, int metric, int form,
                                                            int64_t idx_offset, int flags, const int *__restrict__ flag_list,
@@ -661,14 +724,21 @@ __global__ __launch_bounds__(256) void knn_exact_fallback(const T *__restrict__ 
     for (int f = f_start + blockIdx.x; f < nf; f += gridDim.x) {
         const int64_t i = flag_list[f];
         __syncthreads();
-        for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+        using TQ = typename std::conditional<GQ, T, double>::type;
+        const TQ *q;
+        if constexpr (GQ) {
+            q = qry + i * d;
+        } else {
+            for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+            q = s_q;
+        }
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         double xn = 0.0;
-        for (int c = 0; c < d; ++c) xn = fma(s_q[c], s_q[c], xn);
+        for (int c = 0; c < d; ++c) xn = fma((double)q[c], (double)q[c], xn);
         const double b = bound[i];
         for (int64_t j = threadIdx.x; j < n_ref; j += blockDim.x) {
-            double v = pair_value<T>(s_q, xn, ref + j * d, d, metric, form);
+            double v = pair_value<T, TQ>(q, xn, ref + j * d, d, metric, form);
             if (v <= b) {
                 int pos = atomicAdd(&s_n, 1);
                 if (pos < FB_CAP) { s_v[pos] = v; s_i[pos] = (int)j; }
@@ -794,7 +864,7 @@ __global__ __launch_bounds__(256) void knn_fallback_rank(int k, int metric, int6
 // cells): no collection at all -- k passes over the reference, pass r keeps the smallest (value, index) pair that comes
 // after the pair of pass r - 1.  Same arithmetic (pair_value) and the same order as everywhere else; k x n_ref x d
 // operations per query, for the handful of queries that get here.  One workgroup per query.
-template <typename T>
+template <typename T, bool GQ = false>
 __global__ __launch_bounds__(256) void knn_fallback_select(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry, int d,
                                                            int k, int metric, int form, int64_t idx_offset, int flags,
                                                            const int *__restrict__ ovf, const int *__restrict__ ovf_list,
@@ -809,17 +879,24 @@ __global__ __launch_bounds__(256) void knn_fallback_select(const T *__restrict__
     for (int f = blockIdx.x; f < n; f += gridDim.x) {
         const int64_t i = ovf_list[f];
         __syncthreads();
-        for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+        using TQ = typename std::conditional<GQ, T, double>::type;
+        const TQ *q;
+        if constexpr (GQ) {
+            q = qry + i * d;
+        } else {
+            for (int c = threadIdx.x; c < d; c += blockDim.x) s_q[c] = (double)qry[i * d + c];
+            q = s_q;
+        }
         __syncthreads();
         double xn = 0.0;
-        for (int c = 0; c < d; ++c) xn = fma(s_q[c], s_q[c], xn);
+        for (int c = 0; c < d; ++c) xn = fma((double)q[c], (double)q[c], xn);
         double pv = 0.0;
         long long pj = -1;
         for (int rk = 0; rk < k; ++rk) {
             double bv = INFINITY;
             long long bj = 0x7fffffffffffffffLL;
             for (int64_t j = threadIdx.x; j < n_ref; j += blockDim.x) {
-                const double v = pair_value<T>(s_q, xn, ref + j * d, d, metric, form);
+                const double v = pair_value<T, TQ>(q, xn, ref + j * d, d, metric, form);
                 if ((rk == 0 || pair_before(pv, pj, v, j)) && pair_before(v, j, bv, bj)) { bv = v; bj = j; }
             }
 #pragma unroll
@@ -843,6 +920,152 @@ __global__ __launch_bounds__(256) void knn_fallback_select(const T *__restrict__
                 out_idx[i * k + rk] = (int64_t)bj + idx_offset;
             }
             pv = bv; pj = bj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact scan (no filter) ----------
+// Shapes no filter family serves (round 4: the term-wise metrics beyond 128 columns; k beyond the candidate buffers of the
+// filters): every (query, reference row) value in float64 with pair_value -- the arithmetic and the
+// (value, index) order of the re-rank, so nothing needs certifying -- and a running top-k per query.  A workgroup owns QG
+// queries; thread t evaluates reference row base + t against each of them (query rows straight from global memory: uniform
+// addresses, any width), a value within the query's current k-th value joins its LDS list, a list within 256 entries of its
+// capacity is cut back to its k smallest (rank by counting, written in order), which also gives the next k-th value.
+// Reference rows reach the threads through LDS: XS_T rows x 128 bytes of columns per step, loaded along the rows (coalesced)
+// and read back one row per thread; the queries' columns of the step sit next to them (broadcast reads); the pair accumulators
+// (PairAcc) carry over the column steps.  The cut's scratch shares that buffer (a cut never runs inside a row block).
+constexpr int XS_T = 256;
+template <typename T> __host__ __device__ constexpr int xs_dc() { return 128 / (int)sizeof(T); }   // columns per step
+template <typename T> __host__ __device__ constexpr int xs_dcp() { return xs_dc<T>() + 16 / (int)sizeof(T); }   // row stride: 36 dwords (16-byte reads, no bank conflicts)
+template <typename T> __host__ __device__ constexpr size_t xs_chunk_bytes() { return (size_t)(XS_T * xs_dcp<T>() + 4 * xs_dc<T>()) * sizeof(T); }   // rows + the queries' columns
+template <typename T>
+static inline size_t exact_scan_lds_bytes(int QG, int CAP) {
+    size_t xb = (size_t)CAP * 12 > xs_chunk_bytes<T>() ? (size_t)CAP * 12 : xs_chunk_bytes<T>();
+    xb = (xb + 15) & ~(size_t)15;
+    return (size_t)QG * CAP * 12 + 128 + xb + 32;
+}
+template <typename T, int QG>
+__global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry,
+                                                       int64_t nq, int d, int k, int metric, int form, int64_t idx_offset,
+                                                       int flags, int CAP, void *__restrict__ out_dist,
+                                                       int64_t *__restrict__ out_idx) {
+    constexpr int DC = xs_dc<T>(), DCP = xs_dcp<T>();
+    extern __shared__ __align__(16) unsigned char xs_smem[];
+    size_t xb = (size_t)CAP * 12 > xs_chunk_bytes<T>() ? (size_t)CAP * 12 : xs_chunk_bytes<T>();
+    xb = (xb + 15) & ~(size_t)15;
+    double *s_v = reinterpret_cast<double *>(xs_smem);   // [QG][CAP]: the lists' values
+    double *s_thr = s_v + (size_t)QG * CAP;              // [8] current k-th value per query
+    double *s_xn = s_thr + 8;                            // [8] |q|^2 (sequential fma chain, as the re-rank computes it)
+    unsigned char *s_b = reinterpret_cast<unsigned char *>(s_xn + 8);   // the row block's column step / the cut's scratch
+    T *s_y = reinterpret_cast<T *>(s_b);                 // [XS_T][DCP]
+    T *s_qc = s_y + XS_T * DCP;                          // [QG][DC]
+    double *t_v = reinterpret_cast<double *>(s_b);       // [CAP]
+    int *t_i = reinterpret_cast<int *>(t_v + CAP);       // [CAP]
+    int *s_i = reinterpret_cast<int *>(s_b + xb);        // [QG][CAP]
+    int *s_n = s_i + (size_t)QG * CAP;                   // [8]
+    const int tid = threadIdx.x;
+    const int64_t q0 = (int64_t)blockIdx.x * QG;
+    const int ng = nq - q0 < QG ? (int)(nq - q0) : QG;
+    if (tid < 8) { s_n[tid] = 0; s_thr[tid] = INFINITY; }
+    if (tid < ng) {
+        const T *q = qry + (q0 + tid) * d;
+        double xn = 0.0;
+        for (int c = 0; c < d; ++c) xn = fma((double)q[c], (double)q[c], xn);
+        s_xn[tid] = xn;
+    }
+    __syncthreads();
+    // cut list g back to its k smallest by (value, index), in order (uniform over the workgroup)
+    auto cut = [&](int g) {
+        double *v = s_v + (size_t)g * CAP;
+        int *ix = s_i + (size_t)g * CAP;
+        const int m = s_n[g];
+        for (int s = tid; s < m; s += XS_T) {
+            const double a = v[s];
+            const int id = ix[s];
+            int rk = 0;
+            for (int j = 0; j < m; ++j) rk += pair_before(v[j], ix[j], a, id) ? 1 : 0;
+            if (rk < k) { t_v[rk] = a; t_i[rk] = id; }
+        }
+        __syncthreads();
+        const int keep = m < k ? m : k;
+        for (int s = tid; s < keep; s += XS_T) { v[s] = t_v[s]; ix[s] = t_i[s]; }
+        if (tid == 0) { s_n[g] = keep; if (m >= k) s_thr[g] = t_v[k - 1]; }
+        __syncthreads();
+    };
+    const T *qa[QG], *ql[QG];
+    double xa[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int gg = g < ng ? g : ng - 1;   // (a short last group repeats its last row)
+        qa[g] = qry + (q0 + gg) * d; ql[g] = s_qc + g * DC; xa[g] = s_xn[gg];
+    }
+    // the next step's rows and query columns travel to registers while the current step is evaluated
+    T pre[DC], preq = (T)0;
+    auto fetch = [&](int64_t base, int c0) {
+        const int nv = d - c0 < DC ? d - c0 : DC;
+#pragma unroll
+        for (int it = 0; it < DC; ++it) {
+            const int idx = tid + it * XS_T;
+            const int r = idx / DC, c = idx - r * DC;
+            pre[it] = (base + r < n_ref && c < nv) ? ref[(base + r) * d + c0 + c] : (T)0;
+        }
+        if (tid < QG * DC) {
+            const int g = tid / DC, c = tid - g * DC;
+            preq = c < nv ? qa[g][c0 + c] : (T)0;
+        }
+    };
+    fetch(0, 0);
+    for (int64_t base = 0; base < n_ref; base += XS_T) {
+        const int64_t j = base + tid;
+        PairAcc<T, T, QG> acc;
+        acc.init();
+        for (int c0 = 0; c0 < d; c0 += DC) {
+            const int nv = d - c0 < DC ? d - c0 : DC;
+            __syncthreads();   // (the previous step's readers, or a cut, are done with the buffer)
+#pragma unroll
+            for (int it = 0; it < DC; ++it) {
+                const int idx = tid + it * XS_T;
+                const int r = idx / DC, c = idx - r * DC;
+                s_y[r * DCP + c] = pre[it];
+            }
+            if (tid < QG * DC) s_qc[tid] = preq;
+            __syncthreads();
+            if (c0 + DC < d) fetch(base, c0 + DC);
+            else if (base + XS_T < n_ref) fetch(base + XS_T, 0);
+            if (j < n_ref) {
+                const T *yrow = s_y + tid * DCP;
+                if (nv == DC) acc.template run<DC>(ql, 0, DC, [&](int i) { return yrow[i]; }, metric, form);
+                else acc.run(ql, 0, nv, [&](int i) { return yrow[i]; }, metric, form);
+            }
+        }
+        if (j < n_ref) {
+            double va[QG];
+            acc.finish(xa, metric, form, va);
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const double v = va[g];
+                if (g < ng && v <= s_thr[g]) {
+                    const int pos = atomicAdd(&s_n[g], 1);   // (< CAP: every list entered this pass with 256 free slots)
+                    s_v[(size_t)g * CAP + pos] = v;
+                    s_i[(size_t)g * CAP + pos] = (int)j;
+                }
+            }
+        }
+        __syncthreads();
+        for (int g = 0; g < ng; ++g)
+            if (s_n[g] > CAP - XS_T) cut(g);
+    }
+    for (int g = 0; g < ng; ++g) {
+        cut(g);
+        const int m = s_n[g];
+        const int64_t io = q0 + g;
+        for (int rk = tid; rk < m; rk += XS_T) {
+            const double v = s_v[(size_t)g * CAP + rk];
+            double o = v;
+            if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
+            if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
+            else reinterpret_cast<double *>(out_dist)[io * k + rk] = o;
+            out_idx[io * k + rk] = (int64_t)s_i[(size_t)g * CAP + rk] + idx_offset;
         }
     }
 }
@@ -922,14 +1145,14 @@ struct KnnPlan {
     size_t lds;
 };
 
-cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan *p) {
+// 0: planned; 1: k too large for the on-chip candidate buffers; 2: k too large for the re-rank's lists
+int make_plan_quiet(int64_t n_ref, int64_t nq, int d, int k, KnnPlan *p) {
     p->KP = pick_kp(d);
     // d > 128 (every width the split-fp16 families do not serve): the K-chunked kernel, prepared rows padded to a multiple of its
     // chunk width -- beyond KP = 260 nothing else fits on chip, and from 129 on it is several times faster than the one-piece
     // kernel, whose 128 x KP tile leaves LDS for a single wave of queries (d = 256: 881 -> see DESIGN.md 7b)
     const bool wide = p->KP < 0 || d > 128;
     if (wide) p->KP = (d + 1 + cmk::KCW - 1) / cmk::KCW * cmk::KCW;
-    if (d > KNN_DMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, KNN_DMAX);
     int slack = k / 4 > 8 ? k / 4 : 8;
     p->Kc = k + slack;
     p->C = p->Kc + (wide ? 40 : 64);   // (wide rows: room for four waves next to the 34-KB chunk)
@@ -937,7 +1160,7 @@ cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnP
     for (int nw : {4, 2, 1}) {
         if ((wide ? cmk::phase1_wide_lds_bytes(nw, p->C) : cmk::phase1_lds_bytes(p->KP, nw, p->C)) <= 160 * 1024) { p->NW = nw; break; }
     }
-    if (!p->NW) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip candidate buffers", k);
+    if (!p->NW) return 1;
     p->lds = wide ? cmk::phase1_wide_lds_bytes(p->NW, p->C) : cmk::phase1_lds_bytes(p->KP, p->NW, p->C);
     int QB = p->NW * 32;
     p->nq_pad = (nq + QB - 1) / QB * QB;
@@ -954,7 +1177,13 @@ cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnP
     }
     p->tps = (p->n_tiles + S - 1) / S;
     p->S = (p->n_tiles + p->tps - 1) / p->tps;
-    if (p->S * p->Kc > RR_NCMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large (max %d)", k, RR_NCMAX - 64);
+    if (p->S * p->Kc > RR_NCMAX) return 2;
+    return 0;
+}
+cm_status make_plan(cm_handle_t h, int64_t n_ref, int64_t nq, int d, int k, KnnPlan *p) {
+    const int rc = make_plan_quiet(n_ref, nq, d, k, p);
+    if (rc == 1) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the on-chip candidate buffers", k);
+    if (rc == 2) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large (max %d)", k, RR_NCMAX - 64);
     return CM_OK;
 }
 
@@ -2427,6 +2656,52 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     return CM_OK;
 }
 
+// ---- shapes outside every filter family: the exact scan (knn_exact_scan)
+bool termwise_metric(int metric) {
+    return metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
+}
+bool needs_exact_scan(int64_t n_ref, int64_t nq, int d, int k, int metric) {
+    if (termwise_metric(metric)) return lowd_dpad(d) > 128 || k + knn_slack(k) + 2 * cmk2::CL > 512;   // (the VALU direct filter's limits)
+    if (phase1_path(d, k) != 0) return false;
+    KnnPlan p;
+    return make_plan_quiet(n_ref, nq, d, k, &p) != 0;   // k beyond the f32 filter's candidate buffers
+}
+// list capacity: k, room to grow between cuts (k / 2, at least 256) and the 256 slots one row block can fill
+int exact_scan_cap(int k) { const int c = k + (k / 2 > 256 ? k / 2 : 256) + XS_T; return (c + 255) / 256 * 256; }
+constexpr size_t XS_LDS_MAX = 160 * 1024;
+
+template <typename T>
+cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
+                       int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
+    hipStream_t st = h->stream;
+    const int CAP = exact_scan_cap(k);
+    int QG = 0;
+    for (int g : {4, 2, 1})
+        if (exact_scan_lds_bytes<T>(g, CAP) <= (g == 1 ? XS_LDS_MAX : (size_t)80 * 1024)) { QG = g; break; }   // (two workgroups per CU while the lists allow)
+    if (!QG) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the exact scan's on-chip lists", k);
+    unsigned *words = (unsigned *)cm_ws_alloc(h, 128);
+    if (!words) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    cm_mark(h, 0);
+    hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
+    cm_mark(h, 1);
+    cm_mark(h, 2);
+    cm_mark(h, 3);
+    if (nq > 0) {
+        const size_t lds = exact_scan_lds_bytes<T>(QG, CAP);
+        auto kern = QG == 4 ? knn_exact_scan<T, 4> : (QG == 2 ? knn_exact_scan<T, 2> : knn_exact_scan<T, 1>);
+        CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QG - 1) / QG)), dim3(XS_T), lds, st, d_ref, n_ref, d_qry, nq, d, k, metric, form,
+                           idx_offset, flags, CAP, d_out_dist, d_out_idx);
+        CM_HIP(h, hipGetLastError());
+    }
+    cm_mark(h, 4);
+    CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));   // (no filter: nothing flagged)
+    h->knn_stats[1] = CAP;
+    h->knn_stats[2] = QG;
+    h->knn_stats[3] = 5;
+    return CM_OK;
+}
+
 // Entry point of the search.  d <= 128 (and k small enough for the in-register merges) runs the staged search above;
 // wider rows or very large k use the f32-input MFMA filter (knn_phase1.h: LDS candidate buffers, one pass, certificate
 // from the fmaf-chain bound), then the same re-rank and exact fallback.
@@ -2434,6 +2709,8 @@ template <typename T>
 cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                     int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
+    if (needs_exact_scan(n_ref, nq, d, k, metric))
+        return knn_run_scan<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     if (phase1_path(d, k) != 0 || metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS)
         return knn_run_staged<T>(h, d_ref, n_ref, d_qry, nq, d, k, metric, form, idx_offset, flags, d_out_dist, d_out_idx);
     KnnPlan p;
@@ -2475,13 +2752,18 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     cm_mark(h, 2);
     // fp32 error bound of the MFMA fmaf chain (gamma_n, n = KP + slack for the float conversions): see DESIGN.md
     const float c_eps = (float)(p.KP + 16) * 5.9604645e-8f * 1.01f;
-    hipLaunchKernelGGL(knn_rerank<T>, dim3((unsigned)((nq + 3) / 4)), dim3(256), rerank_lds_bytes(S, Kc, d), st, d_ref, d_qry, nq, d, cand, cthr,
-                       S, Kc, k, metric, form, qnorm, words, c_eps, 0.f, (const float *)nullptr, (const double *)nullptr,
-                       idx_offset, flags, d_out_dist, d_out_idx, flag_list, (int *)(words + 2), bound, (const int *)nullptr, 0,
-                       (const float *)nullptr, 0, (const int *)nullptr);
+    // rows wider than KNN_DMAX: the kernels that stage query rows in LDS read them from global memory instead (GQ), and every
+    // flagged query goes to the one-workgroup-per-query scan (the sliced scan stages reference rows in LDS as well)
+    const bool gq = d > KNN_DMAX;
+    auto rr = gq ? knn_rerank<T, true> : knn_rerank<T, false>;
+    hipLaunchKernelGGL(rr, dim3((unsigned)((nq + 3) / 4)), dim3(256), rerank_lds_bytes(S, Kc, d), st, d_ref, d_qry, nq, d, (const int *)cand,
+                       (const float *)cthr, S, Kc, k, metric, form, (const float *)qnorm, (const unsigned *)words, c_eps, 0.f,
+                       (const float *)nullptr, (const double *)nullptr, idx_offset, flags, d_out_dist, d_out_idx, flag_list,
+                       (int *)(words + 2), bound, (const int *)nullptr, 0, (const float *)nullptr, 0, (const int *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, 0, (float *)nullptr);
     cm_mark(h, 3);
     hipLaunchKernelGGL(zero_words, dim3((FBS_NQ + 255) / 256), dim3(256), 0, st, (unsigned *)fb_count, FBS_NQ);
-    {
+    if (!gq) {
         int rc = (int)((52 * 1024 - (d >= RR_DMAX ? sizeof(double) * FBS_QG * q_stride(d) / 2 : 0)) / ((size_t)d * sizeof(T)));   // rows per staged chunk
         rc = rc >= 256 ? 256 : (rc >= 32 ? rc / 32 * 32 : (rc < 1 ? 1 : rc));
         const size_t fb_lds = (size_t)rc * d * sizeof(T) + sizeof(double) * FBS_QG * q_stride(d);
@@ -2489,15 +2771,17 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds));
         hipLaunchKernelGGL(scan, dim3(FBS_SLICES, FBS_FY), dim3(256), fb_lds, st, d_ref, n_ref, d_qry, d, metric, form, flag_list,
                            (const int *)(words + 2), bound, fb_count, fb_v, fb_i, rc);
+        hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_list,
+                           (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
+                           d_out_idx, (int *)(words + 3), ovf_list);
     }
-    hipLaunchKernelGGL(knn_fallback_rank<T>, dim3(FBS_NQ), dim3(256), 0, st, k, metric, idx_offset, flags, flag_list,
-                       (const int *)(words + 2), (const int *)fb_count, (const double *)fb_v, (const int *)fb_i, d_out_dist,
-                       d_out_idx, (int *)(words + 3), ovf_list);
-    hipLaunchKernelGGL(knn_exact_fallback<T>, dim3(FB_BLOCKS), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
-                       idx_offset, flags, flag_list, (const int *)(words + 2), bound, d_out_dist, d_out_idx,
-                       (int *)(words + 3), ovf_list, FBS_NQ);
+    auto xf = gq ? knn_exact_fallback<T, true> : knn_exact_fallback<T, false>;
+    hipLaunchKernelGGL(xf, dim3(FB_BLOCKS), dim3(256), gq ? 0 : sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
+                       idx_offset, flags, (const int *)flag_list, (const int *)(words + 2), (const double *)bound, d_out_dist, d_out_idx,
+                       (int *)(words + 3), ovf_list, gq ? 0 : FBS_NQ);
     // queries with more than FB_CAP rows inside their bound (words[20] counts them; empty launch otherwise)
-    hipLaunchKernelGGL(knn_fallback_select<T>, dim3(256), dim3(256), sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
+    auto fs = gq ? knn_fallback_select<T, true> : knn_fallback_select<T, false>;
+    hipLaunchKernelGGL(fs, dim3(256), dim3(256), gq ? 0 : sizeof(double) * q_stride(d), st, d_ref, n_ref, d_qry, d, k, metric, form,
                        idx_offset, flags, (const int *)(words + 3), (const int *)ovf_list, d_out_dist, d_out_idx);
     CM_HIP(h, hipGetLastError());
     cm_mark(h, 4);
@@ -2525,6 +2809,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     if (metric == CM_METRIC_CORRELATION)   // float64 centred copies of both sides, then the cosine search over them
         return cm_knn_ws_bytes(n_ref, nq, d, k, CM_F64, CM_METRIC_COSINE) + cm_align(8 * (size_t)n_ref * d) + cm_align(8 * (size_t)nq * d) + 4096;
     (void)dtype;
+    if (needs_exact_scan(n_ref, nq, d, k, metric)) return (size_t)1 << 20;   // (the exact scan keeps its lists on chip)
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
@@ -2592,7 +2877,6 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     if (k < 1 || k > n_ref)
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)n_ref);
     if (n_ref > 0x7fffff00LL) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: more than 2^31 reference rows per shard");
-    if (d > KNN_DMAX) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: embedding dimension %d exceeds the supported maximum of %d", d, KNN_DMAX);
     if (metric == CM_METRIC_CORRELATION) {   // cosine over float64 centred copies (cellmap.h); float64 distances out
         if (dtype != CM_F32 && dtype != CM_F64) CM_FAIL(h, CM_E_INVALID, "k-NN: unknown dtype id %d", dtype);
         double *rc = (double *)cm_ws_alloc(h, 8 * (size_t)n_ref * d), *qc = (double *)cm_ws_alloc(h, 8 * (size_t)(nq > 0 ? nq : 1) * d);
@@ -2615,13 +2899,7 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     const bool ratio_metric = metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
     if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
-    if (metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || ratio_metric) {
-        if (lowd_dpad(d) > 128)
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: the manhattan / chebyshev / canberra / braycurtis metrics are provided for up to 128 dimensions (got %d)", d);
-        if (k + knn_slack(k) + 2 * cmk2::CL > 512)
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors = %d is too large for the manhattan / chebyshev / canberra / braycurtis metrics", k);
-    }
-    if (ratio_metric && dtype == CM_F64) {
+    if (ratio_metric && dtype == CM_F64 && !needs_exact_scan(n_ref, nq, d, k, metric)) {
         // the fp32 filter image flushes magnitudes below float32's normal range: a ratio term |x - y| / (|x| + |y|) of such
         // coordinates would lose all its bits.  One pass over both inputs (read by every later kernel anyway).
         unsigned *tiny = (unsigned *)cm_ws_alloc(h, 256);

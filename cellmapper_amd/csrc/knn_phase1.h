@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, 1) void knn_cand_mfma(const float *__restr
 
 #undef CM_LOAD_TILE
 
-// ---- wide rows (round 3): 260 <= d <= 2047.  The same filter with the contraction CHUNKED over the feature dimension: neither
+// ---- wide rows (round 3: 260 <= d <= 2047; round 4: no upper limit).  The same filter with the contraction CHUNKED over the feature dimension: neither
 // the queries' prepared rows (KP / 2 registers per lane) nor a 128-row reference tile (128 x KP floats of LDS) fit on chip
 // beyond KP = 260, so a tile's four 32 x 32 accumulators (64 registers) stay live while KCW = 64-wide chunks of the tile (LDS,
 // 34 KB) and of the wave's 32 query rows (registers, reloaded per tile: L2 hits) stream through; the filter runs after the

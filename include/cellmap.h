@@ -52,8 +52,9 @@ typedef enum {
 /* Metric pass-through of the reference (knn.py:343,429 hands `metric` to sklearn): the two other Minkowski-family metrics
  * sklearn's trees and brute force share.  Exact like the rest (float64 re-rank in sklearn's arithmetic -- for float32 data
  * brute force the coordinate difference is a float32 and the distance is rounded to float32 once, as DistanceMetric32
- * does -- certificate, fallback); the filter is the fp32 VALU direct-difference kernel, so they are VALU-bound, and the
- * row width is limited to d <= 128 (two queries per lane up to 64 floats per row, one beyond).  CM_E_UNSUPPORTED beyond that. */
+ * does -- certificate, fallback); the filter is the fp32 VALU direct-difference kernel up to d = 128 (two queries per lane up
+ * to 64 floats per row, one beyond), so they are VALU-bound.  Wider rows (round 4) run the exact scan: every pair value in
+ * float64 by the same arithmetic, a running top-k per query (knn_exact_scan) -- no limit on d. */
 #define CM_METRIC_MANHATTAN 2
 #define CM_METRIC_CHEBYSHEV 3
 /* sklearn's "sqeuclidean": always brute force (no tree supports it), EuclideanArgKmin with squared=True -- the euclidean GEMM-form
@@ -69,9 +70,9 @@ typedef enum {
 /* Round 4: sklearn's own DistanceMetric implementations of "canberra" (sum_j |x_j - y_j| / (|x_j| + |y_j|), a 0 / 0 term counts 0)
  * and "braycurtis" (sum_j |x_j - y_j| / sum_j (|x_j| + |y_j|), 0 when the denominator is 0): ArgKmin brute force at d > 15
  * (float32 data: the coordinate difference is a float32, everything else float64, the RESULT rounded to float32 once:
- * DistanceMetric32), ball_tree on float64 copies below.  Same exact machinery and limits as manhattan / chebyshev (fp32
- * VALU direct filter, d <= 128); float64 inputs must not hold non-zero magnitudes below 2^-100 (the filter's float32 copy
- * would flush them: CM_E_UNSUPPORTED).  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
+ * DistanceMetric32), ball_tree on float64 copies below.  Same exact machinery as manhattan / chebyshev (fp32 VALU direct
+ * filter up to d = 128, the exact scan beyond); on the filtered widths float64 inputs must not hold non-zero magnitudes below
+ * 2^-100 (the filter's float32 copy would flush them: CM_E_UNSUPPORTED).  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
 #define CM_METRIC_CANBERRA 6
 #define CM_METRIC_BRAYCURTIS 7
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
@@ -147,8 +148,10 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
  *   ref [n_ref, d], qry [nq, d]  dtype CM_F32 / CM_F64 (both the same)
  *   out_dist: float64 [nq, k] for euclidean; for cosine the input dtype (sklearn keeps float32), [nq, k]
  *   out_idx : int64 [nq, k]
- * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859); d > 2047 -> CM_E_UNSUPPORTED
- * (d <= 61: split-fp16 MFMA filter K = 64; <= 128: K = 128; <= 259: f32 MFMA; <= 2047: f32 MFMA chunked over d). */
+ * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859); k > 4200 -> CM_E_UNSUPPORTED.
+ * No limit on d (d <= 61: split-fp16 MFMA filter K = 64; <= 128: K = 128; beyond: f32 MFMA chunked over d -- past 2047 columns
+ * the re-rank reads its query rows from global memory instead of LDS).  k beyond the filters' candidate buffers (about 190
+ * on the split-fp16 paths, 350 on the f32 path): the exact scan, as for the term-wise metrics beyond 128 columns. */
 cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry, int64_t nq, int32_t d,
                  int32_t dtype, int32_t k, int32_t metric, int32_t form, void *out_dist, int64_t *out_idx);
 

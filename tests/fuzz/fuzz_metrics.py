@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the metric pass-through (run on the GPU box): manhattan, chebyshev, canberra and braycurtis neighbours and distances
-of the GPU search against the CPU oracle (sklearn's DistanceMetric arithmetic, pinned on goldens) over random widths 1..128,
+of the GPU search against the CPU oracle (sklearn's DistanceMetric arithmetic, pinned on goldens) over random widths 1..400 (beyond 128: the exact scan),
 k, dtypes, scales, offsets and duplicated rows -- bit for bit.  Prints one line per case; exits non-zero on a mismatch."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -18,10 +18,10 @@ def main():
     bad = 0
     for case in range(a.cases):
         metric = str(rng.choice(["manhattan", "chebyshev", "canberra", "braycurtis"]))   # (round 4: sklearn's two ratio metrics)
-        d = int(rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 24, 33, 50, 61, 64, 65, 100, 128]))
+        d = int(rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 24, 33, 50, 61, 64, 65, 100, 128, 129, 160, 257, 400]))
         n_ref = int(rng.choice([40, 700, 4097, 9000]))
         nq = int(rng.choice([1, 33, 500]))
-        k = int(min(n_ref, rng.choice([1, 5, 15, 30, 64, 100])))
+        k = int(min(n_ref, rng.choice([1, 5, 15, 30, 64, 100, 100, 450, 1200])))   # (k > ~190: the exact scan)
         dt = np.float64 if rng.random() < 0.4 else np.float32
         scale = float(rng.choice([1e-3, 1.0, 1e3]))
         offset = float(rng.choice([0.0, 0.0, 1e4]))

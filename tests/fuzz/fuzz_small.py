@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check on SMALL shapes (run on the GPU box): reference sets of 1 .. 6 000 rows, 1 .. 1 500 queries, widths
-1 .. 2 047, k from 1 to the reference size (capped at 200), float32 / float64, duplicated rows, all five metrics -- the host tier's
+1 .. 5 000, k from 1 to the reference size (capped at 200; now and then up to 3 000: the exact scan), float32 / float64, duplicated rows, all five metrics -- the host tier's
 cm_knn against the CPU oracle, bit for bit (float32 cosine: sklearn's float32 arithmetic, compared at 4e-7 with tie sets).
 The large-shape fuzzers never visit these corners (k close to n_ref, one query, one reference row per tile ...)."""
 import argparse, json, os, sys, time
@@ -19,12 +19,14 @@ def main():
     bad = 0
     for case in range(a.cases):
         metric = str(rng.choice(["euclidean", "euclidean", "cosine", "manhattan", "chebyshev", "sqeuclidean", "correlation", "canberra", "braycurtis"]))
-        d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259, 260, 300, 512, 777, 1024, 2047]))
-        if metric in ("manhattan", "chebyshev", "canberra", "braycurtis") and d > 128:
-            d = 128
+        d = int(rng.choice([1, 2, 3, 7, 15, 16, 31, 50, 61, 62, 64, 65, 96, 128, 129, 200, 259, 260, 300, 512, 777, 1024, 2047, 2048, 2600, 5000]))
+        if metric in ("manhattan", "chebyshev", "canberra", "braycurtis") and d > 600:
+            d = int(rng.choice([129, 131, 200, 600]))      # (beyond 128 columns: the exact scan)
         n_ref = int(rng.choice([1, 2, 31, 129, 513, 2000, 6000]))
         nq = int(rng.choice([1, 2, 63, 700, 1500]))
-        kmax = min(n_ref, 64 if d > 128 else 200)
+        if d > 2047:
+            nq = min(nq, 300)
+        kmax = min(n_ref, 3000 if rng.random() < 0.08 else 200)      # (large k: beyond the filters' candidate buffers)
         k = int(rng.integers(1, kmax + 1)) if rng.random() < 0.5 else int(min(kmax, rng.choice([1, 15, 30])))
         dt = np.float64 if rng.random() < 0.35 else np.float32
         ref = rng.standard_normal((n_ref, d)).astype(dt)

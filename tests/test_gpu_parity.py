@@ -905,17 +905,63 @@ def test_wide_rows_chunked_filter_is_exact(hip, oracle, d, n_ref, nq, k, dtype, 
         assert np.array_equal(idx, oi) and np.array_equal(dist, od), st
         assert idx[7, 0] == 50 and np.all(dist[7, :8] == 0)
     assert st["lowd_path"] == 1 and st["fallback_queries"] <= max(16, nq // 20), st
-    with pytest.raises(NotImplementedError, match="supported maximum"):
-        hip.knn(np.zeros((100, 2048), np.float32), np.zeros((10, 2048), np.float32), 5)
+
+
+@pytest.mark.parametrize("d,n_ref,nq,k,dtype,metric", [
+    (2048, 1500, 100, 10, np.float32, "euclidean"),     # first width beyond the chunked filter
+    (3000, 1200, 64, 5, np.float64, "euclidean"),
+    (5000, 900, 33, 12, np.float32, "sqeuclidean"),
+    (2500, 1000, 50, 8, np.float32, "cosine"),
+    (2100, 800, 40, 6, np.float32, "correlation"),
+    (2300, 30000, 300, 10, np.float32, "euclidean"),     # reference splits, multi-list re-rank
+    (9000, 600, 40, 5, np.float64, "euclidean"),         # 72-KB rows
+    (130, 3000, 200, 10, np.float32, "manhattan"),      # term-wise metrics beyond the VALU filter's 128 columns
+    (300, 2000, 100, 7, np.float64, "chebyshev"),
+    (200, 2000, 100, 12, np.float32, "canberra"),
+    (150, 2500, 90, 9, np.float64, "braycurtis"),
+    (50, 5000, 50, 1500, np.float32, "euclidean"),      # k beyond every filter's candidate buffers
+    (200, 3000, 21, 700, np.float64, "euclidean"),
+    (20, 4000, 30, 600, np.float32, "manhattan"),
+    (64, 4500, 9, 4200, np.float32, "euclidean"),       # the largest k: one query per workgroup, lists of 6 656
+    (7, 300, 70, 300, np.float32, "chebyshev"),         # k == n_ref
+])
+def test_no_width_limit_and_the_exact_scan(hip, oracle, d, n_ref, nq, k, dtype, metric):
+    """Round 4: no width limit, no 128-column limit for the term-wise metrics, k up to 4 200 (`knn.py:429` and sklearn set
+    none).  Rows beyond 2 047 columns keep the chunked MFMA filter; the re-rank and the exact fallback read the query row from
+    global memory instead of an LDS copy (`GQ`).  Shapes outside every filter family run `knn_exact_scan` -- every pair value
+    in float64 by the re-rank's own arithmetic, a running top-k per query in LDS.  All equal the oracle bit for bit,
+    duplicated rows included."""
+    rng = np.random.default_rng(d * 7 + k)
+    ref = rng.standard_normal((n_ref, d)).astype(dtype)
+    if metric in ("canberra", "braycurtis"):
+        ref[rng.random(ref.shape) < 0.1] = 0
+    ref[50:58] = ref[50]
+    qry = rng.standard_normal((nq, d)).astype(dtype)
+    qry[7] = ref[50]
+    dist, idx = hip.knn(ref, qry, k, metric=metric)
+    st = hip.knn_stats()
+    assert st["lowd_path"] == (1 if d > 2047 else 5) and (d > 2047 or st["fallback_queries"] == 0), st
+    if metric == "cosine":
+        od, oi = oracle.knn_cosine(ref, qry, k)
+        assert (np.sort(idx, 1) == np.sort(oi, 1)).mean() > 0.9999 and np.allclose(dist, od, rtol=0, atol=4e-7)
+    elif metric == "correlation":
+        od, oi = oracle.knn_correlation(ref, qry, k)
+        assert (np.sort(idx, 1) == np.sort(oi, 1)).mean() > 0.9999 and np.allclose(dist, od, rtol=0, atol=1e-13)
+    elif metric in ("euclidean", "sqeuclidean"):
+        od, oi = oracle.knn_euclidean(ref, qry, k, squared=metric == "sqeuclidean")
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+        if metric == "euclidean" and k >= 8:
+            assert idx[7, 0] == 50 and np.all(dist[7, :8] == 0)
+    else:
+        od, oi = oracle.knn_minkowski_family(ref, qry, k, metric)
+        assert np.array_equal(dist, od)
+        ties = dist[:, 1:] == dist[:, :-1]
+        assert np.array_equal(idx[:, 1:][~ties], oi[:, 1:][~ties]) or np.array_equal(idx, oi)
 
 
 def test_metric_passthrough_limits_and_names(hip):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((500, 130)).astype(np.float32)
-    with pytest.raises(NotImplementedError, match="128 dimensions"):
-        hip.knn(x, x[:10], 5, metric="manhattan")
-    with pytest.raises(NotImplementedError, match="128 dimensions"):
-        hip.knn(x, x[:10], 5, metric="braycurtis")          # (built in round 4, same width limit)
     with pytest.raises(ValueError, match="not supported"):
         hip.knn(x, x[:10], 5, metric="mahalanobis")
     tiny = rng.standard_normal((300, 20))
