@@ -983,7 +983,8 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
             const double a = v[s];
             const int id = ix[s];
             int rk = 0;
-            for (int j = 0; j < m; ++j) rk += pair_before(v[j], ix[j], a, id) ? 1 : 0;
+#pragma unroll 8
+            for (int j = 0; j < m; ++j) rk += pair_before(v[j], ix[j], a, id) ? 1 : 0;   // (eight broadcast reads in flight)
             if (rk < k) { t_v[rk] = a; t_i[rk] = id; }
         }
         __syncthreads();
