@@ -23,8 +23,11 @@ BUILD_HINT = (
 CM_F32, CM_F64 = 0, 1
 # metric names as sklearn spells them (the reference hands `metric` to sklearn, knn.py:343,429); minkowski: p = 2, its default
 METRICS = {"euclidean": 0, "l2": 0, "minkowski": 0, "cosine": 1, "manhattan": 2, "cityblock": 2, "l1": 2, "chebyshev": 3, "infinity": 3, "sqeuclidean": 4, "correlation": 5,
-           "canberra": 6, "braycurtis": 7}
-SUPPORTED_METRICS_TEXT = "euclidean / l2 / minkowski (p = 2), sqeuclidean, cosine, correlation, manhattan / cityblock / l1, chebyshev / infinity, canberra, braycurtis"
+           "canberra": 6, "braycurtis": 7,
+           # the counting metrics sklearn takes without parameters (scipy cdist on boolean copies / DistanceMetric on a ball tree)
+           "hamming": 8, "jaccard": 9, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13, "sokalsneath": 14, "yule": 15}
+SUPPORTED_METRICS_TEXT = ("euclidean / l2 / minkowski (p = 2), sqeuclidean, cosine, correlation, manhattan / cityblock / l1, chebyshev / infinity, "
+                          "canberra, braycurtis, hamming, jaccard, dice, rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule")
 FORMS = {"auto": 0, "gemm": 1, "direct": 2}
 KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
 CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK, CM_KNN_F64_OUT = 1, 2, 4

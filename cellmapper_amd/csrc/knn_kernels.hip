@@ -383,14 +383,15 @@ __global__ void prep_rows_lowd(const T *__restrict__ X, int64_t n, int d, int64_
 // over the whole row.
 template <typename T, typename TQ, int NQ>
 struct PairAcc {
-    double a[NQ], b[NQ], yn;
+    double a[NQ], b[NQ], c[NQ], yn;
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int g = 0; g < NQ; ++g) { a[g] = 0.0; b[g] = 0.0; }
+        for (int g = 0; g < NQ; ++g) { a[g] = 0.0; b[g] = 0.0; c[g] = 0.0; }
         yn = 0.0;
     }
     // one loop per (metric family, float32-difference rule): MODE 0 q.y and |y|^2 (cosine, GEMM form), 1 direct squared
-    // differences, 2 manhattan, 3 chebyshev, 4 canberra, 5 braycurtis; F32: the difference is taken in float32 (below)
+    // differences, 2 manhattan, 3 chebyshev, 4 canberra, 5 braycurtis, 6 hamming, 7 the boolean counts; F32: the difference is
+    // taken in float32 (below)
     template <int MODE, bool F32, int UNR, typename YF>
     __device__ __forceinline__ void run_mode(const TQ *const *q, int c0, int n, YF yat) {
         auto step = [&](int i) {
@@ -400,6 +401,13 @@ struct PairAcc {
                 const TQ qv = q[g][c0 + i];
                 if constexpr (MODE == 0) {
                     a[g] = fma((double)qv, (double)yv, a[g]);
+                } else if constexpr (MODE == 6) {   // hamming: coordinates that differ (counts are exact in float64)
+                    a[g] += qv != yv ? 1.0 : 0.0;
+                } else if constexpr (MODE == 7) {   // boolean metrics: ntt, ntf, nft of (x != 0, y != 0)
+                    const bool tq = qv != (TQ)0, ty = yv != (T)0;
+                    a[g] += (tq && ty) ? 1.0 : 0.0;
+                    b[g] += (tq && !ty) ? 1.0 : 0.0;
+                    c[g] += (!tq && ty) ? 1.0 : 0.0;
                 } else if constexpr (MODE == 1) {
                     const double t = (double)qv - (double)yv;
                     a[g] = __dadd_rn(a[g], __dmul_rn(t, t));
@@ -439,16 +447,35 @@ struct PairAcc {
             case CM_METRIC_CHEBYSHEV: if (f32) run_mode<3, true, UNR>(q, c0, n, yat); else run_mode<3, false, UNR>(q, c0, n, yat); return;
             case CM_METRIC_CANBERRA: if (f32) run_mode<4, true, UNR>(q, c0, n, yat); else run_mode<4, false, UNR>(q, c0, n, yat); return;
             case CM_METRIC_BRAYCURTIS: if (f32) run_mode<5, true, UNR>(q, c0, n, yat); else run_mode<5, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_HAMMING: run_mode<6, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_JACCARD: case CM_METRIC_DICE: case CM_METRIC_ROGERSTANIMOTO: case CM_METRIC_RUSSELLRAO:
+            case CM_METRIC_SOKALMICHENER: case CM_METRIC_SOKALSNEATH: case CM_METRIC_YULE: run_mode<7, false, UNR>(q, c0, n, yat); return;
             default: break;
         }
         if (metric != CM_METRIC_COSINE && form == CM_FORM_DIRECT) run_mode<1, false, UNR>(q, c0, n, yat);
         else run_mode<0, false, UNR>(q, c0, n, yat);   // cosine and the GEMM form: q.y per pair, |y|^2 once
     }
-    __device__ __forceinline__ void finish(const double *xn, int metric, int form, double *out) const {
+    // d: the row width (the counting metrics' n)
+    __device__ __forceinline__ void finish(const double *xn, int metric, int form, double *out, int d = 0) const {
         const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
-            if (metric == CM_METRIC_COSINE) {
+            if (metric >= CM_METRIC_HAMMING) {
+                // scipy's cdist kernels (spatial/src/distance_impl.h) and sklearn's DistanceMetric classes: one float64 division
+                // of exact integer counts
+                const double n = (double)d, ntt = a[g], ntf = b[g], nft = c[g], R = ntf + nft, nff = n - ntt - R;
+                double r;
+                switch (metric) {
+                    case CM_METRIC_HAMMING: r = __ddiv_rn(a[g], n); break;
+                    case CM_METRIC_JACCARD: r = (ntt + R) > 0.0 ? __ddiv_rn(R, ntt + R) : 0.0; break;
+                    case CM_METRIC_DICE: r = __ddiv_rn(R, 2.0 * ntt + R); break;   // (0 / 0 = NaN, as upstream)
+                    case CM_METRIC_RUSSELLRAO: r = __ddiv_rn(n - ntt, n); break;
+                    case CM_METRIC_SOKALSNEATH: r = __ddiv_rn(2.0 * R, ntt + 2.0 * R); break;
+                    case CM_METRIC_YULE: r = (ntf * nft) > 0.0 ? __ddiv_rn(2.0 * (ntf * nft), ntt * nff + ntf * nft) : 0.0; break;
+                    default: r = __ddiv_rn(2.0 * R, ntt + nff + 2.0 * R); break;   // rogerstanimoto, sokalmichener
+                }
+                out[g] = r;
+            } else if (metric == CM_METRIC_COSINE) {
                 double nx = sqrt(xn[g]), ny = sqrt(yn);
                 if (!(nx > 0.0)) nx = 1.0;
                 if (!(ny > 0.0)) ny = 1.0;
@@ -1041,10 +1068,10 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
         }
         if (j < n_ref) {
             double va[QG];
-            acc.finish(xa, metric, form, va);
+            acc.finish(xa, metric, form, va, d);
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
-                const double v = va[g];
+                const double v = va[g] == va[g] ? va[g] : (double)INFINITY;   // (a NaN value -- dice / sokalsneath of two all-false rows -- ranks last)
                 if (g < ng && v <= s_thr[g]) {
                     const int pos = atomicAdd(&s_n[g], 1);   // (< CAP: every list entered this pass with 256 free slots)
                     s_v[(size_t)g * CAP + pos] = v;
@@ -1064,6 +1091,7 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
             const double v = s_v[(size_t)g * CAP + rk];
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
+            if ((metric == CM_METRIC_DICE || metric == CM_METRIC_SOKALSNEATH) && !(v < (double)INFINITY)) o = __longlong_as_double(0x7ff8000000000000LL);
             if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
             else reinterpret_cast<double *>(out_dist)[io * k + rk] = o;
             out_idx[io * k + rk] = (int64_t)s_i[(size_t)g * CAP + rk] + idx_offset;
@@ -2662,6 +2690,7 @@ bool termwise_metric(int metric) {
     return metric == CM_METRIC_MANHATTAN || metric == CM_METRIC_CHEBYSHEV || metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
 }
 bool needs_exact_scan(int64_t n_ref, int64_t nq, int d, int k, int metric) {
+    if (metric >= CM_METRIC_HAMMING) return true;   // the counting metrics: no filter at any width
     if (termwise_metric(metric)) return lowd_dpad(d) > 128 || k + knn_slack(k) + 2 * cmk2::CL > 512;   // (the VALU direct filter's limits)
     if (phase1_path(d, k) != 0) return false;
     KnnPlan p;
@@ -2898,7 +2927,8 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         flags |= CM_KNN_SQUARED;
     }
     const bool ratio_metric = metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
-    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric)
+    const bool count_metric = metric >= CM_METRIC_HAMMING && metric <= CM_METRIC_YULE;
+    if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric && !count_metric)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
     if (ratio_metric && dtype == CM_F64 && !needs_exact_scan(n_ref, nq, d, k, metric)) {
         // the fp32 filter image flushes magnitudes below float32's normal range: a ratio term |x - y| / (|x| + |y|) of such

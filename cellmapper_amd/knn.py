@@ -200,6 +200,10 @@ class Neighbors:
         h = _native.default_handle()
         if metric not in _native.METRICS:
             raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: {_native.SUPPORTED_METRICS_TEXT}).")
+        if _native.METRICS[metric] >= 9 and (self.xrep.dtype != bool or self.yrep.dtype != bool):
+            # the boolean metrics read `x != 0`; sklearn says so (metrics/pairwise.py: DataConversionWarning, a UserWarning)
+            import warnings
+            warnings.warn(f"Data was converted to boolean for metric {metric}", UserWarning, stacklevel=2)
         nx, ny = self.xrep.shape[0], self.yrep.shape[0]
         # both representations go to the device ONCE (same dtype rule as the host tier: float32 only if both are);
         # the results stay there (NeighborsResults materialises numpy arrays on first access)

@@ -190,7 +190,8 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int, exchange: 
     return mine
 
 
-SUPPORTED_METRICS = ("euclidean", "sqeuclidean", "cosine", "correlation", "manhattan", "chebyshev", "canberra", "braycurtis")
+SUPPORTED_METRICS = ("euclidean", "sqeuclidean", "cosine", "correlation", "manhattan", "chebyshev", "canberra", "braycurtis",
+                     "hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
 
 
 class ExchangeState:
@@ -248,7 +249,7 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
     slice (``(q_lo, q_hi)`` relative to ``qry``).  ``exchange`` may be an :class:`ExchangeState` (first-step self-check and
     fall-back, see there) passed as ``state``; a plain string runs that exchange unchecked."""
     if metric not in SUPPORTED_METRICS:
-        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, sqeuclidean, cosine, correlation, manhattan, chebyshev, canberra, braycurtis).")
+        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: {', '.join(SUPPORTED_METRICS)}).")
     n_all = dist_mod.get_world_size()
     world = n_all if ref_world is None else ref_world
     rank = dist_mod.get_rank() if ref_rank is None else ref_rank
@@ -375,7 +376,7 @@ def sharded_map_labels(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, 
     Label codes are replicated (A0, ``cellmapper.py:589-623``): the vote needs no communication.
     """
     if metric not in SUPPORTED_METRICS:
-        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: euclidean, sqeuclidean, cosine, correlation, manhattan, chebyshev, canberra, braycurtis).")
+        raise ValueError(f"Metric '{metric}' is not supported by the sharded hip backend (supported: {', '.join(SUPPORTED_METRICS)}).")
     r = sharded_mapping_rows(ops, dist_mod, ref_shard, shard_lo, n_ref_total, qry, k, metric, kernel, epsilon, exchange, group,
                              ref_world, ref_rank, state)
     code, conf = ops.vote(r["cols"], r["vals"], r["cnt"], codes, n_cat)

@@ -75,6 +75,25 @@ typedef enum {
  * 2^-100 (the filter's float32 copy would flush them: CM_E_UNSUPPORTED).  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
 #define CM_METRIC_CANBERRA 6
 #define CM_METRIC_BRAYCURTIS 7
+/* Round 4 (late): the counting metrics sklearn accepts without parameters.  sklearn keeps them away from ArgKmin: brute force
+ * (d > 15) is scipy.spatial.distance.cdist on the data -- converted to boolean (x != 0, DataConversionWarning upstream) for all
+ * but hamming -- and below that the ball tree with sklearn's DistanceMetric classes; both are ratios of the same integer
+ * counts in float64, so one restatement serves both.  With n = d, ntt / ntf / nft / nff the coordinate counts of
+ * (true, true) ... (false, false) and R = ntf + nft:
+ *   hamming #(x_j != y_j) / n (on the values)     jaccard R / (ntt + R), 0 when ntt + R = 0     dice R / (2 ntt + R)
+ *   rogerstanimoto = sokalmichener 2R / (ntt + nff + 2R)     russellrao (n - ntt) / n     sokalsneath 2R / (ntt + 2R)
+ *   yule 2 ntf nft / (ntt nff + ntf nft), 0 when ntf nft = 0 (scipy only: brute force at every d)
+ * dice and sokalsneath are 0 / 0 = NaN between two all-false rows, upstream and here (such a pair ranks last).  No filter:
+ * the exact scan (knn_exact_scan) at every width; float64 distances out.  Neighbours with equal distances are ordered by
+ * index here, arbitrarily upstream (argpartition / tree order): parity is on the distances and on tie groups. */
+#define CM_METRIC_HAMMING 8
+#define CM_METRIC_JACCARD 9
+#define CM_METRIC_DICE 10
+#define CM_METRIC_ROGERSTANIMOTO 11
+#define CM_METRIC_RUSSELLRAO 12
+#define CM_METRIC_SOKALMICHENER 13
+#define CM_METRIC_SOKALSNEATH 14
+#define CM_METRIC_YULE 15
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt

@@ -262,6 +262,11 @@ def main():
         rz = np.random.default_rng(24)
         xrz[rz.random(xrz.shape) < 0.2] = 0.0
         yrz[rz.random(yrz.shape) < 0.2] = 0.0
+        rb_ = np.random.default_rng(25)
+        xb = (rb_.random((1200, 40)) < 0.33).astype(np.float32) * rb_.uniform(0.5, 3.0, (1200, 40)).astype(np.float32)
+        yb = (rb_.random((150, 40)) < 0.33).astype(np.float32) * rb_.uniform(0.5, 3.0, (150, 40)).astype(np.float32)
+        xh = rb_.integers(0, 3, (1200, 40)).astype(np.float32)
+        yh = rb_.integers(0, 3, (150, 40)).astype(np.float32)
         cases = {
             "synth_f32_manhattan_k15": (xr, yr, 15, "manhattan", "X_emb"),
             "synth_f64_manhattan_k30": (xr64, yr64, 30, "manhattan", "X_emb"),
@@ -286,6 +291,21 @@ def main():
             "synth_f32_braycurtis_k15": (xrz, yrz, 15, "braycurtis", "X_emb"),
             "synth_f64_braycurtis_k30": (xr64, yr64, 30, "braycurtis", "X_emb"),
             "synth_d10_braycurtis_k15": (xr10, yr10, 15, "braycurtis", "X_emb"),
+            # round 4 (late): the counting metrics (scipy cdist on boolean copies under brute force, DistanceMetric on a ball
+            # tree at d <= 15).  Binary-ish rows (a third non-zero; hamming: small integer values so that coordinates can agree)
+            "bin40_hamming_k15": (xh, yh, 15, "hamming", "X_emb"),
+            "bin10_hamming_k10": (xh[:, :10].copy(), yh[:, :10].copy(), 10, "hamming", "X_emb"),
+            "bin40_jaccard_k15": (xb, yb, 15, "jaccard", "X_emb"),
+            "bin10_jaccard_k10": (xb[:, :10].copy(), yb[:, :10].copy(), 10, "jaccard", "X_emb"),
+            "bin40_dice_k15": (xb, yb, 15, "dice", "X_emb"),
+            "bin40_rogerstanimoto_k15": (xb, yb, 15, "rogerstanimoto", "X_emb"),
+            "bin40_russellrao_k15": (xb, yb, 15, "russellrao", "X_emb"),
+            "bin40_sokalmichener_k15": (xb, yb, 15, "sokalmichener", "X_emb"),
+            "bin40_sokalsneath_k15": (xb, yb, 15, "sokalsneath", "X_emb"),
+            "bin10_sokalsneath_k10": (xb[:, :10].copy(), yb[:, :10].copy(), 10, "sokalsneath", "X_emb"),
+            "bin40_yule_k15": (xb, yb, 15, "yule", "X_emb"),
+            # (no d = 10 case for yule: no tree has the metric -- brute force at every width -- and at ten columns most of the k
+            #  nearest distances are exactly 0, which the reference's gaussian kernel turns into NaN weights)
         }
         only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. `--only metrics sqeuclidean`: just the cases of one metric
         for name, (a_, b_, k_, m_, key_) in cases.items():

@@ -17,7 +17,9 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for case in range(a.cases):
-        metric = str(rng.choice(["manhattan", "chebyshev", "canberra", "braycurtis"]))   # (round 4: sklearn's two ratio metrics)
+        metric = str(rng.choice(["manhattan", "chebyshev", "canberra", "braycurtis", "canberra", "braycurtis", "manhattan", "chebyshev",   # (round 4: sklearn's two ratio metrics)
+                                 "hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule"]))   # (and the counting metrics)
+        counting = metric in orc.COUNT_METRICS
         d = int(rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 24, 33, 50, 61, 64, 65, 100, 128, 129, 160, 257, 400]))
         n_ref = int(rng.choice([40, 700, 4097, 9000]))
         nq = int(rng.choice([1, 33, 500]))
@@ -36,11 +38,19 @@ def main():
             qry[-1] = 0
         if rng.random() < 0.3:                         # integer-valued coordinates: masses of tied distances
             ref = np.round(ref / scale * 2).astype(dt); qry = np.round(qry / scale * 2).astype(dt)
+        if counting:                                   # small integers (hamming) / sparse non-zero patterns with all-false rows
+            if metric == "hamming":
+                ref = rng.integers(0, 3, (n_ref, d)).astype(dt); qry = rng.integers(0, 3, (nq, d)).astype(dt)
+            else:
+                dens = float(rng.choice([0.05, 0.3, 0.7]))
+                ref = ((rng.random((n_ref, d)) < dens) * rng.uniform(0.5, 3.0, (n_ref, d))).astype(dt)
+                qry = ((rng.random((nq, d)) < dens) * rng.uniform(0.5, 3.0, (nq, d))).astype(dt)
+                ref[1] = 0; qry[-1] = 0
         t0 = time.perf_counter()
         try:
             dist, idx = h.knn(ref, qry, k, metric=metric)
-            od, oi = orc.knn_minkowski_family(ref, qry, k, metric)
-            ok = bool(np.array_equal(idx, oi) and np.array_equal(dist, od))
+            od, oi = orc.knn_count_family(ref, qry, k, metric) if counting else orc.knn_minkowski_family(ref, qry, k, metric)
+            ok = bool(np.array_equal(idx, oi) and np.array_equal(dist, od, equal_nan=True))
             note = ""
         except NotImplementedError as e:               # more than 4 096 rows tied at a k-th distance: refused, never wrong
             ok, note = "overflow" in str(e), "overflow"

@@ -52,6 +52,25 @@ def exact_dist(ref, qry_row, cols, metric):
         return np.divide(np.abs(r - q).sum(1), den, out=np.zeros_like(den), where=den > 0)
     if metric == "sqeuclidean":
         return ((r - q) ** 2).sum(1)
+    if metric == "hamming":
+        return (r != q).sum(1) / float(r.shape[1])
+    if metric in ("jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule"):
+        rb, qb = r != 0, q != 0
+        n = float(r.shape[1])
+        ntt = (rb & qb).sum(1).astype(np.float64); ntf = (qb & ~rb).sum(1).astype(np.float64); nft = (~qb & rb).sum(1).astype(np.float64)
+        R = ntf + nft; nff = n - ntt - R
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if metric == "jaccard":
+                return np.divide(R, ntt + R, out=np.zeros_like(R), where=(ntt + R) > 0)
+            if metric == "dice":
+                return R / (2.0 * ntt + R)
+            if metric == "russellrao":
+                return (n - ntt) / n
+            if metric == "sokalsneath":
+                return (2.0 * R) / (ntt + 2.0 * R)
+            if metric == "yule":
+                return np.divide(2.0 * ntf * nft, ntt * nff + ntf * nft, out=np.zeros_like(R), where=(ntf * nft) > 0)
+            return (2.0 * R) / (ntt + nff + 2.0 * R)
     return np.sqrt(((r - q) ** 2).sum(1))
 
 

@@ -63,6 +63,31 @@ def test_map_matches_reference(name, kern):
     assert "label_pred_colors" in qry.uns
 
 
+@pytest.mark.parametrize("name", ["bin40_jaccard_k15", "bin10_hamming_k10", "bin40_yule_k15"])
+def test_counting_metrics_through_the_class(name):
+    """`metric=` is handed through (cellmapper.py:251 -> knn.py:429): a boolean metric warns that the data is read as `x != 0`
+    (sklearn's DataConversionWarning is a UserWarning), hamming does not; distances equal the reference's bit for bit, neighbours
+    up to the ties upstream orders arbitrarily."""
+    import warnings
+    from cellmapper_amd import CellMapper
+
+    g = load_golden(name)
+    qry, ref = build_pair(g)
+    metric = str(g["metric"])
+    cm = CellMapper(qry, ref)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        cm.compute_neighbors(n_neighbors=int(g["k"]), use_rep="X_emb", metric=metric, only_yx=True)
+    said = any("converted to boolean" in str(x.message) for x in w)
+    assert said == (metric != "hamming")
+    assert np.array_equal(cm.knn.yx.distances, g["yx_dist"], equal_nan=True)
+    n = min(50, g["xrep"].shape[1])
+    assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, g["yx_dist"], g["yx_idx"], g["xrep"][:, :n], g["yrep"][:, :n], metric)
+    cm.compute_mapping_matrix(method="gaussian")
+    cm.map_obs(key="label")
+    assert qry.obs["label_pred"].notna().all()
+
+
 def test_sparse_layer_and_full_mode_and_jaccard():
     from cellmapper_amd import CellMapper
 

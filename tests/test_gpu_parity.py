@@ -850,6 +850,49 @@ def test_metric_passthrough_is_bit_exact(hip, oracle, metric, dtype, d, n_ref, n
     assert np.array_equal(d2, d3) and np.array_equal(i2, i3)
 
 
+COUNT_METRICS = ("hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
+
+
+@pytest.mark.parametrize("metric", COUNT_METRICS)
+@pytest.mark.parametrize("dtype,d,n_ref,nq,k", [(np.float32, 40, 5000, 300, 15), (np.float64, 200, 3000, 150, 30),
+                                                (np.float32, 10, 4000, 200, 8), (np.float32, 1000, 1500, 64, 10)])
+def test_counting_metrics_are_bit_exact(hip, oracle, metric, dtype, d, n_ref, nq, k):
+    """Round 4 (late): the counting metrics sklearn takes without parameters (`knn.py:429` hands any name through): hamming on
+    the values, the boolean family on `x != 0` -- scipy `cdist` under brute force, sklearn's DistanceMetric on the ball tree,
+    one float64 division of the same integer counts either way.  The exact scan gives the oracle's distances AND neighbours
+    bit for bit (ties by index on both sides; the oracle is pinned on the reference by tests/golden/bin*), all-false rows
+    included (dice / sokalsneath: NaN against another all-false row, ranked last)."""
+    rng = np.random.default_rng(900 + d)
+    if metric == "hamming":
+        ref = rng.integers(0, 3, (n_ref, d)).astype(dtype)
+        qry = rng.integers(0, 3, (nq, d)).astype(dtype)
+    else:
+        dens = 0.3 if d <= 200 else 0.05
+        ref = ((rng.random((n_ref, d)) < dens) * rng.uniform(0.5, 3.0, (n_ref, d))).astype(dtype)
+        qry = ((rng.random((nq, d)) < dens) * rng.uniform(0.5, 3.0, (nq, d))).astype(dtype)
+        ref[7] = 0; ref[8] = 0; qry[5] = 0            # all-false rows on both sides
+    ref[100:120] = ref[100]
+    qry[3] = ref[100]
+    dist, idx = hip.knn(ref, qry, k, metric=metric)
+    st = hip.knn_stats()
+    od, oi = oracle.knn_count_family(ref, qry, k, metric)
+    assert dist.dtype == np.float64 and st["lowd_path"] == 5
+    assert np.array_equal(dist, od, equal_nan=True) and np.array_equal(idx, oi)
+    assert idx[3, 0] == 100 or dist[3, 0] == 0
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("bin")])
+def test_counting_metric_goldens(hip, name):
+    """The reference's own output (tests/golden/bin*, made through `oracle/make_golden.py`): distances bit for bit; neighbours
+    up to the order and the choice inside tied distances, which upstream leaves to argpartition / the tree's heap."""
+    g = load_golden(name)
+    xrep, yrep = rep(g)
+    metric = str(g["metric"])
+    dist, idx = hip.knn(xrep, yrep, int(g["k"]), metric=metric)
+    assert np.array_equal(dist, g["yx_dist"], equal_nan=True)
+    assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
+
+
 @pytest.mark.parametrize("dtype,d,n_ref,nq,k", [(np.float32, 50, 12000, 700, 30), (np.float64, 33, 9000, 500, 15),
                                                 (np.float32, 10, 12000, 800, 8), (np.float32, 2, 6000, 6000, 20),
                                                 (np.float32, 128, 6000, 300, 30)])

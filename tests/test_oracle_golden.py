@@ -6,7 +6,8 @@ import scipy.sparse as sp
 
 from parity import (RTOL_FLOAT, assert_csr_close, assert_knn_parity, golden_csr, golden_names, load_golden, tie_rows)
 
-MAPPING_CASES = [n for n in golden_names() if n.startswith(("synth_", "spatial", "identity"))]
+MAPPING_CASES = [n for n in golden_names() if n.startswith(("synth_", "spatial", "identity", "bin"))]
+COUNT_METRICS = ("hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
 KERNELS = ["gaussian", "scarches", "inverse_distance", "equal"]
 
 
@@ -28,6 +29,11 @@ def test_oracle_matches_reference(name, oracle):
         dist, idx = oracle.knn_minkowski_family(xrep, yrep, k, metric)
         if metric in ("canberra", "braycurtis"):
             assert np.array_equal(dist, g["yx_dist"])   # distances bit for bit (neighbours: tie groups, below)
+    elif metric in COUNT_METRICS:
+        # ratios of integer counts: the distances bit for bit; equal distances are ordered arbitrarily upstream (argpartition under
+        # brute force, heap order on the ball tree) and discrete values tie in masses, also across the k-th position
+        dist, idx = oracle.knn_count_family(xrep, yrep, k, metric)
+        assert np.array_equal(dist, g["yx_dist"], equal_nan=True)
     elif metric == "correlation":
         dist, idx = oracle.knn_correlation(xrep, yrep, k)
     elif metric == "sqeuclidean":
@@ -42,7 +48,7 @@ def test_oracle_matches_reference(name, oracle):
     assert dist.dtype == g["yx_dist"].dtype
     n_tie = assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
     trows = tie_rows(idx, g["yx_idx"])
-    if "dups" not in name:
+    if "dups" not in name and metric not in COUNT_METRICS:
         assert len(trows) == 0, f"{n_tie} rows differ only by tie order, {len(trows)} by tie membership"
     # feed the GOLDEN graph into the downstream stages so each stage is pinned independently
     gd, gi = g["yx_dist"], g["yx_idx"]  # float32 for sklearn cosine on float32 input
