@@ -971,8 +971,8 @@ static inline size_t exact_scan_lds_bytes(int QG, int CAP) {
     xb = (xb + 15) & ~(size_t)15;
     return (size_t)QG * CAP * 12 + 128 + xb + 32;
 }
-template <typename T, int QG>
-__global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry,
+template <typename T, int QG, bool VEC>
+__global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry,
                                                        int64_t nq, int d, int k, int metric, int form, int64_t idx_offset,
                                                        int flags, int CAP, void *__restrict__ out_dist,
                                                        int64_t *__restrict__ out_idx) {
@@ -1028,14 +1028,34 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
         qa[g] = qry + (q0 + gg) * d; ql[g] = s_qc + g * DC; xa[g] = s_xn[gg];
     }
     // the next step's rows and query columns travel to registers while the current step is evaluated
+    // (16-byte pieces when every row segment is aligned -- d a multiple of 4 floats / 2 doubles: a quarter of the load and store
+    //  instructions; single elements otherwise)
+    constexpr int E = 16 / (int)sizeof(T), NP = DC / E;   // elements per piece, pieces per row and step (8)
+    struct alignas(16) P16 { T v[E]; };
+    constexpr bool vec = VEC;   // (host: d a multiple of E and the reference 16-byte aligned)
     T pre[DC], preq = (T)0;
     auto fetch = [&](int64_t base, int c0) {
         const int nv = d - c0 < DC ? d - c0 : DC;
+        const T *rb = ref + base * d + c0;
+        if constexpr (vec) {
 #pragma unroll
-        for (int it = 0; it < DC; ++it) {
-            const int idx = tid + it * XS_T;
-            const int r = idx / DC, c = idx - r * DC;
-            pre[it] = (base + r < n_ref && c < nv) ? ref[(base + r) * d + c0 + c] : (T)0;
+            for (int it = 0; it < NP; ++it) {
+                const int idx = tid + it * XS_T;
+                const int r = idx / NP, pc = idx - r * NP;
+                P16 x;
+#pragma unroll
+                for (int e = 0; e < E; ++e) x.v[e] = (T)0;
+                if (base + r < n_ref && (pc + 1) * E <= nv) x = *reinterpret_cast<const P16 *>(rb + (r * d + pc * E));   // (32-bit offsets from a uniform base)
+#pragma unroll
+                for (int e = 0; e < E; ++e) pre[it * E + e] = x.v[e];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < DC; ++it) {
+                const int idx = tid + it * XS_T;
+                const int r = idx / DC, c = idx - r * DC;
+                pre[it] = (base + r < n_ref && c < nv) ? rb[r * d + c] : (T)0;
+            }
         }
         if (tid < QG * DC) {
             const int g = tid / DC, c = tid - g * DC;
@@ -1050,11 +1070,23 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
         for (int c0 = 0; c0 < d; c0 += DC) {
             const int nv = d - c0 < DC ? d - c0 : DC;
             __syncthreads();   // (the previous step's readers, or a cut, are done with the buffer)
+            if constexpr (vec) {
 #pragma unroll
-            for (int it = 0; it < DC; ++it) {
-                const int idx = tid + it * XS_T;
-                const int r = idx / DC, c = idx - r * DC;
-                s_y[r * DCP + c] = pre[it];
+                for (int it = 0; it < NP; ++it) {
+                    const int idx = tid + it * XS_T;
+                    const int r = idx / NP, pc = idx - r * NP;
+                    P16 x;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) x.v[e] = pre[it * E + e];
+                    *reinterpret_cast<P16 *>(s_y + r * DCP + pc * E) = x;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < DC; ++it) {
+                    const int idx = tid + it * XS_T;
+                    const int r = idx / DC, c = idx - r * DC;
+                    s_y[r * DCP + c] = pre[it];
+                }
             }
             if (tid < QG * DC) s_qc[tid] = preq;
             __syncthreads();
@@ -1062,7 +1094,7 @@ __global__ __launch_bounds__(XS_T) void knn_exact_scan(const T *__restrict__ ref
             else if (base + XS_T < n_ref) fetch(base + XS_T, 0);
             if (j < n_ref) {
                 const T *yrow = s_y + tid * DCP;
-                if (nv == DC) acc.template run<DC>(ql, 0, DC, [&](int i) { return yrow[i]; }, metric, form);
+                if (nv == DC) acc.template run<8>(ql, 0, DC, [&](int i) { return yrow[i]; }, metric, form);   // (eight columns in flight: a full unroll spills)
                 else acc.run(ql, 0, nv, [&](int i) { return yrow[i]; }, metric, form);
             }
         }
@@ -2718,7 +2750,9 @@ cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_
     cm_mark(h, 3);
     if (nq > 0) {
         const size_t lds = exact_scan_lds_bytes<T>(QG, CAP);
-        auto kern = QG == 4 ? knn_exact_scan<T, 4> : (QG == 2 ? knn_exact_scan<T, 2> : knn_exact_scan<T, 1>);
+        const bool vec = d % (16 / (int)sizeof(T)) == 0 && (reinterpret_cast<uintptr_t>(d_ref) & 15) == 0;   // 16-byte row pieces
+        auto kern = vec ? (QG == 4 ? knn_exact_scan<T, 4, true> : (QG == 2 ? knn_exact_scan<T, 2, true> : knn_exact_scan<T, 1, true>))
+                        : (QG == 4 ? knn_exact_scan<T, 4, false> : (QG == 2 ? knn_exact_scan<T, 2, false> : knn_exact_scan<T, 1, false>));
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QG - 1) / QG)), dim3(XS_T), lds, st, d_ref, n_ref, d_qry, nq, d, k, metric, form,
                            idx_offset, flags, CAP, d_out_dist, d_out_idx);
