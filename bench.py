@@ -240,6 +240,7 @@ def host_inclusive_leg(a, ref_np, qry_np, codes_np):
     t0 = time.perf_counter()
     one_pass()
     first = time.perf_counter() - t0
+    al = h.alloc_stats()
     for _ in range(max(0, a.warmup - 1)):
         one_pass()
     per = []
@@ -252,9 +253,58 @@ def host_inclusive_leg(a, ref_np, qry_np, codes_np):
     h.close()
     return {"seconds": mean, "value": qry_np.shape[0] / mean, "unit": "query cells/s", "steps": a.steps, "warmup": a.warmup,
             "seconds_min": float(min(per)), "seconds_max": float(max(per)), "first_pass_seconds": first,
+            "first_pass_allocator_ms": {"workspace_alloc": al["workspace_ms"], "workspace_bytes": al["workspace_bytes"],
+                                        "pool_alloc": al["pool_ms"], "pool_bytes": al["pool_bytes"], "pool_allocs": al["pool_calls"],
+                                        "free": al["free_ms"], "cm_create_before_the_pass": al["create_ms"]},
             "what": "numpy in -> numpy out through the graph tier of the C ABI (cm_rep_create x2 incl. the NaN/inf screen, "
                     "cm_graph_knn, cm_graph_mapping, cm_graph_label_vote), H2D/D2H included; mean of `steps` passes after "
                     "`warmup` untimed ones on one handle"}, code, conf
+
+
+def dropin_leg(a, ref_np, qry_np, codes_np, device_code=None):
+    """ONE ``CellMapper(query, reference).map(obs_keys=...)`` on a FRESH handle -- the reference's actual usage (one map() per
+    problem, cellmapper.py:426-491): pandas / numpy in, ``query.obs[label_pred]`` / ``[label_conf]`` out, handle creation
+    (code-object loading), every allocation and both PCIe directions inside the timed region.  Then a second map() on new
+    objects with the same process-wide handle."""
+    import pandas as pd
+
+    from cellmapper_amd import CellMapper, MiniAnnData, _native
+
+    os.environ.setdefault("CELLMAP_DEVICES", os.environ.get("LOCAL_RANK", "0"))   # (this rank's GPU only)
+    os.environ.setdefault("LOGLEVEL", "WARNING")
+    _native.reset_default_handle()
+    cats = [f"c{i:02d}" for i in range(a.ncat)]
+
+    def objects():
+        R = MiniAnnData(X=np.zeros((ref_np.shape[0], 1), np.float32),
+                        obs=pd.DataFrame({"label": pd.Categorical.from_codes(codes_np, categories=cats)}), obsm={"X_pca": ref_np})
+        Q = MiniAnnData(X=np.zeros((qry_np.shape[0], 1), np.float32), obsm={"X_pca": qry_np})
+        return Q, R
+
+    def one():
+        Q, R = objects()
+        t0 = time.perf_counter()
+        CellMapper(Q, R).map(obs_keys="label", use_rep="X_pca", n_neighbors=a.k, metric=a.metric, only_yx=True, mapping_method=a.kernel)
+        return time.perf_counter() - t0, Q
+
+    first, Q = one()
+    al = _native.default_handle().alloc_stats()
+    pred = Q.obs["label_pred"].cat.codes.to_numpy()
+    same = None if device_code is None else bool(np.array_equal(pred.astype(np.int64), device_code.astype(np.int64)))
+    del Q
+    second, Q2 = one()
+    del Q2
+    _native.reset_default_handle()
+    return {"first_call_seconds": first, "value_first_call": qry_np.shape[0] / first, "second_call_seconds": second,
+            "value_second_call": qry_np.shape[0] / second, "unit": "query cells/s",
+            "what": "CellMapper(query, reference).map(obs_keys='label', use_rep='X_pca', n_neighbors=k, only_yx=True) on MiniAnnData "
+                    "objects, process-wide handle created INSIDE the first call (cm_create + code loading + every hipMalloc + "
+                    "H2D + search + kernel + vote + D2H + pandas assembly); second = the same on new objects, same handle",
+            "first_call_allocator": {"cm_create_ms": al["create_ms"], "code_load_ms": al["preload_ms"],
+                                     "workspace_alloc_ms": al["workspace_ms"], "workspace_bytes": al["workspace_bytes"],
+                                     "pool_alloc_ms": al["pool_ms"], "pool_bytes": al["pool_bytes"], "pool_allocs": al["pool_calls"],
+                                     "free_ms": al["free_ms"]},
+            "labels_equal_device_tier": same}
 
 
 def git_rev(path):
@@ -484,7 +534,9 @@ def main_rank(a):
     from cellmapper_amd.device import DevicePipeline
     from cellmapper_amd.sharded import sharded_mapping_rows
 
+    t_h0 = time.perf_counter()
     pipe = DevicePipeline(local_rank)
+    handle_create_ms = (time.perf_counter() - t_h0) * 1e3
     pipe.h.set_profiling(True)
     ctx = RunCtx(a, torch, dist, world, rank, dev, pipe, use_dist)
     lay = ctx.lay
@@ -534,11 +586,41 @@ def main_rank(a):
 
     # the FIRST call on the fresh handle pays what later calls skip: the pilot (~5 ms), the bucket-pruning gate (~1 ms), the
     # workspace allocation, code-object loading -- and at N > 1 the exchange self-check; reported as `first_call_ms`
+    if os.environ.get("CELLMAP_BENCH_RESERVE", "1") != "0" and not use_dist:
+        # size the handle's workspace for THIS problem when the handle is set up (cm_reserve_workspace), as a service that
+        # knows its problem sizes would: the first call then allocates nothing.  Timed and reported (`workspace_reserve_ms`).
+        t_r0 = time.perf_counter()
+        reserved = pipe.h.reserve(a.nref, a.nq, a.d, a.k, metric=a.metric)
+        reserve_ms = (time.perf_counter() - t_r0) * 1e3
+    else:
+        reserved, reserve_ms = 0, 0.0
     torch.cuda.synchronize()
+    al0 = pipe.h.alloc_stats()
+    tmem0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) if hasattr(torch.cuda, "memory_stats") else 0
     tf0 = time.perf_counter()
     out = step()
+    t_ret = time.perf_counter()
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - tf0) * 1e3
+    al1 = pipe.h.alloc_stats()
+    st1 = pipe.h.stage_times() if not use_dist else {}
+    kern1 = float(sum(st1.values()))
+    # where the first call's wall time went: the handle's allocator clock (wall time inside hipMalloc / hipFree, by kind), the
+    # HIP-event stage times of that very call, and the rest (host work of the call: launches, the structure pre-test's host
+    # read, lazily loaded code objects, torch's allocation of the two output arrays)
+    first_call_breakdown = {
+        "workspace_alloc": al1["workspace_ms"] - al0["workspace_ms"],
+        "workspace_alloc_bytes": al1["workspace_bytes"] - al0["workspace_bytes"],
+        "rep_alloc": al1["pool_ms"] - al0["pool_ms"], "rep_alloc_bytes": al1["pool_bytes"] - al0["pool_bytes"],
+        "device_free": al1["free_ms"] - al0["free_ms"],
+        "kernels": kern1, "kernels_by_stage": st1,
+        "host_other": first_call_ms - kern1 - (al1["workspace_ms"] - al0["workspace_ms"]) - (al1["pool_ms"] - al0["pool_ms"]) - (al1["free_ms"] - al0["free_ms"]),
+        "call_returned_after": (t_ret - tf0) * 1e3,
+        "torch_device_allocs_in_call": (torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - tmem0) if hasattr(torch.cuda, "memory_stats") else None,
+        "before_the_call": {"handle_create_ms": handle_create_ms, "cm_create_ms": al1["create_ms"], "code_load_ms": al1["preload_ms"],
+                            "workspace_reserve_ms": reserve_ms, "workspace_reserved_bytes": reserved,
+                            "workspace_reserve_hipMalloc_ms": al0["workspace_ms"]},
+    }
     for _ in range(max(0, a.warmup - 1)):
         out = step()
     torch.cuda.synchronize()
@@ -634,6 +716,8 @@ def main_rank(a):
             # wall time of the first call on the fresh handle (pilot, pruning gate, workspace allocation, code loading and --
             # at N > 1 -- the exchange self-check included): what a first CellMapper.map() pays and the timed steps do not
             "first_call_ms": first_call_ms,
+            "first_call_breakdown_ms": first_call_breakdown,
+            "handle_create_ms": handle_create_ms,
             "config": {"workload": f"{a.nq} query x {a.nref} reference cells, d={a.d}, k={a.k}, {a.metric}, {a.kernel} kernel, "
                                    f"{CONFIGS[a.config]['what']}; {world} GPU(s) = {lay.n_groups} query "
                                    f"group(s) x {lay.ref_shards} reference shard(s), exchange="
@@ -725,8 +809,12 @@ def main_rank(a):
             # fixes `value` as the device-resident rate (inputs in HBM when the timed region starts), so both are in the
             # line under the same step / warm-up protocol and this key says which is which
             result["value_host_inclusive"] = hrec["value"]
+            drec = dropin_leg(a, ref_np, qry.cpu().numpy(), codes.cpu().numpy(), out[0].cpu().numpy())
+            result["dropin"] = drec
+            result["value_dropin_first_call"] = drec["value_first_call"]
             result["value_definitions"] = {"value": "device-resident (bench contract: inputs resident in HBM)",
-                                           "value_host_inclusive": "host arrays in -> host results out, PCIe included (SURVEY.md 8d's wording of the metric)"}
+                                           "value_host_inclusive": "host arrays in -> host results out, PCIe included (SURVEY.md 8d's wording of the metric)",
+                                           "value_dropin_first_call": "ONE CellMapper(query, reference).map(obs_keys=...) on a fresh handle, everything included (the reference's usage)"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -38,7 +38,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = [
-    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_pool_trim", "cm_reload_knobs", "cm_last_error", "cm_set_stream", "cm_synchronize",
+    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_pool_trim", "cm_workspace_bytes", "cm_reserve_workspace", "cm_alloc_stats", "cm_reload_knobs", "cm_last_error", "cm_set_stream", "cm_synchronize",
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
@@ -69,6 +69,10 @@ def load_library():
         lib.cm_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         lib.cm_destroy.argtypes = [vp]
         lib.cm_pool_trim.argtypes = [vp]
+        lib.cm_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32]
+        lib.cm_workspace_bytes.restype = i64
+        lib.cm_reserve_workspace.argtypes = [vp, i64]
+        lib.cm_alloc_stats.argtypes = [vp, vp]
         lib.cm_reload_knobs.argtypes = []
         lib.cm_last_error.argtypes = [vp]
         lib.cm_last_error.restype = C.c_char_p
@@ -127,7 +131,7 @@ def load_library():
         lib.cm_device_count.argtypes = []
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("cm_version", "cm_device_count", "cm_last_error", "cm_payload_index_len"):
+            if name not in ("cm_version", "cm_device_count", "cm_last_error", "cm_payload_index_len", "cm_workspace_bytes"):
                 fn.restype = C.c_int
         _lib = lib
         return lib
@@ -194,6 +198,27 @@ class Handle:
     def trim(self):
         """Return the handle's cached device blocks to the HIP allocator (``cm_pool_trim``)."""
         self.call("cm_pool_trim")
+
+    def reserve(self, n_ref: int, nq: int, d: int, k: int, dtype=np.float32, metric: str = "euclidean"):
+        """Allocate the device workspace of a problem of this shape NOW (``cm_reserve_workspace``): the first search of that
+        problem then allocates nothing.  Returns the bytes reserved."""
+        b = int(self.lib.cm_workspace_bytes(int(n_ref), int(nq), int(d), CM_F64 if np.dtype(dtype) == np.float64 else CM_F32,
+                                            int(k), METRICS[metric]))
+        if b < 0:
+            raise ValueError("reserve: bad problem shape")
+        self.call("cm_reserve_workspace", b)
+        return b
+
+    def alloc_stats(self):
+        """Wall time this handle has spent inside the device allocator since it was created (``cm_alloc_stats``)."""
+        o = np.zeros(16, np.float64)
+        self.call("cm_alloc_stats", _ptr(o))
+        kinds = ["workspace", "pool", "free", "pinned"]
+        rec = {f"{kinds[i]}_ms": float(o[i]) for i in range(4)}
+        rec.update({f"{kinds[i]}_bytes": float(o[4 + i]) for i in range(4) if i != 2})
+        rec.update({f"{kinds[i]}_calls": int(o[8 + i]) for i in range(4)})
+        rec.update(create_ms=float(o[12]), preload_ms=float(o[13]), workspace_capacity=float(o[14]), workspace_peak_bytes=float(o[15]))
+        return rec
 
     def set_stream(self, stream_ptr):
         self.call("cm_set_stream", C.c_void_p(int(stream_ptr) if stream_ptr else 0))
@@ -580,6 +605,16 @@ def default_devices():
         return [int(os.environ.get("CELLMAP_DEVICE", os.environ.get("LOCAL_RANK", "0")))]
     n = int(load_library().cm_device_count())
     return list(range(max(n, 1)))
+
+
+def reset_default_handle() -> None:
+    """Destroy the process-wide handle (the next :func:`default_handle` creates a fresh one).  Objects that still hold device
+    state of the old handle (``DeviceRep`` / ``DeviceGraph``) must be gone before this is called."""
+    global _default
+    with _default_lock:
+        if _default is not None:
+            _default.close()
+            _default = None
 
 
 def default_handle() -> Handle:

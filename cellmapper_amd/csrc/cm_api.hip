@@ -8,6 +8,7 @@
 #include <cstring>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 
@@ -52,6 +53,20 @@ void latch_knobs() {
 }
 std::mutex g_err_mu;
 std::string g_create_err;
+static inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// every device allocation / release of the library goes through these two: the handle keeps the wall time by kind
+// (cm_alloc_stats), so a slow first call can be attributed (bench.py: first_call_breakdown_ms)
+hipError_t timed_malloc(cm_handle_t h, void **p, size_t bytes, int kind) {
+    const double t0 = wall_ms();
+    const hipError_t e = hipMalloc(p, bytes);
+    if (h) { h->alloc_ms[kind] += wall_ms() - t0; h->alloc_bytes[kind] += (double)bytes; h->alloc_calls[kind] += 1; }
+    return e;
+}
+void timed_free(cm_handle_t h, void *p) {
+    const double t0 = wall_ms();
+    (void)hipFree(p);
+    if (h) { h->alloc_ms[2] += wall_ms() - t0; h->alloc_calls[2] += 1; }
+}
 void a3_session_drop(cm_handle_t h);
 void xfer_drop(cm_handle_t h);
 
@@ -71,17 +86,17 @@ void *pool_take(cm_handle_t h, size_t bytes, size_t *got) {
 }
 void pool_release(cm_handle_t h, void *p, size_t bytes) {
     const size_t cap = h ? h->pool_cap : 0;
-    if (!h || bytes > cap / 2) { (void)hipFree(p); return; }
+    if (!h || bytes > cap / 2) { timed_free(h, p); return; }
     h->pool.emplace_back(bytes, p);
     h->pool_bytes += bytes;
     while (h->pool_bytes > cap && !h->pool.empty()) {   // evict the oldest blocks
-        (void)hipFree(h->pool.front().second);
+        timed_free(h, h->pool.front().second);
         h->pool_bytes -= h->pool.front().first;
         h->pool.erase(h->pool.begin());
     }
 }
 void pool_drop(cm_handle_t h) {
-    for (auto &b : h->pool) (void)hipFree(b.second);
+    for (auto &b : h->pool) timed_free(h, b.second);
     h->pool.clear();
     h->pool_bytes = 0;
 }
@@ -97,7 +112,7 @@ struct DevBuf {  // RAII device allocation used by the host tier (pooled per han
     ~DevBuf() { release(); }
     void release() {
         if (p) {
-            if (owner) pool_release(owner, p, cap); else (void)hipFree(p);
+            if (owner) pool_release(owner, p, cap); else timed_free(nullptr, p);
             p = nullptr;
         }
     }
@@ -107,10 +122,10 @@ struct DevBuf {  // RAII device allocation used by the host tier (pooled per han
         bytes = (bytes + 255) & ~size_t(255);
         owner = h;
         if ((p = pool_take(h, bytes, &cap)) != nullptr) return CM_OK;
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e = timed_malloc(h, &p, bytes, 1);
         if (e != hipSuccess && h && !h->pool.empty()) {   // give the pool back to the allocator and retry
             pool_drop(h);
-            e = hipMalloc(&p, bytes);
+            e = timed_malloc(h, &p, bytes, 1);
         }
         if (e != hipSuccess) { p = nullptr; CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
         cap = bytes;
@@ -123,7 +138,7 @@ cm_status begin_call(cm_handle_t h, size_t ws_bytes) {
     if (!h) return CM_E_INVALID;
     h->err.clear();
     CM_HIP(h, hipSetDevice(h->device));
-    h->ws_off = 0;
+    cm_ws_reset(h);
     return cm_ws_reserve(h, ws_bytes);
 }
 
@@ -171,7 +186,9 @@ cm_status xfer_get(cm_handle_t h, Xfer **out) {
     x->T = T;
     x->slot = kn.xfer_slot_kb > 0 ? ((size_t)kn.xfer_slot_kb << 10) : ((size_t)4 << 20);
     h->xfer = x;
+    const double t0 = wall_ms();
     hipError_t e = hipHostMalloc((void **)&x->pinned, x->slot * 2 * (size_t)T, hipHostMallocDefault);
+    h->alloc_ms[3] += wall_ms() - t0; h->alloc_bytes[3] += (double)(x->slot * 2 * (size_t)T); h->alloc_calls[3] += 1;
     if (e != hipSuccess) { x->pinned = nullptr; xfer_drop(h); CM_FAIL(h, CM_E_NOMEM, "hipHostMalloc(staging ring) failed: %s", hipGetErrorString(e)); }
     x->st.assign(T, nullptr); x->ev.assign(2 * T, nullptr);
     for (auto &s : x->st) if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
@@ -382,23 +399,43 @@ void cm_mark(cm_handle_t h, int which) {
 }
 
 // ----------------------------------------------------------------------------- workspace ------------
+static cm_status ws_add_segment(cm_handle_t h, size_t bytes) {
+    char *p = nullptr;
+    hipError_t e = timed_malloc(h, (void **)&p, bytes, 0);
+    if (e != hipSuccess && !h->pool.empty()) {   // give the host tier's parked blocks back to the allocator and retry
+        pool_drop(h);
+        e = timed_malloc(h, (void **)&p, bytes, 0);
+    }
+    if (e != hipSuccess) CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes of workspace) failed: %s", bytes, hipGetErrorString(e));
+    h->ws_segs.push_back({p, bytes, 0});
+    h->ws_cap += bytes;
+    return CM_OK;
+}
 cm_status cm_ws_reserve(cm_handle_t h, size_t bytes) {
     bytes = cm_align(bytes) + 4096;
     if (bytes <= h->ws_cap) return CM_OK;
-    if (h->ws) { CM_HIP(h, hipStreamSynchronize(h->stream)); CM_HIP(h, hipFree(h->ws)); h->ws = nullptr; h->ws_cap = 0; }
-    hipError_t e = hipMalloc((void **)&h->ws, bytes);
-    if (e != hipSuccess) CM_FAIL(h, CM_E_NOMEM, "hipMalloc(%zu bytes of workspace) failed: %s", bytes, hipGetErrorString(e));
-    h->ws_cap = bytes;
-    return CM_OK;
+    return ws_add_segment(h, std::max<size_t>(bytes - h->ws_cap, (size_t)1 << 20));
+}
+void cm_ws_reset(cm_handle_t h) {
+    for (auto &s : h->ws_segs) s.off = 0;
+    h->ws_used = 0;
 }
 void *cm_ws_alloc(cm_handle_t h, size_t bytes) {
     bytes = cm_align(bytes ? bytes : 1);
-    if (h->ws_off + bytes > h->ws_cap) {
-        if (cm_get_knobs().dbg_ws) fprintf(stderr, "[cellmap dbg] workspace: request of %zu bytes at offset %zu exceeds the capacity %zu\n", bytes, h->ws_off, h->ws_cap);
-        return nullptr;
+    cm_handle_s::ws_seg *hit = nullptr;
+    for (auto &s : h->ws_segs)
+        if (s.off + bytes <= s.cap) { hit = &s; break; }
+    if (!hit) {   // no segment has room: grow (at least 64 MB, at most what is asked for plus a sixteenth of what the handle holds)
+        const size_t seg = std::max(bytes, std::max<size_t>((size_t)64 << 20, h->ws_cap / 16));
+        if (cm_get_knobs().dbg_ws) fprintf(stderr, "[cellmap dbg] workspace: request of %zu bytes does not fit the %zu segments (%zu bytes): adding %zu\n", bytes, h->ws_segs.size(), h->ws_cap, seg);
+        (void)hipSetDevice(h->device);
+        if (ws_add_segment(h, seg) != CM_OK) return nullptr;
+        hit = &h->ws_segs.back();
     }
-    void *p = h->ws + h->ws_off;
-    h->ws_off += bytes;
+    void *p = hit->p + hit->off;
+    hit->off += bytes;
+    h->ws_used += bytes;
+    if (h->ws_used > h->ws_peak) h->ws_peak = h->ws_used;
     return p;
 }
 
@@ -420,6 +457,7 @@ cm_status cm_reload_knobs(void) {
 cm_status cm_create(int device, cm_handle_t *out) {
     if (!out) return CM_E_INVALID;
     *out = nullptr;
+    const double t_create0 = wall_ms();
     std::call_once(g_knobs_once, latch_knobs);   // the CELLMAP_* knobs are read by the FIRST cm_create (and by cm_reload_knobs), never on a call path
     auto fail = [&](const char *what, hipError_t e) {
         std::lock_guard<std::mutex> g(g_err_mu);
@@ -443,14 +481,37 @@ cm_status cm_create(int device, cm_handle_t *out) {
         h->pool_cap = (hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? std::min<size_t>(total_b / 8, (size_t)32 << 30) : ((size_t)8 << 30);
         if (cm_get_knobs().pool_mb >= 0) h->pool_cap = (size_t)cm_get_knobs().pool_mb << 20;
     }
+    const double t_pre0 = wall_ms();
     if (!cm_get_knobs().no_preload) {   // load the hot path's code objects now, not inside the first call
         cm_preload_knn(h->stream); cm_preload_q4(h->stream); cm_preload_f16(h->stream); cm_preload_graph(h->stream);   // (the opt-in / K = 128 kernels load on first use)
         hipLaunchKernelGGL(add_offset_i64_touch, dim3(1), dim3(64), 0, h->stream);
         (void)hipStreamSynchronize(h->stream);
         (void)hipGetLastError();
     }
+    h->preload_ms = wall_ms() - t_pre0;
+    h->create_ms = wall_ms() - t_create0;
     *out = h;
     return CM_OK;
+}
+
+cm_status cm_alloc_stats(cm_handle_t h, double out[16]) {
+    if (!h || !out) return CM_E_INVALID;
+    for (int i = 0; i < 4; ++i) { out[i] = h->alloc_ms[i]; out[4 + i] = h->alloc_bytes[i]; out[8 + i] = h->alloc_calls[i]; }
+    out[12] = h->create_ms; out[13] = h->preload_ms; out[14] = (double)h->ws_cap; out[15] = (double)h->ws_peak;
+    return CM_OK;
+}
+
+int64_t cm_workspace_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, int32_t k, int32_t metric) {
+    if (n_ref < 1 || nq < 0 || d < 1 || k < 1 || (dtype != CM_F32 && dtype != CM_F64)) return -1;
+    const size_t nk = (size_t)nq * (size_t)k;   // + the fused pipeline's own lists (cm_map_labels_dev)
+    return (int64_t)(cm_knn_ws_bytes(n_ref, nq, d, k, dtype, metric) + cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024);
+}
+
+cm_status cm_reserve_workspace(cm_handle_t h, int64_t bytes) {
+    if (!h || bytes < 0) return CM_E_INVALID;
+    h->err.clear();
+    CM_HIP(h, hipSetDevice(h->device));
+    return cm_ws_reserve(h, (size_t)bytes);
 }
 
 cm_status cm_pool_trim(cm_handle_t h) {
@@ -469,7 +530,8 @@ cm_status cm_destroy(cm_handle_t h) {
     h->peers.clear();
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    if (h->ws) (void)hipFree(h->ws);
+    for (auto &sg : h->ws_segs) (void)hipFree(sg.p);
+    h->ws_segs.clear();
     a3_session_drop(h);
     pool_drop(h);
     xfer_drop(h);
@@ -727,7 +789,7 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     int64_t nflag = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         int64_t nqc = std::min<int64_t>(chunk, nq - q0);
-        h->ws_off = 0;
+        cm_ws_reset(h);
         CM_TRY(h2d(h, dq.p, (const char *)qry + es * q0 * d, es * nqc * d));
         CM_TRY(nonfinite_enqueue(h, dq.p, es * nqc * d, dtype, dflag.as<int>() + 1, 13));
         CM_TRY(sync(h));

@@ -39,10 +39,16 @@ struct cm_handle_s {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
-    // grow-only device workspace, carved by a bump allocator that is reset at the start of every API call
-    char *ws = nullptr;
-    size_t ws_cap = 0;
-    size_t ws_off = 0;
+    // grow-only device workspace in SEGMENTS, carved by a bump allocator that is reset at the start of every API call
+    // (cm_ws_reset).  Segment 0 is what a call reserves on entry for its common route (cm_ws_reserve); a route that needs more
+    // (bucket pruning, the centred level, the f32 family's split lists ...) adds segments on demand inside cm_ws_alloc --
+    // pointers handed out earlier stay valid, nothing is freed before cm_destroy.  (Round 5: one worst-case block used to be
+    // reserved up front, 16 GB at BASELINE config 2, of which the structure-free route touches 3.)
+    struct ws_seg { char *p; size_t cap; size_t off; };
+    std::vector<ws_seg> ws_segs;
+    size_t ws_cap = 0;    // sum of the segments' capacities
+    size_t ws_used = 0;   // bytes carved since the last reset
+    size_t ws_peak = 0;   // ... largest value of that over the handle's life
     int64_t knn_stats[4] = {0, 0, 0, 0};
     int n_cu = 0;   // compute units of the device (lazily queried)
     const void *a3_index = nullptr;   // last payload index whose header this handle has read (A3, wave-sliced kernel)
@@ -71,6 +77,12 @@ struct cm_handle_s {
     std::vector<cm_handle_s *> peers;
     bool multi_checked = false;        // the peer-copy exchange of this handle has been checked against the host-staged route (first sharded graph)
     bool multi_route_staged = false;   // ... and failed: every later graph exchanges through host memory
+    // allocator clock (cm_alloc_stats): wall time this handle has spent inside the device allocator, by kind --
+    // 0 workspace hipMalloc, 1 pooled blocks (representations, results, payloads) hipMalloc, 2 hipFree, 3 pinned host memory
+    double alloc_ms[4] = {0, 0, 0, 0};
+    double alloc_bytes[4] = {0, 0, 0, 0};
+    double alloc_calls[4] = {0, 0, 0, 0};
+    double create_ms = 0, preload_ms = 0;   // wall time of cm_create as a whole / of its code-object preload
     // optional per-stage timing (cm_set_profiling): events recorded on h->stream around the stages of the last call
     bool profiling = false;
     hipEvent_t ev[CM_N_STAGE_EVENTS] = {};
@@ -108,8 +120,9 @@ void cm_preload_r16(hipStream_t st);
 void cm_preload_graph(hipStream_t st);
 
 // ---- workspace ----
-cm_status cm_ws_reserve(cm_handle_t h, size_t bytes);  // may reallocate: call BEFORE launching work that uses ws
-void *cm_ws_alloc(cm_handle_t h, size_t bytes);         // 256-B aligned carve; nullptr when exhausted
+cm_status cm_ws_reserve(cm_handle_t h, size_t bytes);  // total capacity >= bytes (adds a segment; never moves or frees one)
+void *cm_ws_alloc(cm_handle_t h, size_t bytes);         // 256-B aligned carve; adds a segment when none has room; nullptr = out of device memory
+void cm_ws_reset(cm_handle_t h);                        // start of a call: every segment is free again (stream order protects the previous call's kernels)
 static inline size_t cm_align(size_t b) { return (b + 255) & ~size_t(255); }
 
 // ---- k-NN (knn_kernels.hip) ----

@@ -173,7 +173,7 @@ extern "C" cm_status cm_shared_neighbors(cm_handle_t h, const int64_t *yx, const
     if (k < 1 || k > 1024 || nq < 0 || nr < 1) CM_FAIL(h, CM_E_INVALID, "shared neighbours: bad shape (k=%d)", k);
     if (transform < 0 || transform > 2) CM_FAIL(h, CM_E_INVALID, "shared neighbours: unknown transform %d", transform);
     CM_HIP(h, hipSetDevice(h->device));
-    h->ws_off = 0;
+    cm_ws_reset(h);
     CM_TRY(cm_ws_reserve(h, cm_scan_ws_bytes(std::max(nq, nr)) * 2 + 65536));
     DevBuf dyx, dxx, dyy, dxy, txx_ptr, txx, txy_ptr, txy, tot, rn, optr, oc, ov, gs, mx;
     CM_TRY(dyx.alloc(h, 8 * (size_t)nq * k)); CM_TRY(dyy.alloc(h, 8 * (size_t)nq * k));
@@ -183,9 +183,9 @@ extern "C" cm_status cm_shared_neighbors(cm_handle_t h, const int64_t *yx, const
     CM_HIP(h, hipMemcpyAsync(dxx.p, xx, 8 * (size_t)nr * k, hipMemcpyHostToDevice, h->stream));
     CM_HIP(h, hipMemcpyAsync(dxy.p, xy, 8 * (size_t)nr * k, hipMemcpyHostToDevice, h->stream));
     CM_TRY(build_transpose(h, dxx.as<int64_t>(), nr, k, nr, txx_ptr, txx));  // columns: reference cells
-    h->ws_off = 0;
+    cm_ws_reset(h);
     CM_TRY(build_transpose(h, dxy.as<int64_t>(), nr, k, nq, txy_ptr, txy));  // columns: query cells
-    h->ws_off = 0;
+    cm_ws_reset(h);
     CM_TRY(tot.alloc(h, 4 * (size_t)nq)); CM_TRY(rn.alloc(h, 4 * (size_t)nq)); CM_TRY(optr.alloc(h, 8 * ((size_t)nq + 1)));
     CM_TRY(mx.alloc(h, 16));
     CM_HIP(h, hipMemsetAsync(mx.p, 0, 16, h->stream));

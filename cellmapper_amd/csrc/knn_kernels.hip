@@ -2869,6 +2869,11 @@ static __global__ void tiny_nonzero_f64(const double *__restrict__ x, int64_t n,
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// Workspace a search reserves on entry: what the COMMON route of a problem of this shape carves (every unconditional array
+// of knn_run_staged / knn_run_t, the structure pre-test, the threshold seeds, the locality sort).  Routes only clustered or
+// difficult data take -- bucket pruning (a candidate list per query and sub-bucket: 5.7 GB at config 2), the bucket-centred
+// level (256 side values per reference row: 1.5 GB) -- add a workspace segment when they run (cm_ws_alloc grows on demand);
+// round 4 reserved the sum of every route up front: 16 GB at config 2, of which the benchmark's route touches 3.
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric) {
     if (metric == CM_METRIC_CORRELATION)   // float64 centred copies of both sides, then the cosine search over them
         return cm_knn_ws_bytes(n_ref, nq, d, k, CM_F64, CM_METRIC_COSINE) + cm_align(8 * (size_t)n_ref * d) + cm_align(8 * (size_t)nq * d) + 4096;
@@ -2877,7 +2882,10 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     int slack = knn_slack_level(k, 1);
     int Kc = k + slack;
     int64_t nq_pad = (nq + 511) / 512 * 512;
-    size_t b = 512 * 1024 + (1 << 20) /* structure pre-test (sg_*) */ + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * nq_pad * 16 * Kc) + cm_align(4 * nq_pad * 16) +
+    // rows of the per-split candidate lists: reference splits exist only while there are fewer query blocks than resident
+    // workgroups (make_plan / make_plan2), so blocks x splits stays below twice the resident count
+    const int64_t split_rows = std::min<int64_t>(nq_pad * 16, nq_pad + (int64_t)2 * 640 * 512);
+    size_t b = 512 * 1024 + (1 << 20) /* structure pre-test (sg_*) */ + 2 * cm_align(4 * nq_pad) + cm_align(sizeof(int) * split_rows * Kc) + cm_align(4 * split_rows) +
                cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 4096 + cm_align(4 * FBS_NQ) + cm_align((size_t)12 * FBS_NQ * FB_CAP) + cm_align(4 * OVF_CAP) + 1024;
     // (d <= 128 always takes the staged sizing: the manhattan / chebyshev metrics run the staged search whatever k is, and
     //  this function does not see the metric)
@@ -2885,31 +2893,18 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         int KSTEPS = d + cmk2::NORM_SLOTS <= 32 ? 2 : (d + cmk2::NORM_SLOTS <= 64 ? 4 : 8);
         int64_t n_tiles = (n_ref + cmk2::BR - 1) / cmk2::BR;
         size_t tileb = (size_t)cmk2::tile_bytes(KSTEPS > 4 ? KSTEPS : 4) + 1024;   // any tile image of the staged search: <= 256 B per row
-        b += cm_align((size_t)n_tiles * tileb + 65536) + cm_align((size_t)nq_pad * (KSTEPS > 4 ? cmk2::row_bytes(KSTEPS) : 256));
+        const int64_t pack_slack = (int64_t)256 * cmk2::QB;
+        b += cm_align((size_t)n_tiles * tileb + 65536) + cm_align((size_t)(nq_pad + pack_slack) * (KSTEPS > 4 || lowd_dpad(d) > 64 ? 512 : 256));
         b += cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * (Kc + 16)) + cm_align(sizeof(uint2) * (size_t)320 * 8 * 128 * 2 * cmk2::CL);
-        // staged search (knn_run_staged): subset stages may use more reference splits, second flag list, pilot sample
-        b += cm_align(sizeof(int) * (size_t)(nq_pad + cmk2::QB * 512) * (Kc + 16)) + cm_align(4 * (size_t)(nq_pad + cmk2::QB * 512)) +
-             cm_align(4 * (nq + 1)) + 65536;
-        {   // candidate rows of a split four-accumulator stage (cand_rows in knn_run_staged)
-            const int64_t extra = std::min<int64_t>(3 * (nq_pad + 1024), 2000000 + 2048);
-            b += cm_align(sizeof(int) * (size_t)extra * (Kc + 16)) + cm_align(4 * (size_t)extra);
-        }
-        b += 3 * cm_align((size_t)256 * 512 * 4) + cm_align((size_t)256 * 512 * 512);   // slack rows of the bucket-aligned packing
-        b += cm_align(4 * (size_t)(nq + 1)) + cm_align(4 * (size_t)(nq_pad + 1024 + 256 * 512)) + 4096;   // per-query seeds of the subset stages
+        // staged search (knn_run_staged): the candidate buffer serves subset stages with more reference splits than the full set
+        const int64_t cand_rows = std::max<int64_t>(std::max<int64_t>(split_rows, nq_pad + (int64_t)cmk2::QB * 512),
+                                                    std::min<int64_t>(4 * (nq_pad + 1024), nq_pad + 1024 + 2000000));
+        b += cm_align(sizeof(int) * (size_t)cand_rows * (Kc + 16)) + cm_align(4 * (size_t)cand_rows) + 3 * cm_align(4 * (size_t)(nq_pad + pack_slack)) +
+             3 * cm_align(4 * (nq + 1)) + cm_align(8 * (nq + 1)) + 65536;
         b += cm_align((size_t)(n_ref / 16 + 512) * 136) + cm_align(4 * (size_t)(n_ref / 16 + 256)) +
              cm_align(4 * (size_t)(nq_pad + 1024)) + 4096;   // threshold seeds: hi-only image of a 1/R sample (R >= 16), row map, seeds
         if (d <= 3) b += cm_grid_ws_bytes(n_ref, cm_grid_ncell_max(n_ref, k));
-        b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 4096;   // locality sort
-        if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
-            b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
-                 cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
-        if (d + cmk2::NORM_SLOTS <= 64 && nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
-            const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 512 + 1;
-            b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
-                 cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
-                 cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
-            b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;   // bucket-sorted flag lists of the subset stages
-        }
+        b += cm_align(4 * (size_t)std::max<int64_t>(n_ref, nq)) + cm_align(4 * (size_t)n_ref) + cm_align(4 * (size_t)nq) + 3 * cm_align(4 * (size_t)(nq + 1)) + 65536;   // locality sort
     }
     if (!use_f16_path(d, k)) {   // f32-input kernel: prepared rows of KP floats
         int KP = pick_kp(d);
@@ -2917,7 +2912,7 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
         int64_t nref_pad = (n_ref + cmk::BR - 1) / cmk::BR * cmk::BR;
         b += cm_align(sizeof(float) * nref_pad * KP) + cm_align(sizeof(float) * nq_pad * KP);
     }
-    return b + (b >> 6) + (8u << 20);   // (+1.5 % and 8 MB: alignment of the many small allocations of the staged search)
+    return b + (b >> 6) + (8u << 20);   // (+1.5 % and 8 MB: alignment of the many small allocations)
 }
 
 // "correlation" (scipy.spatial.distance.cdist through sklearn's brute force): x - mean(x) per row, in float64.  One wave per row.

@@ -141,6 +141,17 @@ cm_status cm_destroy(cm_handle_t h);
  * a call path. */
 cm_status cm_pool_trim(cm_handle_t h);
 cm_status cm_reload_knobs(void);
+/* Allocation ahead of the first call (no reference counterpart: the reference allocates nothing it could pre-size).
+ * cm_workspace_bytes = device workspace the k-NN -> kernel -> vote pipeline needs for a problem of this shape (the figure
+ * cm_knn_dev / cm_map_labels_dev / cm_graph_knn reserve on entry; -1 on a bad shape); cm_reserve_workspace grows the handle's
+ * workspace to at least `bytes` NOW, so that the first call of a problem finds it (the workspace is grow-only, in segments --
+ * a route that needs more than was reserved adds a segment inside the call -- and is never returned before cm_destroy).  cm_alloc_stats: wall time this handle has spent inside the device allocator since cm_create --
+ * out[0..3] milliseconds, out[4..7] bytes, out[8..11] calls, each by kind (0 workspace hipMalloc, 1 pooled blocks of the
+ * host / graph tiers, 2 hipFree, 3 pinned host memory); out[12] = milliseconds cm_create took, out[13] of which the
+ * code-object preload; out[14] = workspace capacity (all segments), out[15] = most workspace bytes any one call has carved.  (bench.py: first_call_breakdown_ms) */
+int64_t cm_workspace_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, int32_t k, int32_t metric);
+cm_status cm_reserve_workspace(cm_handle_t h, int64_t bytes);
+cm_status cm_alloc_stats(cm_handle_t h, double out[16]);
 const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
 cm_status cm_set_stream(cm_handle_t h, void *hip_stream); /* NULL = the handle's own stream */
 cm_status cm_synchronize(cm_handle_t h);
