@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=8192, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--check", type=int, default=4096, help="queries verified against the CPU oracle (0 = skip)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-in -> host-out measurement")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the Gaussian-mixture leg of config 2")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0 = pick)")
     a = ap.parse_args(argv)
     c = CONFIGS[a.config]
@@ -228,17 +229,26 @@ def host_inclusive_leg(a, ref_np, qry_np, codes_np):
 
     h = _native.Handle(int(os.environ.get("LOCAL_RANK", "0")))   # ONE device (the process-wide default handle may span the node)
 
-    def one_pass():
+    def one_pass(times=None):
+        tp = [time.perf_counter()]
         xr, yr = _native.DeviceRep(h, ref_np), _native.DeviceRep(h, qry_np)
+        tp.append(time.perf_counter())
         g = _native.DeviceGraph(h, xr, yr, a.k, a.metric)
+        tp.append(time.perf_counter())
         xr.close(); yr.close()
         g.mapping(a.kernel)
+        tp.append(time.perf_counter())
         out = g.label_vote(codes_np, a.ncat)
         g.close()
+        tp.append(time.perf_counter())
+        if times is not None:
+            times.update({n: (tp[i + 1] - tp[i]) * 1e3 for i, n in enumerate(["rep_create_x2", "graph_knn", "graph_mapping", "label_vote"])})
         return out
 
+    first_calls, last_calls = {}, {}
+    clk0 = gpu_clock_mhz(int(os.environ.get("LOCAL_RANK", "0")))
     t0 = time.perf_counter()
-    one_pass()
+    one_pass(first_calls)
     first = time.perf_counter() - t0
     al = h.alloc_stats()
     for _ in range(max(0, a.warmup - 1)):
@@ -247,12 +257,13 @@ def host_inclusive_leg(a, ref_np, qry_np, codes_np):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         t1 = time.perf_counter()
-        code, conf = one_pass()
+        code, conf = one_pass(last_calls)
         per.append(time.perf_counter() - t1)
     mean = (time.perf_counter() - t0) / max(a.steps, 1)
     h.close()
     return {"seconds": mean, "value": qry_np.shape[0] / mean, "unit": "query cells/s", "steps": a.steps, "warmup": a.warmup,
             "seconds_min": float(min(per)), "seconds_max": float(max(per)), "first_pass_seconds": first,
+            "first_pass_calls_ms": first_calls, "last_pass_calls_ms": last_calls, "gpu_sclk_mhz_before_first_pass": clk0,
             "first_pass_allocator_ms": {"workspace_alloc": al["workspace_ms"], "workspace_bytes": al["workspace_bytes"],
                                         "pool_alloc": al["pool_ms"], "pool_bytes": al["pool_bytes"], "pool_allocs": al["pool_calls"],
                                         "free": al["free_ms"], "cm_create_before_the_pass": al["create_ms"]},
@@ -305,6 +316,91 @@ def dropin_leg(a, ref_np, qry_np, codes_np, device_code=None):
                                      "pool_alloc_ms": al["pool_ms"], "pool_bytes": al["pool_bytes"], "pool_allocs": al["pool_calls"],
                                      "free_ms": al["free_ms"]},
             "labels_equal_device_tier": same}
+
+
+def gpu_clock_mhz(index=0):
+    """Current shader clock of GPU `index` from sysfs (pp_dpm_sclk, the starred level) -- best effort, None if unreadable.  Sampled
+    around the first call: a first call that is slow because the GPU was still clocked down after an idle stretch shows up
+    here (and in the call's HIP-event stage times), not in the allocator clock."""
+    import glob
+    import re
+
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        for line in open(cards[index]).read().splitlines():
+            if line.strip().endswith("*"):
+                return float(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+    except Exception:
+        return None
+    return None
+
+
+def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.0, check=2048):
+    """Secondary leg of config 2, OUTSIDE the headline: the same shape (nq x n_ref, d, k, label transfer) on a Gaussian mixture
+    -- what `.obsm["X_pca"]` of an atlas looks like (cellmapper.py:237-251 takes the representation as given; SURVEY.md 8d
+    allows "a Gaussian mixture to mimic cell-type structure -- report which") -- on a FRESH handle, so that `first_call_ms`
+    carries the structure pre-test, the locality sort, the pruning gate and the pilot.  Same step protocol at a smaller step
+    count, its own parity gate against the CPU oracle."""
+    import copy
+
+    import bench_data as bd
+    from cellmapper_amd.device import DevicePipeline
+
+    a, torch, dev = ctx.a, ctx.torch, ctx.dev
+    ref = bd.mixture_rows(torch, bd.STREAM_REF, 0, a.nref, a.d, dev, n_clusters, spread, sigma)
+    qry = bd.mixture_rows(torch, bd.STREAM_QRY, 0, a.nq, a.d, dev, n_clusters, spread, sigma)
+    torch.cuda.synchronize()
+    pipe = DevicePipeline(dev.index or 0)
+    pipe.h.set_profiling(True)
+    prev_stream = torch.cuda.current_stream()
+    torch.cuda.set_stream(pipe.stream)
+    try:
+        pipe.h.reserve(a.nref, a.nq, a.d, a.k, metric=a.metric)
+        al0 = pipe.h.alloc_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel)
+        torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
+        al1 = pipe.h.alloc_stats()
+        st_first = pipe.h.stage_times()
+        for _ in range(max(0, warmup - 1)):
+            pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel)
+        torch.cuda.synchronize()
+        acc = {}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel)
+            for kk, vv in pipe.h.stage_times().items():
+                acc[kk] = acc.get(kk, 0.0) + vv
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        fb = pipe.h.knn_stats()
+        code_t, conf_t, dist_t, idx_t = pipe.map_labels(ref, qry, a.k, codes, a.ncat, metric=a.metric, kernel=a.kernel, want_graph=True)
+        torch.cuda.synchronize()
+        overflow = pipe.h.knn_stats().get("fallback_overflow", 0)
+        a2 = copy.copy(a)
+        a2.check, a2.cpu_sample = check, 0
+        ctx2 = copy.copy(ctx)
+        ctx2.a = a2
+        rec, _, ok = parity_gate(ctx2, dist_t, idx_t, code_t, conf_t, 0, a.nq, False,
+                                 ref_host_fn=lambda: ref.cpu().numpy(),
+                                 qry_rows_fn=lambda ids: bd.mixture_rows_at(torch, bd.STREAM_QRY, ids, a.d, dev, n_clusters, spread, sigma))
+    finally:
+        torch.cuda.set_stream(prev_stream)
+    res = {"data": f"Gaussian mixture from the counter-based streams (bench_data.mixture_rows): {n_clusters} clusters, centres N(0, {spread}^2), "
+                   f"within-cluster sigma {sigma}, reference and query share the centres; {a.nq} x {a.nref}, d={a.d}, k={a.k}",
+           "ms_per_step": ms, "value": a.nq / (ms * 1e-3), "unit": "query cells/s", "steps": steps, "warmup": warmup,
+           "first_call_ms": first_ms, "first_call_over_steady": first_ms / ms,
+           "first_call_allocator_ms": {"workspace": al1["workspace_ms"] - al0["workspace_ms"], "workspace_bytes_added_in_call": al1["workspace_bytes"] - al0["workspace_bytes"]},
+           "first_call_stage_ms": st_first, "stage_ms_mean": {kk: vv / steps for kk, vv in acc.items()},
+           "filter_level": fb.get("filter_products"), "filter_kernel": fb.get("filter_kernel"), "tiles_visited_pct": fb.get("tiles_visited_pct"),
+           "fallback_queries": fb.get("fallback_queries"), "candidates_per_query": fb.get("candidates"),
+           "fallback_overflow": bool(overflow), "parity_check": rec}
+    del ref, qry, out, code_t, conf_t, dist_t, idx_t
+    pipe.h.close()
+    torch.cuda.empty_cache()
+    return res, bool(ok) and not overflow
 
 
 def git_rev(path):
@@ -595,6 +691,7 @@ def main_rank(a):
     else:
         reserved, reserve_ms = 0, 0.0
     torch.cuda.synchronize()
+    clk0 = gpu_clock_mhz(local_rank)
     al0 = pipe.h.alloc_stats()
     tmem0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) if hasattr(torch.cuda, "memory_stats") else 0
     tf0 = time.perf_counter()
@@ -602,6 +699,7 @@ def main_rank(a):
     t_ret = time.perf_counter()
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - tf0) * 1e3
+    clk1 = gpu_clock_mhz(local_rank)
     al1 = pipe.h.alloc_stats()
     st1 = pipe.h.stage_times() if not use_dist else {}
     kern1 = float(sum(st1.values()))
@@ -617,6 +715,7 @@ def main_rank(a):
         "host_other": first_call_ms - kern1 - (al1["workspace_ms"] - al0["workspace_ms"]) - (al1["pool_ms"] - al0["pool_ms"]) - (al1["free_ms"] - al0["free_ms"]),
         "call_returned_after": (t_ret - tf0) * 1e3,
         "torch_device_allocs_in_call": (torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - tmem0) if hasattr(torch.cuda, "memory_stats") else None,
+        "gpu_sclk_mhz_before_and_after": [clk0, clk1],
         "before_the_call": {"handle_create_ms": handle_create_ms, "cm_create_ms": al1["create_ms"], "code_load_ms": al1["preload_ms"],
                             "workspace_reserve_ms": reserve_ms, "workspace_reserved_bytes": reserved,
                             "workspace_reserve_hipMalloc_ms": al0["workspace_ms"]},
@@ -786,6 +885,11 @@ def main_rank(a):
                 result["cpu_baseline"] = cb
         if a.check <= 0:
             parity_ok = True
+    if (a.config == 2 and world == 1 and not use_dist and a.check > 0 and a.metric == "euclidean" and not a.no_clustered
+            and a.nq == CONFIGS[2]["nq"] and a.nref == CONFIGS[2]["nref"]):
+        crec, c_ok = clustered_leg(ctx, codes, steps=max(3, a.steps // 4), warmup=max(1, min(2, a.warmup)))
+        result["clustered"] = crec
+        parity_ok = parity_ok and c_ok
     if rank == 0 and a.cpu_sample > 0 and a.metric == "euclidean":
         from oracle import oracle as orc
 

@@ -23,6 +23,8 @@ _C2 = 0x846CA68B - (1 << 32)     # as a wrapped int32
 _GOLD = 0x9E3779B1 - (1 << 32)
 
 STREAM_REF, STREAM_QRY, STREAM_LABEL, STREAM_OBSM, STREAM_X, STREAM_XY, STREAM_SPCOL, STREAM_SPVAL = range(1, 9)
+STREAM_CENTRE = 9          # cluster centres of the mixture generator (shared by both sides)
+STREAM_MEMBER = 16         # + the side's stream: which cluster a row belongs to
 
 
 def _lsr(x, s: int):
@@ -92,6 +94,34 @@ def rows_at(torch, kind: str, stream: int, row_ids, width: int, device, c0: int 
     else:
         out = (h1 & 0xFFFFFF).to(torch.float32) * (1.0 / 16777216.0)
     return out * scale if scale != 1.0 else out
+
+
+def mixture_centres(torch, n_clusters: int, width: int, device, spread: float = 5.0):
+    """[n_clusters, width] float32 cluster centres N(0, spread^2) of the Gaussian-mixture embeddings ("a
+    50-component Gaussian mixture to mimic cell-type structure"; the 40-cluster shape of DESIGN.md section 6's table)."""
+    return normal_block(torch, STREAM_CENTRE, 0, n_clusters, 0, width, device) * spread
+
+
+def mixture_rows_at(torch, stream: int, row_ids, width: int, device, n_clusters: int = 40, spread: float = 5.0, sigma: float = 1.0):
+    """Mixture rows at arbitrary row numbers: row i of `stream` = centre[member(i)] + sigma * N(0, 1) -- a pure function of
+    (stream, i, column), like every other stream here, so any rank can draw its shard and the parity gate can re-draw its
+    sample.  Reference and query share the centres (a query maps onto the atlas' cell types)."""
+    rows = torch.as_tensor(row_ids, dtype=torch.int32, device=device)
+    cen = mixture_centres(torch, n_clusters, width, device, spread)
+    zero = torch.zeros(1, dtype=torch.int32, device=device)
+    member = (_lsr(hash_grid(torch, STREAM_MEMBER + stream, rows, zero)[:, 0], 8) % n_clusters).to(torch.int64)
+    return cen[member] + rows_at(torch, "normal", stream, rows, width, device) * sigma
+
+
+def mixture_rows(torch, stream: int, r0: int, r1: int, width: int, device, n_clusters: int = 40, spread: float = 5.0,
+                 sigma: float = 1.0, chunk_rows: int = 500_000):
+    """Rows [r0, r1) of the mixture as one float32 tensor, in row chunks."""
+    out = torch.empty((r1 - r0, width), dtype=torch.float32, device=device)
+    for a in range(r0, r1, chunk_rows):
+        b = min(r1, a + chunk_rows)
+        out[a - r0:b - r0] = mixture_rows_at(torch, stream, torch.arange(a, b, dtype=torch.int32, device=device), width, device,
+                                             n_clusters, spread, sigma)
+    return out
 
 
 def integers(torch, stream: int, r0: int, r1: int, m: int, device):

@@ -241,7 +241,7 @@ class Handle:
         self.call("cm_knn_stats", _ptr(out))
         # out[3]: 1 = f32-input MFMA, 2 = split-fp16 MFMA (K<=64), 3 = low-d VALU, 4 = split-fp16 MFMA (K=128)
         return dict(fallback_queries=int(out[0]), candidates=int(out[1]), ref_splits=int(out[2]) % 100,
-                    filter_products=int(out[2]) // 100, lowd_path=int(out[3]) % 100,
+                    filter_products=(int(out[2]) // 100) % 100, filter_kernel=int(out[2]) // 10000, lowd_path=int(out[3]) % 100,
                     # bucket pruning: (query block, reference tile) pairs visited, per cent of a full scan (0 = not used)
                     tiles_visited_pct=int(out[3]) // 100,
                     # 1 = a query's exact-fallback list overflowed (results truncated): device-tier callers must check

@@ -46,6 +46,7 @@ void latch_knobs() {
     k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
     k.multi_staged = on("CELLMAP_MULTI_STAGED"); k.multi_check_fail = on("CELLMAP_MULTI_CHECK_FAIL");
     k.no_pretest = on("CELLMAP_NO_PRETEST"); k.no_preload = on("CELLMAP_NO_PRELOAD");
+    k.xfer_mode = 3;   // default (round 5): downloads of 64 MB and more go through the pinned staging ring, everything else takes the plain path
     if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
     k.xfer_threads = (int)num("CELLMAP_XFER_THREADS", 0); k.xfer_slot_kb = (int)num("CELLMAP_XFER_SLOT_KB", 0);
     k.xfer_min_kb = (int)num("CELLMAP_XFER_MIN_KB", 0);
@@ -177,7 +178,7 @@ void xfer_drop(cm_handle_t h) {
 cm_status xfer_get(cm_handle_t h, Xfer **out) {
     if (h->xfer) { *out = static_cast<Xfer *>(h->xfer); return CM_OK; }
     const cm_knobs &kn = cm_get_knobs();
-    int T = kn.xfer_threads > 0 ? kn.xfer_threads : 8;
+    int T = kn.xfer_threads > 0 ? kn.xfer_threads : 4;   // (4 threads move what 8 do: profiles/r04_host_leg.md; half the pinned memory and streams to set up)
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) T = std::min(T, std::max(1, CPU_COUNT(&set)));
     T = std::max(1, std::min(T, 32));
@@ -281,12 +282,21 @@ cm_status xfer_run(cm_handle_t h, void *dev, size_t dpitch, void *host, size_t h
 }
 
 cm_status h2d(cm_handle_t h, void *dst, const void *src, size_t bytes) {
-    if (bytes >= xfer_min() && cm_get_knobs().xfer_mode >= 2) return xfer_run(h, dst, bytes, const_cast<void *>(src), bytes, bytes, 1, true);
+    if (bytes >= xfer_min() && cm_get_knobs().xfer_mode == 2) return xfer_run(h, dst, bytes, const_cast<void *>(src), bytes, bytes, 1, true);
     if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     return CM_OK;
 }
+// does a download of `bytes` (into what is usually a freshly allocated host array) go through the staging ring?  Default: from
+// 64 MB on -- the ring's threads fault the destination's pages in parallel, which is what bounds a plain copy into fresh memory
+// (720 MB of k-NN lists: 39.6 -> 15.6 ms, profiles/r04_host_leg.md); the ring is created on first use, so calls that only bring
+// small results down (labels, confidences) never pay its ~30 ms set-up.  CELLMAP_XFER=0 switches it off, =d2h / =1 lower the
+// threshold to CELLMAP_XFER_MIN_KB (8 MB).
+static inline bool ring_for_download(size_t bytes) {
+    const int m = cm_get_knobs().xfer_mode;
+    return m == 3 ? bytes >= ((size_t)64 << 20) : (m >= 1 && bytes >= xfer_min());
+}
 cm_status d2h(cm_handle_t h, void *dst, const void *src, size_t bytes) {
-    if (bytes >= xfer_min() && cm_get_knobs().xfer_mode >= 1) return xfer_run(h, const_cast<void *>(src), bytes, dst, bytes, bytes, 1, false);
+    if (ring_for_download(bytes)) return xfer_run(h, const_cast<void *>(src), bytes, dst, bytes, bytes, 1, false);
     if (bytes) CM_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     return CM_OK;
 }
@@ -786,6 +796,10 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     CM_TRY(dflag.alloc(h, 256));
     h->d_nflag_pinned[12] = h->d_nflag_pinned[13] = 0;
     CM_TRY(nonfinite_enqueue(h, dref.p, es * n_ref * d, dtype, dflag.as<int>(), 12));
+    if (nq == 0) {   // no query chunk will read the reference's verdict: read it here (sklearn's check_array rejects the fit data before any query)
+        CM_TRY(sync(h));
+        if (h->d_nflag_pinned[12]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
+    }
     int64_t nflag = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         int64_t nqc = std::min<int64_t>(chunk, nq - q0);
@@ -940,6 +954,11 @@ static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const
     CM_TRY(dB.alloc(h, es * (size_t)n_ref * cw));
     CM_TRY(dO[0].alloc(h, es * (size_t)qt * cw));
     CM_TRY(dO[1].alloc(h, es * (size_t)qt * cw));
+    // the product comes down into a fresh [nq, n_out] host array: 64 MB and more of it go tile by tile through the staging
+    // ring (parallel first touch of the destination; the plain copy ran at 20-30 GB/s over the link for that reason, DESIGN.md
+    // section 3b).  The ring call waits for the tile's kernel and returns when the rows have arrived: the product itself is a
+    // tenth of the transfer time, so nothing is lost by not overlapping them.
+    const bool ring = ring_for_download(es * (size_t)nq * (size_t)(c_end - c_begin)) && es * (size_t)cw <= ((size_t)1 << 20);
     for (int64_t c0 = c_begin; c0 < c_end; c0 += cw) {
         const int64_t w = std::min<int64_t>(cw, c_end - c0);
         CM_HIP(h, hipMemcpy2DAsync(dB.p, es * w, (const char *)B + es * c0, es * n_out, es * w, (size_t)n_ref, hipMemcpyHostToDevice, h->stream));
@@ -947,6 +966,11 @@ static cm_status spmm_dense_stream(cm_handle_t h, const int64_t *d_indptr, const
         for (int64_t q0 = 0; q0 < nq; q0 += qt, ++it) {
             const int64_t nt = std::min<int64_t>(qt, nq - q0);
             const int b = it & 1;
+            if (ring) {
+                CM_TRY(cm_spmm_dense_run(h, d_indptr + q0, d_cols, d_vals, nt, dB.p, w, b_dtype, dO[0].p));
+                CM_TRY(xfer_run(h, dO[0].p, es * w, (char *)out + es * ((size_t)q0 * n_out + c0), es * n_out, es * w, (size_t)nt, false));
+                continue;
+            }
             if (it >= 2) CM_HIP(h, hipStreamWaitEvent(h->stream, h->tile_ev[b], 0));   // the copy of tile it-2 has left this buffer
             CM_TRY(cm_spmm_dense_run(h, d_indptr + q0, d_cols, d_vals, nt, dB.p, w, b_dtype, dO[b].p));
             CM_HIP(h, hipEventRecord(h->tile_ev[b], h->stream));
@@ -1489,7 +1513,7 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
         // 2. + 3. device p owns query slice p: it brings that slice of every device's two planes over (peer copies, or
         //    staged through the host where the platform has no peer access) and merges the P lists per query by
         //    (value, global index) -- the rule of a single search, so the result is exact
-        int route = cm_get_knobs().multi_staged ? 1 : 0;
+        int route = (cm_get_knobs().multi_staged || h->multi_route_staged) ? 1 : 0;   // (an earlier graph's self-check failed: the handle stays on the host-staged route)
         for (size_t a = 0; a < P && !route; ++a)
             for (size_t b = 0; b < P && !route; ++b) {
                 int can = 1;
@@ -1540,9 +1564,6 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
                     rc = exchange_all(1);
                 }
             }
-        } else if (h->multi_route_staged && route == 0 && rc == CM_OK) {
-            route = 1;   // (an earlier graph's self-check failed: this handle stays on the host-staged route)
-            rc = exchange_all(1);
         }
         g->exchange_route = route;
         for (size_t i = 0; i < P; ++i) { (void)hipSetDevice(hp[i]->device); packed[i].release(); }

@@ -456,7 +456,7 @@ struct PairAcc {
         else run_mode<0, false, UNR>(q, c0, n, yat);   // cosine and the GEMM form: q.y per pair, |y|^2 once
     }
     // d: the row width (the counting metrics' n)
-    __device__ __forceinline__ void finish(const double *xn, int metric, int form, double *out, int d = 0) const {
+    __device__ __forceinline__ void finish(const double *xn, int metric, int form, double *out, int d) const {
         const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
@@ -503,7 +503,7 @@ __device__ __forceinline__ double pair_value(const TQ *__restrict__ q, double xn
     acc.init();
     acc.run(qa, 0, d, [&](int c) { return y[c]; }, metric, form);
     double out[1];
-    acc.finish(&xn, metric, form, out);
+    acc.finish(&xn, metric, form, out, d);
     return out[0];
 }
 
@@ -1133,29 +1133,44 @@ __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ 
 
 // ------------------------------------------------------------------ shard merge ---------------------
 // parts [nparts, nq, k] -> the k smallest by (distance, global index).  One wave per query.
+// Ranks are UNIQUE whatever the lists hold, so every output slot is written exactly once: entries are ordered by (value, index,
+// position in the concatenated lists) -- two shards never report the same reference row, but a caller that hands in
+// overlapping lists gets both copies, not an unwritten slot -- and a NaN value (dice / sokalsneath between two all-false rows:
+// the exact scan writes the NaN sklearn returns into the per-shard lists) ranks as +inf, after every number, like the
+// single-device scan ranks it; it is written out as NaN again (round-4 advisor finding: NaN compared false against everything,
+// took rank 0 and raced with the true nearest neighbour).
 __global__ __launch_bounds__(256) void knn_merge(const double *__restrict__ pd, const int64_t *__restrict__ pi,
                                                   int nparts, int64_t part_stride, int64_t nq, int k, int sqrt_out,
                                                   double *__restrict__ out_dist, int64_t *__restrict__ out_idx) {
     __shared__ double s_v[4][MG_NCMAX];
     __shared__ int64_t s_i[4][MG_NCMAX];
+    constexpr int64_t NAN_TAG = (int64_t)1 << 62;   // (global row numbers stay far below 2^62)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + w;
     if (i >= nq) return;
     const int nc = nparts * k;
     for (int s = lane; s < nc; s += 64) {
         int p = s / k, t = s - p * k;
-        s_v[w][s] = pd[(int64_t)p * part_stride + i * k + t];
-        s_i[w][s] = pi[(int64_t)p * part_stride + i * k + t];
+        const double v = pd[(int64_t)p * part_stride + i * k + t];
+        const int64_t id = pi[(int64_t)p * part_stride + i * k + t];
+        const bool is_nan = v != v && id >= 0;
+        s_v[w][s] = v != v ? INFINITY : v;
+        s_i[w][s] = is_nan ? (id | NAN_TAG) : id;
     }
     __builtin_amdgcn_wave_barrier();
     for (int s = lane; s < nc; s += 64) {
         double v = s_v[w][s];
         int64_t id = s_i[w][s];
         int rk = 0;
-        for (int j = 0; j < nc; ++j) rk += pair_before(s_v[w][j], s_i[w][j], v, id) ? 1 : 0;
+        for (int j = 0; j < nc; ++j) {
+            const double vj = s_v[w][j];
+            const int64_t ij = s_i[w][j];
+            rk += (vj < v || (vj == v && (ij < id || (ij == id && j < s)))) ? 1 : 0;
+        }
         if (rk < k) {
-            out_dist[i * k + rk] = sqrt_out ? sqrt(v) : v;
-            out_idx[i * k + rk] = id;
+            const bool was_nan = (id & NAN_TAG) != 0;
+            out_dist[i * k + rk] = was_nan ? __longlong_as_double(0x7ff8000000000000LL) : (sqrt_out ? sqrt(v) : v);
+            out_idx[i * k + rk] = id & ~NAN_TAG;
         }
     }
 }
@@ -2197,7 +2212,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         return CM_OK;
     };
     int img = -1;          // reference image currently in Rp: 0 full [hi|lo] tiles, 1 hi-only tiles, 2 direct (fp32 rows)
-    int last_Kc = Kc_max, last_S = 1;
+    int last_Kc = Kc_max, last_S = 1, last_variant = 0;   // (variant: which filter kernel the stage launched, see cm_knn_stats)
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     int seeds_from_level = 0;   // level of the stage whose re-rank wrote the current per-query seeds (0: none)
     auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
@@ -2303,7 +2318,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg; a.ctr = d_ctr;
+        a.dbg = dbg & ~(16 | 64); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
@@ -2320,11 +2335,24 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         } else {
             // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
             c_split = (level == 1 ? 2.0f : (level == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f;
-            // accumulation (device-validated model of the f16 MFMA chain, doubled) + representation; see knn_run_t
-            c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
-            // 16x16x32 shape: 32 products per instruction, K / 32 instructions per chain -- the same device-validated model
-            // with 32 in place of 16 (tests/test_gpu_parity.py::test_mfma_f16_accumulation_bound checks both shapes), doubled
-            if (r16) c_eps = 2.0f * (float)(32 + 2 * (p2.KSTEPS / 2)) * 5.9604645e-8f + 8.4e-7f;
+            // Accumulation + representation (8.4e-7).  Levels 1 and 2 (and the bucket-centred level, which is level 1's arithmetic):
+            // the ANALYTIC worst case of the chain -- n = 16 KSTEPS products per split product summed into the accumulator (+ the
+            // |y|^2 operand of K = 128), every addition rounding by at most one unit in the last place of a partial sum that
+            // never exceeds the sum of the magnitudes (truncation assumed, whatever the order inside an instruction):
+            // (n + 1) 2^-23 sum|terms|.  It holds for either MFMA shape (16 or 32 products per instruction: the same number
+            // of additions).  The dropped split products (c_split / the lo norms) are 60 - 270 x larger at these levels, so
+            // the proven constant costs nothing measurable (profiles/r05_accumulation_bound.md) and the exactness argument of
+            // the levels every benchmark configuration certifies at contains no measured constant.
+            // Level 3 keeps the device-validated model of the f16 MFMA chain, doubled (tests/test_gpu_parity.py::
+            // test_mfma_f16_accumulation_bound checks it on the device the tests run on): there the accumulation term IS the
+            // error bound, and the analytic constant (193 2^-23 at K = 64, four times the model) would send queries of tight
+            // clusters on to level 4, fifteen times the cost.
+            if (level <= 2 && !(dbg & 64))   // (CELLMAP_DBG=64: the measured model at every level -- the A/B of profiles/r05_accumulation_bound.md)
+                c_eps = (float)(16 * p2.KSTEPS * level + (wide || cenl ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // (+1: the |y|^2 / side-value operand)
+            else {
+                c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
+                if (r16) c_eps = 2.0f * (float)(32 + 2 * (p2.KSTEPS / 2)) * 5.9604645e-8f + 8.4e-7f;   // (not reachable: r16 is a level-1 kernel)
+            }
         }
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
@@ -2335,6 +2363,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
             const int op = lp_metric ? (metric == CM_METRIC_MANHATTAN ? 1 : (metric == CM_METRIC_CHEBYSHEV ? 2 : (metric == CM_METRIC_CANBERRA ? 3 : 4))) : 0;
+            if (!x.seed_len) last_variant = level == 4 ? 5 : (w3 ? 4 : ((q4 && !x.wlist) ? (r16 ? 3 : 2) : 1));
             if (level == 4 && dl > 64) return cm_p1direct_wide_launch(h, dl, op, p2.grid, p2.lds, x);
             if (level == 4 && lp_metric) return cm_p1lowd_metric_launch(h, dl, op, p2.grid, p2.lds, x);
             if (level == 4) return cm_p1lowd_launch(h, dl, p2.grid, p2.lds, x);
@@ -2622,10 +2651,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const int *qmap = start == 5 ? (const int *)qpack : (const int *)qperm;   // full set: bucket-packed / locality-sorted order
     int64_t nsub = start == 5 ? n_packed : nq;
     int *flag_out = flag_a;
-    int level = start, main_Kc = Kc_max, main_S = 1;
+    int level = start, main_Kc = Kc_max, main_S = 1, main_variant = 0;
     for (int stage = 0;; ++stage) {
         CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
-        if (stage == 0) { main_Kc = last_Kc; main_S = last_S; }
+        if (stage == 0) { main_Kc = last_Kc; main_S = last_S; main_variant = last_variant; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
         // (after a seeded stage the failures first get an unseeded pass of the same level: the image is in place, and
         // most of them only had a seed that was too tight)
@@ -2712,7 +2741,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     cm_mark(h, 4);
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = main_Kc;
-    h->knn_stats[2] = main_S + 100 * start;
+    h->knn_stats[2] = main_S + 100 * start + 10000 * main_variant;
     h->knn_stats[3] = (wide ? 4 : (lowp ? 3 : 2)) + 100 * ivf_pct;
     return CM_OK;
 }
@@ -2859,11 +2888,12 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
 
 }  // namespace
 
-// float64 inputs of the ratio metrics: is there a non-zero magnitude below 2^-100 (see cm_knn_run)?
-static __global__ void tiny_nonzero_f64(const double *__restrict__ x, int64_t n, unsigned *__restrict__ flag) {
+// inputs of the ratio metrics: is there a non-zero magnitude below 2^-100 (see cm_knn_run)?
+template <typename T>
+static __global__ void tiny_nonzero(const T *__restrict__ x, int64_t n, unsigned *__restrict__ flag) {
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double a = fabs(x[i]);
+        const double a = fabs((double)x[i]);
         bad |= a > 0.0 && a < 7.888609052210118e-31;
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -2959,18 +2989,32 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
     const bool count_metric = metric >= CM_METRIC_HAMMING && metric <= CM_METRIC_YULE;
     if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric && !count_metric)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
-    if (ratio_metric && dtype == CM_F64 && !needs_exact_scan(n_ref, nq, d, k, metric)) {
-        // the fp32 filter image flushes magnitudes below float32's normal range: a ratio term |x - y| / (|x| + |y|) of such
-        // coordinates would lose all its bits.  One pass over both inputs (read by every later kernel anyway).
+    if (ratio_metric && (dtype == CM_F32 || dtype == CM_F64) && nq > 0 && !needs_exact_scan(n_ref, nq, d, k, metric)) {
+        // The fp32 filter of the ratio metrics divides by |x| + |y| with the hardware reciprocal, which has no denormal support, and
+        // its image of float64 rows flushes magnitudes below float32's normal range: a term |x - y| / (|x| + |y|) of such
+        // coordinates would come out inf / NaN and drop a true neighbour without moving the threshold (round-4 advisor finding
+        // for float32 input; float64 input used to be refused).  One pass over both inputs (read by every later kernel anyway):
+        // data holding a non-zero magnitude below 2^-100 takes the exact scan -- float64 pair values by the re-rank's own
+        // arithmetic, no filter -- instead.
         unsigned *tiny = (unsigned *)cm_ws_alloc(h, 256);
         if (!tiny) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         CM_HIP(h, hipMemsetAsync(tiny, 0, 4, h->stream));
-        hipLaunchKernelGGL(tiny_nonzero_f64, dim3(1024), dim3(256), 0, h->stream, (const double *)d_ref, n_ref * (int64_t)d, tiny);
-        hipLaunchKernelGGL(tiny_nonzero_f64, dim3(1024), dim3(256), 0, h->stream, (const double *)d_qry, nq * (int64_t)d, tiny);
+        if (dtype == CM_F64) {
+            hipLaunchKernelGGL(tiny_nonzero<double>, dim3(1024), dim3(256), 0, h->stream, (const double *)d_ref, n_ref * (int64_t)d, tiny);
+            hipLaunchKernelGGL(tiny_nonzero<double>, dim3(1024), dim3(256), 0, h->stream, (const double *)d_qry, nq * (int64_t)d, tiny);
+        } else {
+            hipLaunchKernelGGL(tiny_nonzero<float>, dim3(1024), dim3(256), 0, h->stream, (const float *)d_ref, n_ref * (int64_t)d, tiny);
+            hipLaunchKernelGGL(tiny_nonzero<float>, dim3(1024), dim3(256), 0, h->stream, (const float *)d_qry, nq * (int64_t)d, tiny);
+        }
         CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 14, tiny, 4, hipMemcpyDeviceToHost, h->stream));
         CM_HIP(h, hipStreamSynchronize(h->stream));
-        if (h->d_nflag_pinned[14])
-            CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: canberra / braycurtis on float64 data with non-zero magnitudes below 2^-100 is not supported");
+        if (h->d_nflag_pinned[14]) {
+            const int fm = (d > 15 || k >= n_ref / 2) ? CM_FORM_GEMM : CM_FORM_DIRECT;
+            const int f2 = form == CM_FORM_AUTO ? fm : form;
+            if (dtype == CM_F32)
+                return knn_run_scan<float>(h, (const float *)d_ref, n_ref, (const float *)d_qry, nq, d, k, metric, f2, idx_offset, flags, d_out_dist, d_out_idx);
+            return knn_run_scan<double>(h, (const double *)d_ref, n_ref, (const double *)d_qry, nq, d, k, metric, f2, idx_offset, flags, d_out_dist, d_out_idx);
+        }
     }
     if (form == CM_FORM_AUTO) form = (d > 15 || k >= n_ref / 2) ? CM_FORM_GEMM : CM_FORM_DIRECT;
     if (nq == 0) return CM_OK;

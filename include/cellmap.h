@@ -71,8 +71,8 @@ typedef enum {
  * and "braycurtis" (sum_j |x_j - y_j| / sum_j (|x_j| + |y_j|), 0 when the denominator is 0): ArgKmin brute force at d > 15
  * (float32 data: the coordinate difference is a float32, everything else float64, the RESULT rounded to float32 once:
  * DistanceMetric32), ball_tree on float64 copies below.  Same exact machinery as manhattan / chebyshev (fp32 VALU direct
- * filter up to d = 128, the exact scan beyond); on the filtered widths float64 inputs must not hold non-zero magnitudes below
- * 2^-100 (the filter's float32 copy would flush them: CM_E_UNSUPPORTED).  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
+ * filter up to d = 128, the exact scan beyond); inputs holding a non-zero magnitude below 2^-100 (which the filter's float32
+ * image would flush, and which its reciprocal cannot divide by) are screened and take the exact scan too.  Goldens through the reference pin the arithmetic (tests/golden/ *canberra*, *braycurtis*). */
 #define CM_METRIC_CANBERRA 6
 #define CM_METRIC_BRAYCURTIS 7
 /* Round 4 (late): the counting metrics sklearn accepts without parameters.  sklearn keeps them away from ArgKmin: brute force
@@ -162,7 +162,9 @@ cm_status cm_synchronize(cm_handle_t h);
 cm_status cm_set_profiling(cm_handle_t h, int32_t on);
 cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
 /* counters of the last cm_knn / cm_knn_dev call: out[0] = queries sent to the exact fallback,
- * out[1] = candidate-list size K', out[2] = reference splits + 100 * (filter level the full set started at),
+ * out[1] = candidate-list size K', out[2] = reference splits + 100 * (filter level the full set started at)
+ *          + 10000 * (filter kernel of the main stage: 1 two-accumulator split-fp16 (512-query blocks), 2 four-accumulator (1 024-query
+ *          blocks), 3 its 16x16x32 re-tile, 4 the K = 128 three-product kernel, 5 direct VALU; 0 = grid / other families),
  * out[3] = filter family (1 f32-input MFMA, 2 split-fp16 MFMA K <= 64, 3 direct VALU / grid, 4 split-fp16 MFMA K = 128)
  *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning),
  * out[4] = 1 if the exact fallback overflowed (more than 16 384 queries of one call each had more than 4 096 rows

@@ -640,7 +640,7 @@ def test_staging_ring_moves_the_same_bytes(monkeypatch, oracle):
             monkeypatch.setenv("CELLMAP_XFER_MIN_KB", "1"); monkeypatch.setenv("CELLMAP_XFER_SLOT_KB", "96")
             monkeypatch.setenv("CELLMAP_XFER_THREADS", "3")
         else:
-            monkeypatch.delenv("CELLMAP_XFER", raising=False)
+            monkeypatch.setenv("CELLMAP_XFER", "0")
         _native.reload_knobs()
         h = _native.Handle(0)
         xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
@@ -658,3 +658,39 @@ def test_staging_ring_moves_the_same_bytes(monkeypatch, oracle):
         assert np.array_equal(a, b)
     o = oracle.knn_euclidean(ref, qry, 15)
     assert np.array_equal(outs[1][1], o[1]) and np.array_equal(outs[1][0], o[0])
+    _native.reload_knobs()
+
+
+def test_large_downloads_take_the_ring_by_default(monkeypatch):
+    """Round 5: without any knob, a download of 64 MB or more (k-NN lists, a dense layer product) goes through the staging ring,
+    created on first use; smaller results never create it.  Same bytes as the plain path (CELLMAP_XFER=0)."""
+    from cellmapper_amd import _native
+
+    rng = np.random.default_rng(12)
+    ref = rng.standard_normal((30_000, 20)).astype(np.float32)
+    qry = rng.standard_normal((120_000, 20)).astype(np.float32)
+    B = rng.random((ref.shape[0], 160), dtype=np.float32)
+    codes = rng.integers(0, 9, ref.shape[0]).astype(np.int32)
+    outs, pinned = [], []
+    for plain in (True, False):
+        if plain:
+            monkeypatch.setenv("CELLMAP_XFER", "0")
+        else:
+            monkeypatch.delenv("CELLMAP_XFER", raising=False)
+        _native.reload_knobs()
+        h = _native.Handle(0)
+        xr, yr = _native.DeviceRep(h, ref), _native.DeviceRep(h, qry)
+        g = _native.DeviceGraph(h, xr, yr, 70)
+        g.mapping("gaussian")
+        code, conf = g.label_vote(codes, 9)             # 480 KB + 480 KB down: plain path
+        small_only = h.alloc_stats()["pinned_calls"]
+        dist, idx = g.fetch_knn()                        # 2 x 67 MB
+        lay = g.spmm_dense(B)                            # 77 MB, in query tiles
+        pinned.append((small_only, h.alloc_stats()["pinned_calls"]))
+        outs.append((code, conf, dist, idx, lay))
+        g.close(); xr.close(); yr.close(); h.close()
+    monkeypatch.delenv("CELLMAP_XFER", raising=False)
+    _native.reload_knobs()
+    assert pinned == [(0, 0), (0, 1)], pinned
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

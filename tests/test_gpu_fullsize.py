@@ -4,6 +4,7 @@ What can be compared in full is (config 1 against the oracle; config 2's 1.5 M r
 route); the rest is checked through size-independent properties plus oracle samples, as SURVEY.md 8d prescribes.
 Reference call sites: knn.py:428-440 (search), cellmapper.py:338 (obsm), :372-373 (layers), :595-605 (labels)."""
 import argparse
+import json
 
 import numpy as np
 import pytest
@@ -77,6 +78,15 @@ def test_config2_all_rows_by_an_independent_route(pipe, oracle, monkeypatch):
     assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
 
 
+A3_MS_PER_MILLION_ROWS_MAX = 200.0
+
+
+def _emit(capsys, tag, rec):
+    """Print a result line past pytest's capture, so that the log of whoever runs the suite carries the numbers of THAT box."""
+    with capsys.disabled():
+        print(f"\n[{tag}] " + json.dumps(rec), flush=True)
+
+
 def _args(**kw):
     a = argparse.Namespace(config=2, nq=0, nref=0, d=50, k=30, genes=0, density=0.03, tile=0, ncat=20, kernel="gaussian",
                            metric="euclidean", steps=1, warmup=0, check=256, cpu_sample=0, ref_shards=0, exchange="alltoall")
@@ -94,10 +104,11 @@ def _ctx(pipe, **kw):
     return bench.RunCtx(_args(**kw), torch, dist, 1, 0, pipe.device, pipe, False)
 
 
-def test_config3_full_size_dense_layer_transfer(pipe):
+def test_config3_full_size_dense_layer_transfer(pipe, capsys):
     """BASELINE configs[2]: 1.5 M x 1.5 M search, obsm (d_out = 2) and the dense layer over 20 000 genes (120 GB payload,
     120 GB product) through the device tier -- sampled product rows bit-equal to the oracle's csr_matvecs restatement
-    (inside bench_wide.run_config3), the A2 kernel above half of the HBM roofline."""
+    (inside bench_wide.run_config3), the A2 kernel at or above north_star's 60 % of the HBM roofline (builder-run: 71 %).  The
+    line is printed so that the driver's pytest log carries the figure of ITS box."""
     import torch
 
     import bench_wide
@@ -107,8 +118,9 @@ def test_config3_full_size_dense_layer_transfer(pipe):
     if free_b < n * G * 4 + (24 << 30):
         pytest.skip(f"needs the 120 GB payload resident: {free_b >> 30} GiB free")
     r, ok = bench_wide.run_config3(_ctx(pipe, config=3, nq=n, nref=n, genes=G))
+    _emit(capsys, "config3 line", r)
     assert ok and r["parity_check"]["ok"], r["parity_check"]
-    assert r["roofline"]["frac"] > 0.5, r["roofline"]
+    assert r["roofline"]["frac"] >= 0.60, r["roofline"]
     torch.cuda.empty_cache()
 
 
@@ -165,7 +177,43 @@ def test_config4_d128_large_reference_shard_merge(pipe, oracle):
     assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
 
 
-def test_config5_full_size_spatial_self_mapping_and_sparse_imputation(pipe, oracle):
+def test_config4_rank_share_filter_kernel_floor(pipe, oracle, capsys):
+    """What ONE rank of BASELINE configs[3] searches at 8 GPUs: 1.5 M queries against its 1.5 M-row shard, d=128, k=30 -- the
+    K = 128 split-fp16 filter (`knn_cand_f16p<8>`) must stay at or above 44 % of the dense f16 peak on algorithmic flops
+    (builder-run: 46-49 % by box; best of two runs, HIP events of the handle around the filter stage), with an oracle sample
+    bit-exact.  A regression on the driver's box shows up here, not in a stale table."""
+    import torch
+
+    g = torch.Generator(device=pipe.device)
+    g.manual_seed(44)
+    n, d, k = 1_500_000, 128, 30
+    ref = torch.randn((n, d), generator=g, device=pipe.device)
+    qry = torch.randn((n, d), generator=g, device=pipe.device)
+    pipe.h.set_profiling(True)
+    try:
+        best, stages = 1e30, None
+        for _ in range(3):   # (first run: warm-up -- workspace, K = 128 code objects)
+            dist, idx = pipe.knn(ref, qry, k)
+            pipe.synchronize()
+            st = pipe.h.stage_times()
+            if _ > 0 and st["phase1_mfma"] < best:
+                best, stages = st["phase1_mfma"], st
+        ks = pipe.h.knn_stats()
+    finally:
+        pipe.h.set_profiling(False)
+    frac = 2.0 * n * n * d / (best * 1e-3) / 2.5e15
+    _emit(capsys, "config4 share line", {"workload": "1.5 M x 1.5 M, d=128, k=30 (one rank's shard of config 4 at 8 GPUs)",
+                                         "filter_ms": best, "frac_f16_peak": frac, "stages_ms": stages, "knn_stats": ks})
+    assert ks["lowd_path"] == 4 and ks["fallback_queries"] <= 64, ks
+    assert frac >= 0.44, (best, frac)
+    sel = torch.arange(0, n, n // 64, device=pipe.device)[:64]
+    od, oi = oracle.knn_euclidean(ref.cpu().numpy(), qry[sel].cpu().numpy(), k)
+    assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
+    del ref, qry, dist, idx
+    torch.cuda.empty_cache()
+
+
+def test_config5_full_size_spatial_self_mapping_and_sparse_imputation(pipe, oracle, capsys):
     """BASELINE configs[4]: 4 M spatial cells (d=2, k=90).  Search: every cell is its own nearest neighbour at distance 0,
     rows sorted, neighbours distinct and in range, oracle sample.  Expression imputation from the sparse payload
     (30 000 genes, 3 %) on the first 200 k query rows in 16 k-row tiles: sampled CSR rows bit-equal to the oracle's
@@ -191,6 +239,11 @@ def test_config5_full_size_spatial_self_mapping_and_sparse_imputation(pipe, orac
     assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
     del dist, idx, srt
     torch.cuda.empty_cache()
-    r, ok = bench_wide.run_config5(_ctx(pipe, config=5, nq=200_000, nref=200_000, d=2, k=k, genes=30_000))
+    r, ok = bench_wide.run_config5(_ctx(pipe, config=5, nq=200_000, nref=200_000, d=2, k=k, genes=30_000, steps=2, warmup=1))
+    _emit(capsys, "config5 slice line", r)
     assert ok and r["parity_check"]["ok"], r["parity_check"]
     assert r["config"]["output_nnz"] > 200_000 * 20_000   # near-dense product rows (the union of 90 neighbours' supports)
+    # floor for the A3 kernel (spgemm_sliced + locality sort + payload index): milliseconds per million product rows on this
+    # 200 k-row slice (builder-run: see DESIGN.md section 6; the full 4 M-row config runs at ~125 ms per million rows)
+    ms_per_m = r["roofline"]["kernel_ms"] / 0.2
+    assert ms_per_m <= A3_MS_PER_MILLION_ROWS_MAX, (ms_per_m, r["roofline"])

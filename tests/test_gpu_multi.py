@@ -204,3 +204,39 @@ def test_metrics_and_the_low_d_path_through_the_sharded_merge(metric, d, oracle)
     else:
         assert np.array_equal(im, i1) and np.array_equal(dm, d1)
     g.close(); xr.close(); yr.close(); h1.close(); hm.close()
+
+
+@pytest.mark.parametrize("metric", ["dice", "sokalsneath"])
+def test_all_false_rows_rank_last_through_the_sharded_merge(metric, oracle):
+    """dice / sokalsneath between two all-false rows is 0 / 0 = NaN upstream and here.  An all-false query against a shard
+    that holds fewer than k rows with a number to offer puts NaN entries into that shard's packed list; the merge must rank
+    them after every number (as +inf, like the one-device scan) instead of letting a NaN -- which compares false against
+    everything -- take rank 0 and race with the true nearest neighbour (round-4 advisor finding).  Three shards of 4 096 rows,
+    the first all-false apart from three rows."""
+    from cellmapper_amd import _native
+
+    rng = np.random.default_rng(123)
+    n, d, k = 3 * 4096, 40, 6
+    ref = (rng.random((n, d)) < 0.3).astype(np.float32)
+    ref[:4096] = 0                        # shard 0: all-false rows ...
+    ref[[5, 900, 4000], 0] = 1            # ... except three
+    qry = (rng.random((1100, d)) < 0.3).astype(np.float32)
+    qry[::7] = 0                          # all-false queries: NaN against every all-false reference row
+    h1, hm = _native.Handle(0), _native.Handle(devices=[0, 0, 0])
+    d1, i1 = h1.knn(ref, qry, k, metric=metric)
+    xr, yr = _native.DeviceRep(hm, ref), _native.DeviceRep(hm, qry)
+    g = _native.DeviceGraph(hm, xr, yr, k, metric)
+    assert g.n_devices == 3
+    dm, im = g.fetch_knn()
+    od, oi = oracle.knn_count_family(ref, qry, k, metric)
+    for dist in (d1, dm):
+        assert np.array_equal(np.isnan(dist), np.isnan(od)) and np.array_equal(np.nan_to_num(dist, nan=-1.0), np.nan_to_num(od, nan=-1.0))
+    # neighbours outside ties (ratios of small counts tie in masses; NaN entries are all "tied" at the end)
+    for idx, dist in ((i1, d1), (im, dm)):
+        v = np.nan_to_num(dist, nan=np.inf)
+        uniq = np.ones_like(v, dtype=bool)
+        uniq[:, 1:] &= v[:, 1:] != v[:, :-1]
+        uniq[:, :-1] &= v[:, :-1] != v[:, 1:]
+        assert np.array_equal(idx[uniq], oi[uniq])
+    assert np.array_equal(dm[::7][:, 0], d1[::7][:, 0]) and not np.isnan(dm[::7][:, 0]).any()   # an all-false query's nearest is a number
+    g.close(); xr.close(); yr.close(); h1.close(); hm.close()
