@@ -69,8 +69,11 @@ def parse(argv=None):
     ap.add_argument("--metric", default="euclidean", choices=["euclidean", "cosine", "manhattan", "chebyshev"])
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--ref-shards", type=int, default=0,
-                    help="reference shards R (world = query groups x R); 0 = default (2 when world is even; the whole "
-                         "world for config 4), world = pure reference sharding")
+                    help="reference shards R (world = query groups x R); 0 = default (the fewest shards that fit a GPU -- 1 for "
+                         "configs 2 / 3 / 5: profiles/r05_rank_shares.md; the whole world for config 4, which is defined that way), "
+                         "world = pure reference sharding")
+    ap.add_argument("--no-ref-sharded-leg", action="store_true",
+                    help="N > 1, config 2: skip the secondary leg that runs the pure reference sharding + RCCL merge next to the headline layout")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (+ --share-gpu) rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -403,6 +406,69 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
     return res, bool(ok) and not overflow
 
 
+def reference_sharded_leg(ctx, ref_full, codes, out_main, steps, warmup):
+    """N > 1, config 2, secondary leg OUTSIDE the headline: the north-star's own choreography -- the reference partitioned over
+    ALL ranks, every rank searching every query against its shard, ONE packed RCCL collective, the strided exact merge -- next
+    to the default layout (query groups only), which is faster at this size because the filter's per-query work does not
+    shrink with the shard (profiles/r05_rank_shares.md).  Both numbers of one run on the same GPUs; this rank's merged lists
+    are compared bit for bit with the headline layout's lists of the same query rows."""
+    import bench_data as bd
+    from cellmapper_amd.sharded import ExchangeState, Layout, shard_bounds, sharded_mapping_rows
+
+    a, torch, dist, dev, world, rank, ops = ctx.a, ctx.torch, ctx.dist, ctx.dev, ctx.world, ctx.rank, ctx.ops
+    lay2 = Layout(world, rank, a.nq, world)
+    lo2, hi2 = shard_bounds(a.nref, world, rank)
+    qry_all = bd.fill_rows(torch, "normal", bd.STREAM_QRY, 0, a.nq, a.d, dev)
+    state = ExchangeState(a.exchange)
+    timer = StreamTimer(torch)
+    state.timer = timer
+
+    def step():
+        timer.begin_step()
+        r = sharded_mapping_rows(ops, dist, ref_full[lo2:hi2], lo2, a.nref, qry_all, a.k, metric=a.metric, kernel=a.kernel,
+                                 exchange=a.exchange, group=None, ref_world=world, ref_rank=rank, state=state)
+        code, conf = ops.vote(r["cols"], r["vals"], r["cnt"], codes, a.ncat)
+        return code, conf, r["dist"], r["idx"]
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step()                     # (first step: the exchange self-check runs here)
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(0, warmup - 1)):
+        out = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timer.on = False
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+    # this rank's slice of the merged result against the headline layout's result for the same query rows
+    same = None
+    ql, qh = lay2.my_slice
+    ml, mh = ctx.lay.my_slice
+    if (ql, qh) == (ml, mh) and out_main is not None and len(out_main) >= 4:
+        same = bool(torch.equal(out[3], out_main[3]) and torch.equal(out[2], out_main[2]) and torch.equal(out[0], out_main[0]))
+        same = ctx.all_true(same)
+    tm = timer.means()
+    return {"parallelism": f"q1xr{world}", "what": "the reference partitioned over all ranks, every rank searches all queries against its shard, one packed "
+            "RCCL collective, strided exact merge, world-wide bandwidth, vote on the rank's query slice (the north-star's choreography)",
+            "ms_per_step": el / steps * 1e3, "value": a.nq * steps / el, "unit": "query cells/s", "steps": steps, "warmup": warmup,
+            "first_call_ms": first_ms, "exchange": state.describe(),
+            "rank0_stream_ms": {"local_search": tm.get("search_to_exchange_ms"), "exchange_and_merge": tm.get("exchange_to_merged_ms")},
+            "exchange_bytes_handed_to_the_collective_rank0": float(state.sent_words) * 8.0,
+            "lists_and_labels_equal_headline_layout": same}, (same is not False)
+
+
 def git_rev(path):
     try:
         return subprocess.check_output(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, text=True,
@@ -469,7 +535,7 @@ class RunCtx:
 
         self.a, self.torch, self.dist, self.world, self.rank, self.dev, self.pipe, self.use_dist = a, torch, dist, world, rank, dev, pipe, use_dist
         default_shards = world if a.config == 4 else None
-        self.lay = Layout(world, rank, a.nq, a.ref_shards or default_shards)
+        self.lay = Layout(world, rank, a.nq, a.ref_shards or default_shards, ref_bytes=4 * a.nref * a.d)
         self.ops = HipOps(pipe)
         self.pg = make_groups(dist, world, self.lay.n_groups, self.lay.ref_shards, a.exchange) if world > 1 else None
         self.state = ExchangeState(a.exchange)
@@ -885,6 +951,11 @@ def main_rank(a):
                 result["cpu_baseline"] = cb
         if a.check <= 0:
             parity_ok = True
+    if use_dist and world > 1 and a.config == 2 and lay.ref_shards == 1 and not a.no_ref_sharded_leg:
+        rrec, r_ok = reference_sharded_leg(ctx, ref, codes, out, steps=max(3, a.steps // 4), warmup=max(1, min(2, a.warmup)))
+        if rank == 0:
+            result["reference_sharded"] = rrec
+        parity_ok = parity_ok and r_ok
     if (a.config == 2 and world == 1 and not use_dist and a.check > 0 and a.metric == "euclidean" and not a.no_clustered
             and a.nq == CONFIGS[2]["nq"] and a.nref == CONFIGS[2]["nref"]):
         crec, c_ok = clustered_leg(ctx, codes, steps=max(3, a.steps // 4), warmup=max(1, min(2, a.warmup)))

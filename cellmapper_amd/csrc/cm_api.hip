@@ -178,7 +178,7 @@ void xfer_drop(cm_handle_t h) {
 cm_status xfer_get(cm_handle_t h, Xfer **out) {
     if (h->xfer) { *out = static_cast<Xfer *>(h->xfer); return CM_OK; }
     const cm_knobs &kn = cm_get_knobs();
-    int T = kn.xfer_threads > 0 ? kn.xfer_threads : 4;   // (4 threads move what 8 do: profiles/r04_host_leg.md; half the pinned memory and streams to set up)
+    int T = kn.xfer_threads > 0 ? kn.xfer_threads : 8;   // (downloads into FRESH arrays are bound by page faults, which scale with the threads: 4 threads 34 GB/s, profiles/r05_host_layer.md)
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) T = std::min(T, std::max(1, CPU_COUNT(&set)));
     T = std::max(1, std::min(T, 32));

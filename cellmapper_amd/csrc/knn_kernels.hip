@@ -2335,20 +2335,24 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         } else {
             // dropped split products: |ql.y'| <= 2^-11 |q||y'| each (fp16 round-to-nearest), y' = -2y
             c_split = (level == 1 ? 2.0f : (level == 2 ? 1.0f : 0.f)) * 4.8828125e-4f * 1.01f;
-            // Accumulation + representation (8.4e-7).  Levels 1 and 2 (and the bucket-centred level, which is level 1's arithmetic):
-            // the ANALYTIC worst case of the chain -- n = 16 KSTEPS products per split product summed into the accumulator (+ the
-            // |y|^2 operand of K = 128), every addition rounding by at most one unit in the last place of a partial sum that
-            // never exceeds the sum of the magnitudes (truncation assumed, whatever the order inside an instruction):
-            // (n + 1) 2^-23 sum|terms|.  It holds for either MFMA shape (16 or 32 products per instruction: the same number
-            // of additions).  The dropped split products (c_split / the lo norms) are 60 - 270 x larger at these levels, so
-            // the proven constant costs nothing measurable (profiles/r05_accumulation_bound.md) and the exactness argument of
-            // the levels every benchmark configuration certifies at contains no measured constant.
-            // Level 3 keeps the device-validated model of the f16 MFMA chain, doubled (tests/test_gpu_parity.py::
-            // test_mfma_f16_accumulation_bound checks it on the device the tests run on): there the accumulation term IS the
-            // error bound, and the analytic constant (193 2^-23 at K = 64, four times the model) would send queries of tight
-            // clusters on to level 4, fifteen times the cost.
-            if (level <= 2 && !(dbg & 64))   // (CELLMAP_DBG=64: the measured model at every level -- the A/B of profiles/r05_accumulation_bound.md)
-                c_eps = (float)(16 * p2.KSTEPS * level + (wide || cenl ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // (+1: the |y|^2 / side-value operand)
+            // Accumulation + representation (8.4e-7).  The plain levels 1 and 2 use the ANALYTIC worst case of the chain -- n = 16 KSTEPS
+            // products per split product summed into the accumulator (+ the |y|^2 operand of K = 128), every addition rounding by
+            // at most one unit in the last place of a partial sum that never exceeds the sum of the magnitudes (truncation
+            // assumed, whatever the order inside an instruction): (n + 1) 2^-23 sum|terms|.  It holds for either MFMA shape (16
+            // or 32 products per instruction: the same number of additions).  The dropped split products (c_split / the lo
+            // norms) are 60 - 270 x larger at these levels, so the proven constant costs nothing: config 2 and the sigma = 2
+            // mixture certify every query at level 1 in the same time under either constant (profiles/r05_accumulation_bound.md),
+            // and the exactness argument of the level every benchmark configuration's headline certifies at contains no
+            // measured constant.
+            // Level 3 and the bucket-centred level keep the device-validated model of the f16 MFMA chain, doubled
+            // (tests/test_gpu_parity.py::test_mfma_f16_accumulation_bound checks it on the device the tests run on): there the
+            // accumulation term IS the error bound -- three exact products at level 3; at the centred level the dropped products
+            // scale with the bucket radius, not with |q'| -- and the analytic constant (2.1 x / 4 x the model) sends the queries of
+            // tight clusters on to the next level: measured on the sigma = 0.1 mixture, 750 k x 1.5 M, the centred level
+            // certified 69 % under the model and the pilot skipped it altogether under the analytic constant (97 -> 185 ms,
+            // same file).  DESIGN.md section 4.
+            if (level <= 2 && !cenl && !(dbg & 64))   // (CELLMAP_DBG=64: the measured model at every level -- the A/B of profiles/r05_accumulation_bound.md)
+                c_eps = (float)(16 * p2.KSTEPS * level + (wide ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // (+1: the |y|^2 operand of K = 128)
             else {
                 c_eps = 2.0f * (float)(16 + 2 * (p2.KSTEPS * level + (wide ? 1 : 0))) * 5.9604645e-8f + 8.4e-7f;   // K = 128: + the |y|^2 add
                 if (r16) c_eps = 2.0f * (float)(32 + 2 * (p2.KSTEPS / 2)) * 5.9604645e-8f + 8.4e-7f;   // (not reachable: r16 is a level-1 kernel)

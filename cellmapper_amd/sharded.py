@@ -69,6 +69,12 @@ class HipOps:
                    out=(buf[0].view(t.float64)[:nq], buf[1][:nq]))
         return buf
 
+    def local_knn_final(self, ref_shard, qry, k, metric, idx_offset):
+        """The search of a layout with ONE reference shard: final ``(dist float64 [nq, k], idx int64 [nq, k])`` -- the values
+        :meth:`merge_packed` of a single part would return (euclidean: the root of the squared ranking values), without the
+        packed buffer and the merge pass."""
+        return self.p.knn(ref_shard, qry, k, metric=metric, idx_offset=idx_offset, f64_out=True)
+
     def merge_packed(self, buf, nparts, part_stride, dist_off, idx_off, nq, k, metric):
         """k-way merge of ``nparts`` lists per query living in one packed buffer (offsets / stride in 8-byte words)."""
         return self.p.merge_strided(buf, nparts, part_stride, dist_off, idx_off, nq, k, sqrt_out=(metric == "euclidean"))
@@ -120,16 +126,29 @@ class HipOps:
         return self.t.tensor([1 if ok else 0], dtype=self.t.int32, device=like.device)
 
 
-def grid_2d(world: int, ref_shards: int | None = None):
+REF_SHARD_BUDGET_BYTES = 32 << 30   # a reference shard larger than this is split further (MI355X: 288 GB; the search's tile image, the
+                                    # per-query workspace and the payloads want the rest)
+
+
+def grid_2d(world: int, ref_shards: int | None = None, ref_bytes: int | None = None, budget: int = REF_SHARD_BUDGET_BYTES):
     """(query groups, reference shards) with ``groups * shards == world``.
 
-    The reference is always partitioned when there is more than one GPU; by default two-way, and the
-    remaining parallelism goes to the QUERY axis: query groups need no exchange at all, and a rank's shard stays large
-    enough for the filter's log-n per-query overhead to amortise.  ``ref_shards=world`` gives the
-    pure reference sharding of the north-star wording.
+    Default (round 5, from measurements -- profiles/r05_rank_shares.md): the FEWEST reference shards whose shard fits
+    ``budget`` bytes of a GPU, all remaining parallelism on the QUERY axis.  One rank's share of BASELINE config 2 on the
+    current library, per query searched: 0.030 us per shard visited + 8.5e-8 us per reference row (d = 50; d = 128: 0.029 us +
+    2.1e-7) -- the filter's candidate handling (appends, merges, re-rank) is paid once per (query, shard) and does not shrink
+    with the shard, so splitting the reference R ways adds R x that overhead in total while splitting the queries adds
+    nothing and needs no exchange.  At 8 GPUs: 8 query groups x 1 shard 37 ms per step, 4 x 2 45 ms, 2 x 4 48 ms, pure
+    reference sharding (1 x 8) 65 ms.  A reference that does not fit one GPU (``ref_bytes / shards > budget``) is split
+    as far as needed; ``ref_shards=world`` forces the pure reference sharding of the north-star wording (BASELINE config 4
+    is DEFINED that way and bench.py runs it so), any other value the 2-D layout.  Without ``ref_bytes`` the reference is
+    taken to fit.
     """
     if ref_shards is None:
-        ref_shards = 2 if world % 2 == 0 else (world if world > 1 else 1)
+        ref_shards = 1
+        if ref_bytes is not None:
+            while ref_shards < world and (world % ref_shards or ref_bytes / ref_shards > budget):
+                ref_shards += 1
     ref_shards = max(1, min(world, int(ref_shards)))
     while world % ref_shards:
         ref_shards -= 1
@@ -139,9 +158,9 @@ def grid_2d(world: int, ref_shards: int | None = None):
 class Layout:
     """Who owns what in the 2-D layout: ``rank = group * ref_shards + ref_rank``.  All row numbers are GLOBAL query rows."""
 
-    def __init__(self, world: int, rank: int, nq_total: int, ref_shards: int | None = None):
+    def __init__(self, world: int, rank: int, nq_total: int, ref_shards: int | None = None, ref_bytes: int | None = None):
         self.world, self.rank, self.nq_total = int(world), int(rank), int(nq_total)
-        self.n_groups, self.ref_shards = grid_2d(world, ref_shards)
+        self.n_groups, self.ref_shards = grid_2d(world, ref_shards, ref_bytes)
         self.group, self.ref_rank = rank // self.ref_shards, rank % self.ref_shards
         self.group_lo, self.group_hi = shard_bounds(nq_total, self.n_groups, self.group)   # the queries this rank searches
 
@@ -259,6 +278,15 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
     nq_pad = per * world
     if state is not None:
         state.mark("search")
+    if world == 1 and hasattr(ops, "local_knn_final"):
+        # one reference shard (the default layout when the reference fits a GPU): nothing to exchange or merge -- the search
+        # writes the final lists itself (float64 values, root taken for euclidean: what the merge of one part would produce)
+        dist, idx = ops.local_knn_final(ref_shard, qry, k, metric, shard_lo)
+        if state is not None:
+            state.mark("exchange")
+            state.sent_words = 0
+            state.mark("merged")
+        return dist, idx, (0, nq)
     send = ops.local_knn_packed(ref_shard, qry, k, metric, shard_lo, nq_pad)   # [2, nq_pad, k] 8-byte words
     if state is not None:
         state.mark("exchange")
@@ -266,6 +294,8 @@ def sharded_knn(ops, dist_mod, ref_shard, shard_lo, qry, k, metric="euclidean", 
     pk = per * k
     if world == 1:
         dist, idx = ops.merge_packed(send, 1, 2 * nq_pad * k, 0, nq_pad * k, nq, k, metric)
+        if state is not None:
+            state.mark("merged")
         return dist, idx, (0, nq)
     q_lo, q_hi = slice_bounds(nq, world, rank)
     n_mine = max(q_hi - q_lo, 0)

@@ -177,9 +177,12 @@ def test_query_imputed_setter_validation():
 def test_grid_2d_layout():
     from cellmapper_amd.sharded import grid_2d
 
-    assert grid_2d(1) == (1, 1) and grid_2d(2) == (1, 2) and grid_2d(4) == (2, 2) and grid_2d(8) == (4, 2)
+    # default (round 5): as few reference shards as fit a GPU -- all parallelism on the query axis when the reference fits
+    assert grid_2d(1) == (1, 1) and grid_2d(2) == (2, 1) and grid_2d(4) == (4, 1) and grid_2d(8) == (8, 1)
+    assert grid_2d(8, None, ref_bytes=300 << 20) == (8, 1) and grid_2d(8, None, ref_bytes=100 << 30) == (2, 4)
+    assert grid_2d(8, None, ref_bytes=1 << 40) == (1, 8) and grid_2d(6, None, ref_bytes=70 << 30) == (2, 3)
     assert grid_2d(8, 8) == (1, 8) and grid_2d(8, 4) == (2, 4) and grid_2d(8, 1) == (8, 1)
-    assert grid_2d(3) == (1, 3) and grid_2d(6, 4) == (2, 3)
+    assert grid_2d(3) == (3, 1) and grid_2d(6, 4) == (2, 3) and grid_2d(3, 3) == (1, 3)
     for w in range(1, 17):
         for r in (None, 1, 2, 3, 4, 8, 16):
             g, s = grid_2d(w, r)

@@ -40,13 +40,24 @@ def test_config4_at_its_full_size_on_one_gpu():
     assert r["roofline"]["frac"] > 0.35, r["roofline"]
 
 
-@pytest.mark.parametrize("n", [2, 4])
-def test_sharded_label_transfer_line_is_self_checked(n):
+@pytest.mark.parametrize("n,ref_shards", [(2, 0), (4, 0), (4, 2), (2, 2)])
+def test_sharded_label_transfer_line_is_self_checked(n, ref_shards):
+    """ref_shards = 0: the default layout (round 5: query groups only, the reference replicated -- no exchange in the headline)
+    with the reference-sharded secondary leg, whose packed exchange checks itself and whose merged lists must equal the
+    headline layout's bit for bit; ref_shards > 0: the exchange in the headline path (2-D / pure reference sharding)."""
     args = ["--steps", "1", "--warmup", "1", "--nq", "120000", "--nref", "150000", "--check", "512", "--cpu-sample", "512",
-            "--no-host-leg", "--backend", "gloo", "--share-gpu", "--master-port", str(29600 + n)]
+            "--no-host-leg", "--backend", "gloo", "--share-gpu", "--master-port", str(29600 + n + 10 * ref_shards)]
+    if ref_shards:
+        args += ["--ref-shards", str(ref_shards)]
     r = _bench("--gpus", str(n), *args)
     assert r["n_gpus"] == n and r["parity_check"]["ok"] and r["parity_check"]["ranks_sampled"] == n, r.get("parity_check")
-    assert r["config"]["exchange"]["self_check"] == "passed" and r["cpu_baseline"]["cores"] >= 1, r["config"]["exchange"]
+    assert r["cpu_baseline"]["cores"] >= 1
+    if ref_shards:
+        assert r["config"]["parallelism"] == f"q{n // ref_shards}xr{ref_shards}" and r["config"]["exchange"]["self_check"] == "passed", r["config"]
+    else:
+        assert r["config"]["parallelism"] == f"q{n}xr1" and r["config"]["exchange"] is None, r["config"]
+        rs = r["reference_sharded"]
+        assert rs["parallelism"] == f"q1xr{n}" and rs["exchange"]["self_check"] == "passed" and rs["lists_and_labels_equal_headline_layout"] is True, rs
 
 
 def test_sharded_layer_transfers_equal_the_one_gpu_run():

@@ -78,7 +78,7 @@ def test_config2_all_rows_by_an_independent_route(pipe, oracle, monkeypatch):
     assert np.array_equal(idx[sel].cpu().numpy(), oi) and np.array_equal(dist[sel].cpu().numpy(), od)
 
 
-A3_MS_PER_MILLION_ROWS_MAX = 200.0
+A3_MS_PER_MILLION_ROWS_MAX = 160.0   # (builder-run, round 5: 125 ms per million rows on this slice, 125-127 at the full 4 M)
 
 
 def _emit(capsys, tag, rec):

@@ -157,14 +157,16 @@ def test_sharded_rejects_unsupported_metric():
 
 
 @pytest.mark.parametrize("world,ref_shards,exchange,kernel,metric", [
-    (2, None, "alltoall", "gaussian", "euclidean"),    # 1 query group x 2 reference shards (pure reference sharding)
-    (2, None, "allgather", "scarches", "euclidean"),
+    (2, 2, "alltoall", "gaussian", "euclidean"),       # 1 query group x 2 reference shards (pure reference sharding)
+    (2, 2, "allgather", "scarches", "euclidean"),
+    (2, None, "alltoall", "gaussian", "euclidean"),    # the default layout (round 5): query groups only, the reference replicated -- no exchange, world-wide sigma
+    (4, None, "alltoall", "scarches", "euclidean"),
     (4, 2, "alltoall", "gaussian", "euclidean"),       # 2 query groups x 2 reference shards: the groups' all-to-all inside the world's (split sizes), world-wide sigma
     (4, 2, "allgather", "gaussian", "euclidean"),      # ... and through real sub-groups (new_group)
     (3, 3, "alltoall", "scarches", "euclidean"),       # odd world, ragged slices
-    (2, None, "alltoall", "gaussian", "cosine"),       # cosine: merged values are NOT square-rooted
+    (2, 2, "alltoall", "gaussian", "cosine"),          # cosine: merged values are NOT square-rooted
     (3, 3, "allgather", "inverse_distance", "cosine"),
-    (2, None, "alltoall", "gaussian", "manhattan"),    # metric pass-through: merged values are the distances themselves
+    (2, 2, "alltoall", "gaussian", "manhattan"),       # metric pass-through: merged values are the distances themselves
 ])
 def test_sharded_choreography(world, ref_shards, exchange, kernel, metric, tmp_path, oracle):
     import torch.multiprocessing as mp
@@ -259,7 +261,8 @@ def _worker_layers(rank, world, port, out_dir, ref_shards, break_alltoall):
 
 
 @pytest.mark.parametrize("world,ref_shards,break_alltoall", [
-    (2, None, False),    # 1 query group x 2 reference shards
+    (2, 2, False),       # 1 query group x 2 reference shards
+    (2, None, False),    # default layout: 2 query groups x 1 shard
     (4, 2, False),       # 2 x 2: ragged query groups (157 rows), world-wide all-gather of the mapping-matrix rows
     (3, 3, False),       # odd world, ragged slices and gene slabs
     (4, 2, True),        # the all-to-all raises on the first step -> world all-gather fall-back, same results
