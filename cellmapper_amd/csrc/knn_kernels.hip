@@ -1678,7 +1678,7 @@ __global__ void fl_gather(const int *__restrict__ flag, const int *__restrict__ 
 // said about it; for the rows that were visited the usual certificate (min over the lists' thresholds) applies.
 // Nothing here depends on how good the buckets are: bad buckets only mean nothing is skipped.
 constexpr int IVF_SB = 13;      // pass-B runs (candidate lists) per query block; slot 0 is pass A
-constexpr int IVF_CSTR = 64;    // doubles per centre (d <= 61 on this path)
+constexpr int IVF_CSTR = 128;   // doubles per centre (round 5: the K = 128 family prunes too, d <= 128)
 // the IVF_SB + 1 candidate lists per query are the one large buffer of the scheme: not worth more than 16 GiB of workspace
 static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
     return (size_t)(nq_pad + 256 * 512) * (IVF_SB + 1) * (size_t)Kc_max * 4 <= ((size_t)16 << 30);
@@ -1691,36 +1691,42 @@ static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
 template <typename T, bool RAD>
 __global__ __launch_bounds__(256) void ivf_ball_pass(const T *__restrict__ X, int d, int metric, const double *__restrict__ mean,
                                                      const int *__restrict__ map, const int *__restrict__ gstart, int64_t n_map,
-                                                     double *__restrict__ cen, unsigned long long *__restrict__ rad2,
+                                                     int gsize, double *__restrict__ cen, unsigned long long *__restrict__ rad2,
                                                      int *__restrict__ cnt) {
-    __shared__ double s_acc[4][64];
+    // lane e holds coordinates e and e + 64 (d <= 128); gsize: rows per group when there is no gstart (the query block of the
+    // stage's filter kernel: 512, or 256 for the three-product kernel of the K = 128 family)
+    __shared__ double s_acc[4][128];
     __shared__ double s_r[4];
     __shared__ int s_n[4];
     const int g = blockIdx.x, e = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t lo = gstart ? (int64_t)gstart[g] : (int64_t)g * cmk2::QB;
-    int64_t hi = gstart ? (int64_t)gstart[g + 1] : lo + cmk2::QB;
+    const int e2 = e + 64;
+    const int64_t lo = gstart ? (int64_t)gstart[g] : (int64_t)g * gsize;
+    int64_t hi = gstart ? (int64_t)gstart[g + 1] : lo + gsize;
     if (hi > n_map) hi = n_map;
-    const double me = e < d ? mean[e] : 0.0;
-    const double ce = RAD ? cen[(size_t)g * IVF_CSTR + e] : 0.0;
-    double acc = 0.0;   // RAD: running max of the squared distance; otherwise this lane's coordinate sum
+    const double me = e < d ? mean[e] : 0.0, me2 = e2 < d ? mean[e2] : 0.0;
+    const double ce = RAD ? cen[(size_t)g * IVF_CSTR + e] : 0.0, ce2 = RAD ? cen[(size_t)g * IVF_CSTR + e2] : 0.0;
+    double acc = 0.0, acc2 = 0.0;   // RAD: running max of the squared distance (acc); otherwise this lane's coordinate sums
     int n = 0;
     for (int64_t r = lo + (int64_t)blockIdx.y * 4 + w; r < hi; r += 4 * (int64_t)gridDim.y) {
         const int src = map ? map[r] : (int)r;
         if (src < 0) continue;   // (wave-uniform)
         double v = e < d ? (double)X[(int64_t)src * d + e] : 0.0;
+        double v2 = e2 < d ? (double)X[(int64_t)src * d + e2] : 0.0;
         if (metric == CM_METRIC_COSINE) {
-            double s2 = v * v;
+            double s2 = v * v + v2 * v2;
             for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
             const double nrm = sqrt(s2);
-            v *= nrm > 0.0 ? 1.0 / nrm : 1.0;
+            const double ns = nrm > 0.0 ? 1.0 / nrm : 1.0;
+            v *= ns; v2 *= ns;
         }
         if (RAD) {
-            const double t = e < d ? v - me - ce : 0.0;
-            double s2 = t * t;
+            const double t = e < d ? v - me - ce : 0.0, t2 = e2 < d ? v2 - me2 - ce2 : 0.0;
+            double s2 = t * t + t2 * t2;
             for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
             acc = fmax(acc, s2);
         } else {
             acc += e < d ? v - me : 0.0;
+            acc2 += e2 < d ? v2 - me2 : 0.0;
         }
         ++n;
     }
@@ -1731,9 +1737,13 @@ __global__ __launch_bounds__(256) void ivf_ball_pass(const T *__restrict__ X, in
             atomicMax(&rad2[g], (unsigned long long)__double_as_longlong(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3]))));
     } else {
         s_acc[w][e] = acc;
+        s_acc[w][e2] = acc2;
         if (e == 0) s_n[w] = n;
         __syncthreads();
-        if (w == 0 && e < d) atomicAdd(&cen[(size_t)g * IVF_CSTR + e], s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]);
+        if (w < 2) {
+            const int c = e + 64 * w;
+            if (c < d) atomicAdd(&cen[(size_t)g * IVF_CSTR + c], s_acc[0][c] + s_acc[1][c] + s_acc[2][c] + s_acc[3][c]);
+        }
         if (threadIdx.x == 0) atomicAdd(&cnt[g], s_n[0] + s_n[1] + s_n[2] + s_n[3]);
     }
 }
@@ -1752,13 +1762,13 @@ __global__ void ivf_ball_radius(int G, double *__restrict__ rad /* in: bits of t
 }
 template <typename T>
 static void ivf_ball(hipStream_t st, const T *X, int d, int metric, const double *mean, const int *map, const int *gstart,
-                     int64_t n_map, int G, int slices, double *cen, double *rad, int *cnt) {
+                     int64_t n_map, int G, int slices, double *cen, double *rad, int *cnt, int gsize = cmk2::QB) {
     const unsigned nb = (unsigned)((G * IVF_CSTR + 255) / 256);
     auto *rad2 = reinterpret_cast<unsigned long long *>(rad);
     hipLaunchKernelGGL(ivf_ball_zero, dim3(nb), dim3(256), 0, st, G, cen, rad2, cnt);
-    hipLaunchKernelGGL((ivf_ball_pass<T, false>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, cen, rad2, cnt);
+    hipLaunchKernelGGL((ivf_ball_pass<T, false>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, gsize, cen, rad2, cnt);
     hipLaunchKernelGGL(ivf_ball_centre, dim3(nb), dim3(256), 0, st, G, cen, (const int *)cnt);
-    hipLaunchKernelGGL((ivf_ball_pass<T, true>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, cen, rad2, cnt);
+    hipLaunchKernelGGL((ivf_ball_pass<T, true>), dim3(G, slices), dim3(256), 0, st, X, d, metric, mean, map, gstart, n_map, gsize, cen, rad2, cnt);
     hipLaunchKernelGGL(ivf_ball_radius, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, rad);
 }
 
@@ -1827,7 +1837,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
                                                   float c_eps, int level, const int4 *__restrict__ wl_a,
                                                   const int *__restrict__ jstar, int4 *__restrict__ wl_b,
-                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb) {
+                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb, int qblk) {
     // sb <= IVF_SB: runs (candidate lists) per block this stage may use -- the re-rank holds (sb + 1) * K' candidates
     // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
     // relative error -c_eps and the float64 -> float32 input rounding dlt per coordinate (see knn_rerank)
@@ -1840,7 +1850,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     const double rho_y = (double)__uint_as_float(gmax[5]);
     const double dlt = is_f64 ? 2.0 * 5.9604645e-8 * (double)__uint_as_float(gmax[4]) : 0.0;
     double dm = 0.0;
-    for (int64_t i = (int64_t)b * cmk2::QB + tid; i < (int64_t)(b + 1) * cmk2::QB && i < nsub; i += 256) {
+    for (int64_t i = (int64_t)b * qblk + tid; i < (int64_t)(b + 1) * qblk && i < nsub; i += 256) {   // (qblk: queries per block of the stage's filter kernel)
         if (qmap && qmap[i] < 0) continue;
         const float tau = cthr[i * S];
         double D = INFINITY;
@@ -2170,7 +2180,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
     if (!hint_same || h->staged_ivf_nref != n_ref || h->staged_ivf_nq != nq) h->staged_ivf_skip = 0;
-    bool ivf_try = rperm && !wide && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !cm_get_knobs().no_ivf;
+    // (round 5: the K = 128 family prunes too -- its hi*hi level on 512-query blocks like the K <= 64 kernels, its three-product
+    //  level on the 256-query blocks of knn_cand_f16w)
+    bool ivf_try = rperm && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !cm_get_knobs().no_ivf;
     if (ivf_try && h->staged_ivf_skip > 0 && !cm_get_knobs().no_hint) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
@@ -2280,6 +2292,30 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps;
             }
         }
+        // Round 5: the same rounds x item-cost choice for the hi*hi level of the K = 128 family (knn_cand_f16p<8>, one 512-query
+        // workgroup per CU): its plan used to split the reference only when there were fewer query blocks than CUs, so a set of
+        // 1.2 .. 3 rounds left up to 40 % of the last round idle.  Splitting is cheap at this width -- the per-query candidate
+        // handling is a twentieth of an item, not a quarter (one rank's share of config 4 at 1.5 M / 3 M / 6 M reference rows
+        // per query: 2.19 / 2.09 / 2.06 e-10 s per pair, profiles/r05_rank_shares.md) -- so the model takes 1 .. 4 splits when
+        // that finishes sooner.  Large sets (config 4's 2 930 blocks: 11.45 rounds) keep S = 1.
+        if (wide && level == 1 && !pilot && !cenl && !forced && p2.S == 1 && cm_get_knobs().q4 != 0) {
+            const int res = h->n_cu > 0 ? h->n_cu : 256;
+            auto item = [](int S) { return 0.95 / S + 0.05 * (1.0 + log(std::max(1.0, 12.0 / S))) / (1.0 + log(12.0)); };
+            auto rounds = [&](int64_t blocks, int S) { return (double)((blocks * S + res - 1) / res); };
+            double best = rounds(p2.nqb, 1) * item(1);
+            int Sw = 1;
+            for (int S = 2; S <= 4; ++S) {
+                if (S * p2.Kc > RR_NCMAX || p2.n_tiles / S < 256 || (int64_t)p2.nq_pad * S > cand_rows) continue;
+                const double r = rounds(p2.nqb, S) * item(S);
+                if (r < best * 0.94) { best = r; Sw = S; }   // (6 % margin: the split's lists cost the re-rank ~2 ms per 200 k queries too)
+            }
+            if (Sw > 1) {
+                p2.tps = (p2.n_tiles + Sw - 1) / Sw;
+                p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps;
+                const int64_t nw = (int64_t)p2.nqb * p2.S;
+                p2.grid = (int)(nw < res ? nw : res);
+            }
+        }
         // Round 4: under CELLMAP_R16=1 the 128-queries-per-wave stage at K = 64 runs on the 16x16x32 MFMA shape
         // (knn_phase1_r16.h: built, exact, measured level with the 32x32x16 kernel -- profiles/r04_mfma_shape_probe.md -- and
         // therefore not the default).  Its chains are 2 instructions of 32 products each: see c_eps below.
@@ -2385,12 +2421,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
         // must never be dropped for holding too many (its only way out would be the exact scan with a loose bound)
         const int ivf_sb = std::min(IVF_SB, RR_NCMAX / p2.Kc - 1);
-        if (ivf_try && full_set && !pilot && rerank && !w3 && ivf_sb >= 2 && nsub >= 65536) {
+        if (ivf_try && full_set && !pilot && rerank && ivf_sb >= 2 && nsub >= 65536) {
+            const int qblk = (int)(p2.nq_pad / std::max(p2.nqb, 1));   // queries per work item of this stage's filter kernel (512; 256: knn_cand_f16w, direct rows beyond 64 floats)
             const int BRt = level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR;   // reference rows per tile of this level's image
 
             // ---- bucket pruning: pass A over every block's nearest bucket, plan, pass B over what cannot be ruled out
             const int C = LS_CMAX;
-            const int64_t nqb_max = (nq_pad + pack_slack) / cmk2::QB + 1;
+            const int64_t nqb_max = (nq_pad + pack_slack) / (big_rows ? 256 : cmk2::QB) + 1;
             if (!ivf_rcen) {
                 ivf_rcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * IVF_CSTR);
                 ivf_rrad = (double *)cm_ws_alloc(h, sizeof(double) * C);
@@ -2411,7 +2448,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                             ivf_rcen, ivf_rrad, ivf_rcnt);
             }
             ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
-                        ivf_bcnt);
+                        ivf_bcnt, qblk);
             hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
             hipLaunchKernelGGL(ivf_overlap, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
                                (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, BRt,
@@ -2468,7 +2505,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                (const float *)ivf_cthr, ivf_S, (const float *)qnorm, (const float *)qlo,
                                cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
                                (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
-                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256, ivf_sb);
+                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256, ivf_sb, qblk);
             CM_HIP(h, hipGetLastError());
             int *hc = h->d_nflag_pinned + 4;
             CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -1119,11 +1119,20 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
     const unsigned arow = c * ROWB + ((hh ^ swz(c, KSTEPS)) * 16);   // see knn_cand_f16
     const unsigned yrow = BR * ROWB + 16 * hh;   // |y|^2 side block: rows 4*hh + {0..3} + 8*i of a sub-tile
 
-    const int n_work = a.nqb * a.S;
+    // work items: (query block, reference split) pairs, or -- bucket pruning (round 5) -- the explicit (query block, tile run,
+    // candidate-list slot) items of a work list, as in knn_cand_f16 (static hand-out: the items of a pruned stage are many and short)
+    const int n_work = a.wlist ? (a.n_wlist_dev ? *a.n_wlist_dev : a.n_wlist) : a.nqb * a.S;
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
-        const int qb = work / a.S, split = work - qb * a.S;
-        const int t0 = split * a.tiles_per_split;
-        const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        int qb, split, t0, t1;
+        if (a.wlist) {
+            const int4 w_ = a.wlist[work];
+            qb = __builtin_amdgcn_readfirstlane(w_.x); t0 = __builtin_amdgcn_readfirstlane(w_.y);
+            t1 = __builtin_amdgcn_readfirstlane(w_.z); split = __builtin_amdgcn_readfirstlane(w_.w);
+        } else {
+            qb = work / a.S; split = work - qb * a.S;
+            t0 = split * a.tiles_per_split;
+            t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
+        }
         const int64_t qbase = (int64_t)qb * QBW + wave * 32;
         half8 qh[KSTEPS], ql[KSTEPS];
         {
@@ -1138,6 +1147,10 @@ __global__ __launch_bounds__(NTW, 2) void knn_cand_f16w(P1Args a) {
         for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[s]), "v"(ql[s]));  // see knn_cand_f16
         // slot 1 of the per-lane state is inert (threshold -inf): the shared macros iterate over two accumulators
         float thr[2] = {INFINITY, -INFINITY};
+        if (a.thr0_slot0) {   // pass B of a pruned stage starts from the pass-A threshold of the query (list slot 0)
+            thr[0] = a.cthr[(qbase + c) * a.S];
+            asm volatile("" : "+v"(thr[0]));
+        }
         int cnt[2] = {0, 0};
         int keptn[2] = {0, 0};
 

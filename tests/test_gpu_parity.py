@@ -454,6 +454,33 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
+@pytest.mark.parametrize("d,sigma,dtype", [(128, 1.0, np.float32), (100, 0.3, np.float32), (72, 2.5, np.float64)])
+def test_wide_family_bucket_pruning_is_exact(hip, oracle, monkeypatch, d, sigma, dtype):
+    """Round 5: the K = 128 family (62 <= d <= 128) prunes (query block, reference bucket) pairs like the K <= 64 kernels -- the
+    hi*hi level on 512-query blocks, the three-product level (knn_cand_f16w, work-list mode) on 256-query blocks, the direct
+    level on 256-query blocks.  Clustered sets large enough for the gate: identical to the search without pruning on EVERY row,
+    identical to the oracle on a sample; the pruned stage visits a fraction of the (block, tile) pairs."""
+    rng = np.random.default_rng(65 + d)
+    k, n_ref, nq = 20, 220_000, 140_000
+    cen = rng.standard_normal((40, d)) * 5.0
+    ref = (cen[rng.integers(0, 40, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(dtype)
+    qry = (cen[rng.integers(0, 40, nq)] + sigma * rng.standard_normal((nq, d))).astype(dtype)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    assert st["lowd_path"] == 4 and st["fallback_queries"] <= 64, st
+    if sigma <= 1.0:
+        assert 0 < st["tiles_visited_pct"] <= 13, st
+    monkeypatch.setenv("CELLMAP_NO_IVF", "1")
+    dist2, idx2 = hip.knn(ref, qry, k)
+    st2 = hip.knn_stats()
+    assert st2["tiles_visited_pct"] == 0, st2
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2), (st, st2)
+    sel = rng.choice(nq, 400, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 @pytest.mark.parametrize("d,k,dtype", [(32, 10, np.float32), (50, 30, np.float64), (100, 15, np.float32)])
 def test_sample_seeded_thresholds_are_exact(hip, oracle, monkeypatch, d, k, dtype):
     """Unclustered sets over >= 1 024 reference tiles: the main scan starts from thresholds seeded by a
