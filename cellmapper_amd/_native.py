@@ -519,7 +519,7 @@ class DeviceGraph:
             v = np.zeros(8, np.int64)
             self.h.call("cm_graph_part_info", self._g, int(p), _ptr(v))
             out.append(dict(device=int(v[0]), q_lo=int(v[1]), nq=int(v[2]), ref_lo=int(v[3]), ref_rows=int(v[4]),
-                            ref_bytes=int(v[5]), qry_bytes=int(v[6]), exchange=("peer copies", "host-staged")[int(v[7]) % 10],
+                            ref_bytes=int(v[5]), qry_bytes=int(v[6]), exchange=("peer copies", "host-staged", "none (query slices)")[int(v[7]) % 10],
                             self_check=("not run", "passed", "FAILED")[int(v[7]) // 10]))
         return out
 

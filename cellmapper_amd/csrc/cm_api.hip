@@ -44,7 +44,7 @@ void latch_knobs() {
     k.no_sort = on("CELLMAP_NO_SORT"); k.no_chain = on("CELLMAP_NO_CHAIN"); k.no_centre = on("CELLMAP_NO_CENTRE");
     k.no_ivf = on("CELLMAP_NO_IVF"); k.no_hint = on("CELLMAP_NO_HINT"); k.no_perm = on("CELLMAP_NO_PERM");
     k.no_seed = on("CELLMAP_NO_SEED"); k.no_subseed = on("CELLMAP_NO_SUBSEED"); k.no_skip3 = on("CELLMAP_NO_SKIP3");
-    k.multi_staged = on("CELLMAP_MULTI_STAGED"); k.multi_check_fail = on("CELLMAP_MULTI_CHECK_FAIL");
+    k.multi_staged = on("CELLMAP_MULTI_STAGED"); k.multi_check_fail = on("CELLMAP_MULTI_CHECK_FAIL"); k.multi_ref_shard = on("CELLMAP_MULTI_REF_SHARD");
     k.no_pretest = on("CELLMAP_NO_PRETEST"); k.no_preload = on("CELLMAP_NO_PRELOAD");
     k.xfer_mode = 3;   // default (round 5): downloads of 64 MB and more go through the pinned staging ring, everything else takes the plain path
     if (const char *e = getenv("CELLMAP_XFER")) k.xfer_mode = !strcmp(e, "d2h") ? 1 : ((!strcmp(e, "0") || !*e) ? 0 : 2);
@@ -1214,7 +1214,7 @@ struct GraphPart {
 struct cm_graph_s {
     int64_t nq = 0, n_ref = 0;
     int32_t k = 0, metric = 0, dist_is_f32 = 0;
-    int32_t exchange_route = 0;   // multi-device: 0 = peer copies (hipMemcpyPeerAsync), 1 = staged through host memory
+    int32_t exchange_route = 0;   // multi-device: 0 = peer copies (hipMemcpyPeerAsync), 1 = staged through host memory, 2 = none (query slices, reference replicated)
     int32_t self_check = 0;       // multi-device: 0 = not run for this graph, 1 = passed, 2 = FAILED (the graph was re-exchanged through host memory)
     std::vector<GraphPart> parts;
     bool has_map = false;
@@ -1397,14 +1397,15 @@ cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r) {
 
 // one device's search of the queries [0, nq) against reference rows [r_lo, r_lo + n_rows): d_refrows points at row r_lo on
 // the device, d_qry at query 0
-static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const void *d_refrows, const cm_rep_s *qry, const void *d_qry, int64_t r_lo,
+// one device's search of `nq` queries (d_qry points at the first of them) against reference rows [r_lo, r_lo + n_rows)
+static cm_status part_knn(cm_handle_t hp, const cm_rep_s *ref, const void *d_refrows, const void *d_qry, int64_t nq, int64_t r_lo,
                           int64_t n_rows, int32_t k, int32_t metric, int32_t form, int32_t flags, void *d_dist, size_t des, int64_t *d_idx,
                           int64_t *nflag_out) {
     const int64_t QCH = 1 << 21;   // queries in chunks of 2^21 rows like the host tier (bounds the workspace)
     const size_t es = ref->dtype == CM_F64 ? 8 : 4;
     int64_t nflag = 0;
-    for (int64_t q0 = 0; q0 < qry->n; q0 += QCH) {
-        const int64_t nqc = std::min<int64_t>(QCH, qry->n - q0);
+    for (int64_t q0 = 0; q0 < nq; q0 += QCH) {
+        const int64_t nqc = std::min<int64_t>(QCH, nq - q0);
         CM_TRY(begin_call(hp, cm_knn_ws_bytes(n_rows, nqc, ref->d, k, ref->dtype, metric)));
         CM_TRY(cm_knn_run(hp, d_refrows, n_rows, (const char *)d_qry + es * q0 * ref->d, nqc, ref->d,
                           ref->dtype, k, metric, form, r_lo, flags, (char *)d_dist + des * q0 * k, d_idx + q0 * k));
@@ -1462,6 +1463,46 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
     g->dist_is_f32 = (metric == CM_METRIC_COSINE && ref->dtype == CM_F32) ? 1 : 0;
     const auto hs = handle_devices(h);
     size_t P = std::min(hs.size(), std::min(ref->bufs.size(), qry->bufs.size()));
+    // Round 5: a multi-device graph splits the QUERIES when the reference fits a device (32 GB of it; CELLMAP_MULTI_REF_SHARD
+    // forces the reference-sharded choreography below): every device gets the whole reference and its query slice by one peer
+    // copy each, searches on its own, and owns that slice of the graph from then on -- no exchange, no merge, no limit from the
+    // merge's list capacity, and float32 cosine keeps the one-device arithmetic per query by construction.  Measured shares of
+    // one rank (profiles/r05_rank_shares.md): the search costs a fixed amount per (query, shard), so at 8 devices query slices
+    // finish in 37 ms where reference shards take 65.
+    if (P > 1 && !cm_get_knobs().multi_ref_shard && (size_t)ref->n * ref->row_bytes() <= ((size_t)32 << 30)) {
+        size_t Pq = P;
+        while (Pq > 1 && qry->n < (int64_t)Pq * 512) --Pq;   // (a slice should fill at least one 512-query block)
+        if (Pq > 1) {
+            g->parts.resize(Pq);
+            std::vector<int64_t> nflag(Pq, 0);
+            const std::vector<cm_handle_t> hp(hs.begin(), hs.begin() + Pq);
+            const size_t des = g->dist_is_f32 ? 4 : 8;
+            cm_status rc = for_parts(h, Pq, hp, [&](size_t i) -> cm_status {
+                GraphPart &p = g->parts[i];
+                const int64_t base = g->nq / (int64_t)Pq, extra = g->nq % (int64_t)Pq;
+                p.h = hp[i];
+                p.q_lo = (int64_t)i * base + std::min<int64_t>((int64_t)i, extra);
+                p.nq = base + ((int64_t)i < extra ? 1 : 0);
+                p.ref_lo = 0; p.ref_rows = ref->n;
+                CM_TRY(begin_call(hp[i], 0));
+                const void *d_ref = nullptr, *d_q = nullptr;
+                CM_TRY(rep_ensure(h, hs, ref, i, 0, ref->n, &d_ref, &p.ref_bytes));
+                if (ref == qry) { d_q = (const char *)d_ref + (size_t)p.q_lo * ref->row_bytes(); p.qry_bytes = p.ref_bytes; }
+                else CM_TRY(rep_ensure(h, hs, qry, i, p.q_lo, p.nq, &d_q, &p.qry_bytes));
+                CM_TRY(p.dist.alloc(hp[i], des * (size_t)p.nq * k));
+                CM_TRY(p.idx.alloc(hp[i], 8 * (size_t)p.nq * k));
+                return part_knn(hp[i], ref, d_ref, d_q, p.nq, 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag[i]);
+            });
+            (void)hipSetDevice(h->device);
+            int64_t tot = 0;
+            for (auto v : nflag) tot += v;
+            h->knn_stats[0] = tot;
+            g->exchange_route = 2;   // none: query slices
+            if (rc != CM_OK) { (void)cm_graph_destroy(h, g); return rc; }
+            *out = g;
+            return CM_OK;
+        }
+    }
     // reference shards need room for k neighbours and enough rows to be worth a launch; float32 cosine keeps the one-device
     // arithmetic (sklearn's float32 distances)
     // ... and the merge ranks at most CM_MERGE_NCMAX = parts x k entries per query: a large k uses fewer devices (k = 97 on an
@@ -1479,7 +1520,7 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
         rc = p.dist.alloc(h, des * nk);
         if (rc == CM_OK) rc = p.idx.alloc(h, 8 * nk);
         int64_t nflag = 0;
-        if (rc == CM_OK) rc = part_knn(h, ref, ref->bufs[0].p, qry, qry->bufs[0].p, 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag);
+        if (rc == CM_OK) rc = part_knn(h, ref, ref->bufs[0].p, qry->bufs[0].p, qry->n, 0, ref->n, k, metric, form, 0, p.dist.p, des, p.idx.as<int64_t>(), &nflag);
         h->knn_stats[0] = nflag;
     } else {
         // 1. every device: all queries against its reference shard, GLOBAL indices, float64 ranking values (squared for
@@ -1507,7 +1548,7 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
             }
             p.ref_lo = lo; p.ref_rows = rows;
             CM_TRY(packed[i].alloc(hp[i], 16 * nk));
-            return part_knn(hp[i], ref, d_refrows, qry, d_q, lo, rows, k, metric, form, CM_KNN_SQUARED | CM_KNN_F64_OUT,
+            return part_knn(hp[i], ref, d_refrows, d_q, qry->n, lo, rows, k, metric, form, CM_KNN_SQUARED | CM_KNN_F64_OUT,
                             packed[i].p, 8, packed[i].as<int64_t>() + nk, &nflag[i]);
         });
         // 2. + 3. device p owns query slice p: it brings that slice of every device's two planes over (peer copies, or
@@ -1823,7 +1864,7 @@ cm_status cm_graph_part_info(cm_handle_t h, cm_graph_t g, int32_t part, int64_t 
     const GraphPart &p = g->parts[(size_t)part];
     out[0] = p.h ? p.h->device : -1; out[1] = p.q_lo; out[2] = p.nq; out[3] = p.ref_lo; out[4] = p.ref_rows;
     out[5] = p.ref_bytes; out[6] = p.qry_bytes;
-    out[7] = g->exchange_route + 10 * g->self_check;   // route (0 peer copies, 1 host-staged) + 10 x self-check (0 not run, 1 passed, 2 failed)
+    out[7] = g->exchange_route + 10 * g->self_check;   // route (0 peer copies, 1 host-staged, 2 none: the graph is split by QUERY slices) + 10 x self-check (0 not run, 1 passed, 2 failed)
     return CM_OK;
 }
 

@@ -25,6 +25,7 @@ struct cm_knobs {
     bool dbg_ws = false, weights_lds = false, lowd_brute = false, no_sort = false, no_chain = false, no_centre = false, no_ivf = false,
          no_hint = false, no_perm = false, no_seed = false, no_subseed = false, no_skip3 = false,
          multi_staged = false,       // CELLMAP_MULTI_STAGED: multi-device graphs exchange their lists through host memory (the route of platforms without peer access)
+         multi_ref_shard = false,    // CELLMAP_MULTI_REF_SHARD: a multi-device graph shards the REFERENCE rows (exchange + merge) even when the reference fits one device
          multi_check_fail = false,   // CELLMAP_MULTI_CHECK_FAIL: the exchange self-check of a multi-device handle reports a mismatch (tests the fall-back)
          no_pretest = false,     // CELLMAP_NO_PRETEST: skip the structure pre-test of the staged search (always sort, gate and pilot)
          no_preload = false;     // CELLMAP_NO_PRELOAD: cm_create does not load the hot path's code objects ahead of the first call

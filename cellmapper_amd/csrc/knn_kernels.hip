@@ -17,7 +17,9 @@
 cm_status cm_p1_wide_launch(cm_handle_t h, int KP, int NW, dim3 grid, size_t lds, const float *Q, const float *R, int tps, int n_tiles,
                             int Kc, int C, int *cand, float *cthr);   // knn_phase1_inst.hip (group 3): K-chunked kernel, d >= 260
 cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
-cm_status cm_p1f16r_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);   // 16x16x32 re-tile (knn_phase1_r16.h)
+#ifdef CM_ABLATE
+cm_status cm_p1f16r_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);   // 16x16x32 re-tile (knn_phase1_r16.h): experiment builds only
+#endif
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
@@ -975,7 +977,12 @@ template <typename T, int QG, bool VEC>
 __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ ref, int64_t n_ref, const T *__restrict__ qry,
                                                        int64_t nq, int d, int k, int metric, int form, int64_t idx_offset,
                                                        int flags, int CAP, void *__restrict__ out_dist,
-                                                       int64_t *__restrict__ out_idx) {
+                                                       int64_t *__restrict__ out_idx, int k_total, int k_off,
+                                                       double *__restrict__ lb_v, int *__restrict__ lb_i, int have_lb) {
+    // k_total / k_off / lb_* (round 5: any k): a k beyond what the on-chip lists hold is served in PASSES of k entries each --
+    // this launch writes ranks [k_off, k_off + k) of rows of k_total entries, and ranks only pairs strictly after the query's
+    // lower bound (lb_v, lb_i) in the (value, index) order, i.e. after the last entry the previous pass wrote; it leaves its
+    // own last entry there for the next pass.  One pass (k_total = k, k_off = 0, no bound) is the round-4 kernel.
     constexpr int DC = xs_dc<T>(), DCP = xs_dcp<T>();
     extern __shared__ __align__(16) unsigned char xs_smem[];
     size_t xb = (size_t)CAP * 12 > xs_chunk_bytes<T>() ? (size_t)CAP * 12 : xs_chunk_bytes<T>();
@@ -1021,11 +1028,14 @@ __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ 
         __syncthreads();
     };
     const T *qa[QG], *ql[QG];
-    double xa[QG];
+    double xa[QG], lbv[QG];
+    int lbi[QG];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int gg = g < ng ? g : ng - 1;   // (a short last group repeats its last row)
         qa[g] = qry + (q0 + gg) * d; ql[g] = s_qc + g * DC; xa[g] = s_xn[gg];
+        lbv[g] = have_lb ? lb_v[q0 + gg] : -(double)INFINITY;
+        lbi[g] = have_lb ? lb_i[q0 + gg] : -1;
     }
     // the next step's rows and query columns travel to registers while the current step is evaluated
     // (16-byte pieces when every row segment is aligned -- d a multiple of 4 floats / 2 doubles: a quarter of the load and store
@@ -1104,7 +1114,7 @@ __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ 
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
                 const double v = va[g] == va[g] ? va[g] : (double)INFINITY;   // (a NaN value -- dice / sokalsneath of two all-false rows -- ranks last)
-                if (g < ng && v <= s_thr[g]) {
+                if (g < ng && v <= s_thr[g] && (!have_lb || pair_before(lbv[g], (int64_t)lbi[g], v, (int64_t)j))) {
                     const int pos = atomicAdd(&s_n[g], 1);   // (< CAP: every list entered this pass with 256 free slots)
                     s_v[(size_t)g * CAP + pos] = v;
                     s_i[(size_t)g * CAP + pos] = (int)j;
@@ -1124,10 +1134,11 @@ __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ 
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
             if ((metric == CM_METRIC_DICE || metric == CM_METRIC_SOKALSNEATH) && !(v < (double)INFINITY)) o = __longlong_as_double(0x7ff8000000000000LL);
-            if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k + rk] = (T)o;
-            else reinterpret_cast<double *>(out_dist)[io * k + rk] = o;
-            out_idx[io * k + rk] = (int64_t)s_i[(size_t)g * CAP + rk] + idx_offset;
+            if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k_total + k_off + rk] = (T)o;
+            else reinterpret_cast<double *>(out_dist)[io * k_total + k_off + rk] = o;
+            out_idx[io * k_total + k_off + rk] = (int64_t)s_i[(size_t)g * CAP + rk] + idx_offset;
         }
+        if (lb_v && tid == 0 && m > 0) { lb_v[io] = s_v[(size_t)g * CAP + m - 1]; lb_i[io] = s_i[(size_t)g * CAP + m - 1]; }
     }
 }
 
@@ -2319,7 +2330,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // Round 4: under CELLMAP_R16=1 the 128-queries-per-wave stage at K = 64 runs on the 16x16x32 MFMA shape
         // (knn_phase1_r16.h: built, exact, measured level with the 32x32x16 kernel -- profiles/r04_mfma_shape_probe.md -- and
         // therefore not the default).  Its chains are 2 instructions of 32 products each: see c_eps below.
+#ifdef CM_ABLATE
         const bool r16 = q4 && p2.KSTEPS == 4 && cm_get_knobs().r16 != 0;
+#else
+        const bool r16 = false;   // (the 16x16x32 re-tile is built by `make ABLATE=1` only)
+#endif
         const int want = level == 4 ? 2 : (level < 3 ? 1 : 0);
         const int64_t nref_pad = (int64_t)p2.n_tiles * (level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR);
         if (img != want) {
@@ -2413,7 +2428,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 y.nqb = (int)(p2.nq_pad / cmk2::QBQ);
                 const int res = h->n_cu > 0 ? h->n_cu : 256;
                 const int64_t nw = (int64_t)y.nqb * y.S;
+#ifdef CM_ABLATE
                 if (r16) return cm_p1f16r_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
+#endif
                 return cm_p1f16q_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
             }
             return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);
@@ -2806,12 +2823,23 @@ template <typename T>
 cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry, int64_t nq, int d, int k, int metric,
                        int form, int64_t idx_offset, int flags, void *d_out_dist, int64_t *d_out_idx) {
     hipStream_t st = h->stream;
-    const int CAP = exact_scan_cap(k);
+    // k beyond the on-chip lists of one query per workgroup (~4 200 entries): passes of k_pass entries (knn_exact_scan, lb_*)
+    int k_pass = k;
+    while (exact_scan_lds_bytes<T>(1, exact_scan_cap(k_pass)) > XS_LDS_MAX && k_pass > 64) k_pass = k_pass > 4096 ? 4096 : k_pass / 2;
+    if (exact_scan_lds_bytes<T>(1, exact_scan_cap(k_pass)) > XS_LDS_MAX) CM_FAIL(h, CM_E_INTERNAL, "k-NN: exact scan list sizing");
+    const int CAP = exact_scan_cap(k_pass);
     int QG = 0;
     for (int g : {4, 2, 1})
         if (exact_scan_lds_bytes<T>(g, CAP) <= (g == 1 ? XS_LDS_MAX : (size_t)80 * 1024)) { QG = g; break; }   // (two workgroups per CU while the lists allow)
-    if (!QG) CM_FAIL(h, CM_E_UNSUPPORTED, "k-NN: n_neighbors=%d too large for the exact scan's on-chip lists", k);
+    if (!QG) CM_FAIL(h, CM_E_INTERNAL, "k-NN: exact scan list sizing");
     unsigned *words = (unsigned *)cm_ws_alloc(h, 128);
+    double *lb_v = nullptr;
+    int *lb_i = nullptr;
+    if (k_pass < k) {
+        lb_v = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)std::max<int64_t>(nq, 1));
+        lb_i = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)std::max<int64_t>(nq, 1));
+        if (!lb_v || !lb_i) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+    }
     if (!words) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
     cm_mark(h, 0);
     hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words, 32);
@@ -2824,8 +2852,11 @@ cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_
         auto kern = vec ? (QG == 4 ? knn_exact_scan<T, 4, true> : (QG == 2 ? knn_exact_scan<T, 2, true> : knn_exact_scan<T, 1, true>))
                         : (QG == 4 ? knn_exact_scan<T, 4, false> : (QG == 2 ? knn_exact_scan<T, 2, false> : knn_exact_scan<T, 1, false>));
         CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QG - 1) / QG)), dim3(XS_T), lds, st, d_ref, n_ref, d_qry, nq, d, k, metric, form,
-                           idx_offset, flags, CAP, d_out_dist, d_out_idx);
+        for (int off = 0; off < k; off += k_pass) {
+            const int kp = std::min(k_pass, k - off);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + QG - 1) / QG)), dim3(XS_T), lds, st, d_ref, n_ref, d_qry, nq, d, kp, metric, form,
+                               idx_offset, flags, CAP, d_out_dist, d_out_idx, k, off, lb_v, lb_i, off > 0 ? 1 : 0);
+        }
         CM_HIP(h, hipGetLastError());
     }
     cm_mark(h, 4);

@@ -1,7 +1,11 @@
 // Instantiations + launcher of the four-accumulator hi*hi filter (knn_phase1_q4.h): its own translation unit, so that work
 // on this kernel does not recompile the rest of the split-fp16 family.
 #include "cm_internal.h"
+#ifdef CM_ABLATE   // timing experiments (scripts/build_q4_variant.sh): the copy of the kernel that carries the CM2Q_EXP / _EVMASK / _PRIO switches
+#include "../../scripts/ablate/knn_phase1_q4_ablate.h"
+#else
 #include "knn_phase1_q4.h"
+#endif
 
 template <int KSTEPS, bool DBG>
 static cm_status launch_q4(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {

@@ -180,7 +180,8 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
  *   ref [n_ref, d], qry [nq, d]  dtype CM_F32 / CM_F64 (both the same)
  *   out_dist: float64 [nq, k] for euclidean; for cosine the input dtype (sklearn keeps float32), [nq, k]
  *   out_idx : int64 [nq, k]
- * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859); k > 4200 -> CM_E_UNSUPPORTED.
+ * Errors: k > n_ref -> CM_E_INVALID (sklearn raises ValueError, neighbors/_base.py:848-859).  Any k <= n_ref is served (round 5: beyond
+ * ~4 200 the exact scan runs in passes of 4 096 ranks, each pass ranking only the pairs after the previous pass's last entry).
  * No limit on d (d <= 61: split-fp16 MFMA filter K = 64; <= 128: K = 128; beyond: f32 MFMA chunked over d -- past 2047 columns
  * the re-rank reads its query rows from global memory instead of LDS).  k beyond the filters' candidate buffers (about 190
  * on the split-fp16 paths, 350 on the f32 path): the exact scan, as for the term-wise metrics beyond 128 columns. */

@@ -19,20 +19,28 @@
 namespace cmk2 {
 
 constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumulator kernel
-// (The timing experiments of rounds 2-4 -- stages switched off one by one, the per-group event path, wave priority, the
-//  in-place 16x16x32 probe -- live in scripts/ablate/knn_phase1_q4_ablate.h, which a -DCM_ABLATE build of
-//  knn_phase1_q4_inst.hip includes instead of this file: scripts/build_q4_variant.sh.  This is the production kernel only.)
+#ifndef CM2Q_EXP
+#define CM2Q_EXP 0   // timing experiments only (scripts/ablate_q4.sh): 1 no DMA pieces, 2 no barrier, 4 no fragment reads,
+                     // 8 no min trees, 16 no threshold test, 64 thresholds at -inf (never append)
+#endif
+#ifndef CM2Q_EVMASK
+#define CM2Q_EVMASK 1   // 1: event path with the six group tests hoisted into scalar masks (A/B: profiles/r03_filter_ablation.md)
+#endif
+#ifndef CM2Q_PRIO
+#define CM2Q_PRIO 0   // wave priority while an append event is handled (s_setprio; 0 = leave it alone)
+#endif
 
 // One accumulator's event: the partial minima T0..T4 (registers 3g..3g+2) and the accumulator itself.
 #define CM2Q_EVENT(ACC, T0, T1, T2, T3, T4, J, RB)                                                             \
     {                                                                                                          \
         unsigned long long te0_ = 0;                                                                           \
+        if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(CM2Q_PRIO);   /* the event is on the path to the tile barrier */ \
         if (adbg & 4) { ++c_br; te0_ = __builtin_amdgcn_s_memtime(); }                                        \
         const float tj_ = thr[J];                                                                              \
         int cj_ = cnt[J];                                                                                      \
         const unsigned loff_ = (unsigned)((((J) * 32 + c) * 2 + hh) * CL * 8);                                 \
-        {   /* all six group tests issued back to back into scalar masks: ONE vector -> scalar hand-over instead of one  \
-               per group, then scalar-only branching (A/B against the per-group path: profiles/r03_filter_ablation.md) */ \
+        if (CM2Q_EVMASK) {   /* all six group tests issued back to back into scalar masks: ONE vector -> scalar hand-over  \
+                                instead of one per group, then scalar-only branching */                                \
             const unsigned long long g0_ = __ballot((T0) < tj_), g1_ = __ballot((T1) < tj_), g2_ = __ballot((T2) < tj_); \
             const unsigned long long g3_ = __ballot((T3) < tj_), g4_ = __ballot((T4) < tj_), g5_ = __ballot((ACC)[15] < tj_); \
             if (g0_) { CM2_APPEND_B((ACC)[0], 0, RB, loff_) CM2_APPEND_B((ACC)[1], 1, RB, loff_) CM2_APPEND_B((ACC)[2], 2, RB, loff_) } \
@@ -41,9 +49,14 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
             if (g3_) { CM2_APPEND_B((ACC)[9], 9, RB, loff_) CM2_APPEND_B((ACC)[10], 10, RB, loff_) CM2_APPEND_B((ACC)[11], 11, RB, loff_) } \
             if (g4_) { CM2_APPEND_B((ACC)[12], 12, RB, loff_) CM2_APPEND_B((ACC)[13], 13, RB, loff_) CM2_APPEND_B((ACC)[14], 14, RB, loff_) } \
             if (g5_) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                                                    \
+        } else {                                                                                               \
+        CM2_GROUP_B(ACC, T0, 0, RB, loff_) CM2_GROUP_B(ACC, T1, 1, RB, loff_) CM2_GROUP_B(ACC, T2, 2, RB, loff_) \
+        CM2_GROUP_B(ACC, T3, 3, RB, loff_) CM2_GROUP_B(ACC, T4, 4, RB, loff_)                                  \
+        if (__ballot((ACC)[15] < tj_) != 0ull) CM2_APPEND_B((ACC)[15], 15, RB, loff_)                          \
         }                                                                                                      \
         cnt[J] = cj_;                                                                                          \
         if (adbg & 4) c_evcyc += __builtin_amdgcn_s_memtime() - te0_;                                         \
+        if (CM2Q_PRIO) __builtin_amdgcn_s_setprio(0);                                                          \
     }
 
 // DBG = false is the production body: the CELLMAP_DBG modes (adbg: 1 never append, 2 skip the filter, 4 in-kernel
@@ -114,9 +127,9 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[j][s]));
-        const float thr_init = (adbg & 1) ? -INFINITY : INFINITY;
+        const float thr_init = (((adbg & 1) | (CM2Q_EXP & 64)) != 0) ? -INFINITY : INFINITY;
         float thr[NJ] = {thr_init, thr_init, thr_init, thr_init};
-        if (a.thr0) {
+        if (a.thr0 && !(CM2Q_EXP & 64)) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) thr[j] = a.thr0[qbase + j * 32 + c];
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]));
@@ -204,15 +217,26 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             float T_[5], U_[2], tot_ = INFINITY;                                                               \
             const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
             _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s) {                                               \
+                if (CM2Q_EXP & 128) {   /* timing probe: the same flops as two 16x16x32 (four 16x16 tiles x two k-steps per chain) */ \
+                    const int ta_ = (s & 1) * 2; const bool first_ = s < 2;                                          \
+                    f32x4 u0_ = {acc[j][4 * ta_], acc[j][4 * ta_ + 1], acc[j][4 * ta_ + 2], acc[j][4 * ta_ + 3]}; \
+                    f32x4 u1_ = {acc[j][4 * ta_ + 4], acc[j][4 * ta_ + 5], acc[j][4 * ta_ + 6], acc[j][4 * ta_ + 7]}; \
+                    const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};                                                    \
+                    u0_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[s], qh[j][s], first_ ? z4_ : u0_, 0, 0, 0); \
+                    u1_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(CUR[s ^ 1], qh[j][s], first_ ? z4_ : u1_, 0, 0, 0); \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { acc[j][4 * ta_ + e_] = u0_[e_]; acc[j][4 * ta_ + 4 + e_] = u1_[e_]; } \
+                } else                                                                                         \
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CUR[s], qh[j][s], s == 0 ? zero_ : acc[j], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
-                if (j == 0) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \
-                _Pragma("unroll") for (int q_ = 0; q_ < 8 / KSTEPS; ++q_)                                      \
-                    CM2Q_TREE_STEP(s * (8 / KSTEPS) + q_, acc[jp], T_, U_, tot_)                               \
-                if (j == 1 && s == 0 && (ST) < NPIECE && t + AHEAD < t1) CM2Q_DMA_PIECE(ptile_a, (t + AHEAD) % RING, (ST)); \
+                if (j == 0 && !(CM2Q_EXP & 4)) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \
+                if (!(CM2Q_EXP & 8)) { _Pragma("unroll") for (int q_ = 0; q_ < 8 / KSTEPS; ++q_)                 \
+                    CM2Q_TREE_STEP(s * (8 / KSTEPS) + q_, acc[jp], T_, U_, tot_) }                               \
+                if (!(CM2Q_EXP & 1) && j == 1 && s == 0 && (ST) < NPIECE && t + AHEAD < t1) CM2Q_DMA_PIECE(ptile_a, (t + AHEAD) % RING, (ST)); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                                  \
-            if (!(adbg & 2)) {                                                                                 \
+            if (CM2Q_EXP & 8) asm volatile("" ::"v"(acc[jp][0]), "v"(acc[jp][7]), "v"(acc[jp][15]));                \
+            else if (CM2Q_EXP & 16) asm volatile("" ::"v"(tot_));                                              \
+            if (!(adbg & 2) && !(CM2Q_EXP & 16)) {                                                            \
                 const bool pass_ = tot_ < thr[jp];                                                             \
                 if (__ballot(pass_) != 0ull) {                                                                 \
                     const int rbj_ = jp >= 2 ? rb_prev : rb_cur;                                               \
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
                 if (t + AHEAD - 1 >= t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * NPIECE) : "memory");
                 if (adbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
-                __builtin_amdgcn_s_barrier();
+                if (!(CM2Q_EXP & 2)) __builtin_amdgcn_s_barrier();
                 if (adbg & 4) c_barcyc += __builtin_amdgcn_s_memtime() - tb0_;
             }
             const unsigned tile = ldsbase + (t % RING) * TILEB;

@@ -5,7 +5,7 @@ set -e
 name=$1; flags=$2
 cd "$(dirname "$0")/../cellmapper_amd/csrc"
 mkdir -p ../../build_ab /tmp/cm_q4var
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I. -I../../include $flags -c knn_phase1_q4_inst.hip -o /tmp/cm_q4var/q4_$name.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I. -I../../include -DCM_ABLATE $flags -c knn_phase1_q4_inst.hip -o /tmp/cm_q4var/q4_$name.o
 objs=$(ls build/*.o | grep -v knn_phase1_q4_inst.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o ../../build_ab/lib_$name.so $objs /tmp/cm_q4var/q4_$name.o
 echo built build_ab/lib_$name.so

@@ -9,6 +9,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _choreography(request, monkeypatch):
+    """Round 5: a multi-device graph splits the QUERIES by default (the reference replicated: no exchange).  The tests of this
+    file that were written for the reference-sharded choreography -- exchange, self-check, strided merge -- keep exercising
+    it under CELLMAP_MULTI_REF_SHARD=1; tests with `query_slices` in their name run the default."""
+    from cellmapper_amd import _native
+
+    if "query_slices" not in request.node.name:
+        monkeypatch.setenv("CELLMAP_MULTI_REF_SHARD", "1")
+    _native.reload_knobs()
+    yield
+    monkeypatch.delenv("CELLMAP_MULTI_REF_SHARD", raising=False)
+    _native.reload_knobs()
+
+
 @pytest.fixture(scope="module")
 def problem():
     rng = np.random.default_rng(11)
@@ -240,3 +255,49 @@ def test_all_false_rows_rank_last_through_the_sharded_merge(metric, oracle):
         assert np.array_equal(idx[uniq], oi[uniq])
     assert np.array_equal(dm[::7][:, 0], d1[::7][:, 0]) and not np.isnan(dm[::7][:, 0]).any()   # an all-false query's nearest is a number
     g.close(); xr.close(); yr.close(); h1.close(); hm.close()
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_default_multi_device_graph_is_split_by_query_slices(problem, ndev, oracle):
+    """The default of a multi-device handle (round 5): every device holds the whole reference and ITS query slice, searches on its
+    own and owns that slice of the graph -- no exchange, no merge; float32 cosine and large k spread over all devices too.
+    Results: the single-device bits."""
+    from cellmapper_amd import _native
+
+    ref, qry = problem
+    k, n_cat = 15, 9
+    codes = np.random.default_rng(3).integers(0, n_cat, ref.shape[0]).astype(np.int32)
+    h1, hm = _native.Handle(0), _native.Handle(devices=[0] * ndev)
+    xr, yr = _native.DeviceRep(hm, ref), _native.DeviceRep(hm, qry)
+    g = _native.DeviceGraph(hm, xr, yr, k)
+    parts = g.parts()
+    rb, qb = ref.shape[1] * 4, qry.shape[1] * 4
+    assert len(parts) == ndev and all(p["exchange"] == "none (query slices)" and p["self_check"] == "not run" for p in parts), parts
+    assert all(p["ref_lo"] == 0 and p["ref_rows"] == ref.shape[0] and p["ref_bytes"] == ref.shape[0] * rb for p in parts)
+    assert sum(p["nq"] for p in parts) == qry.shape[0] and [p["q_lo"] for p in parts] == list(np.cumsum([0] + [p["nq"] for p in parts[:-1]]))
+    assert parts[0]["qry_bytes"] == qry.shape[0] * qb and all(p["qry_bytes"] == p["nq"] * qb for p in parts[1:])   # peers: their slice only
+    dist, idx = g.fetch_knn()
+    o = oracle.run_path(ref, qry, k, labels=codes, n_cat=n_cat)
+    assert np.array_equal(idx, o["idx"]) and np.array_equal(dist, o["dist"])
+    assert idx[5, 0] == 17 and idx[5, 1] == 15000
+    g.mapping("gaussian")
+    code, conf = g.label_vote(codes, n_cat)
+    assert (code == o["pred_code"]).mean() > 0.9995
+    np.testing.assert_allclose(conf, o["conf"], rtol=1e-5)
+    # float32 cosine and k = 400 (beyond the merge's 768 / parts entries): all devices, one-device arithmetic per query
+    for kk, metric in ((12, "cosine"), (400, "euclidean")):
+        gm = _native.DeviceGraph(hm, xr, yr, kk, metric)
+        assert gm.n_devices == ndev
+        dm, im = gm.fetch_knn()
+        d1, i1 = h1.knn(ref, qry, kk, metric=metric)
+        assert np.array_equal(im, i1) and np.array_equal(dm, d1)
+        gm.close()
+    gs = _native.DeviceGraph(hm, xr, xr, k)      # a self-join: the query slice is a window of the replicated reference
+    ds, is_ = gs.fetch_knn()
+    os_ = oracle.knn_euclidean(ref, ref[:300], k)
+    assert np.array_equal(is_[:300], os_[1]) and np.array_equal(ds[:300], os_[0])
+    small = _native.DeviceGraph(hm, xr, _native.DeviceRep(hm, qry[:700]), k)   # fewer than 512 queries per device: fewer devices
+    assert small.n_devices == 1
+    for x in (g, gs, small):
+        x.close()
+    xr.close(); yr.close(); h1.close(); hm.close()
