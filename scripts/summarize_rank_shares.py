@@ -49,7 +49,7 @@ out += ["",
         "* Shares below 0.30 of the f16 peak are exactly the ones with a quarter or less of the reference per rank (q1xr4, q2xr4, q4xr2, q1xr8):",
         "  what the table names is the per-(query, shard) overhead, and the fix is not to create those shards when the reference fits.  Inside the",
         "  search the partition model already picks the kernel and the split count per shape (column 5); the K = 128 family got the same model this",
-        "  round (`profiles/r05_kernel_stats_d128.md`).",
+        "  round (`profiles/r05_d128_pruning.md`).",
         "* The merge of R lists is rank-by-counting over R k entries: 0.9 / 2.7 / 4.6 ms for 2 / 4 / 8 lists of 1.5 M / R ... queries -- 7 % of the",
         "  step in the worst layout (q1xr8), nothing in the default one.",
         "",
