@@ -14,4 +14,3 @@ done
 unset CELLMAP_XFER
 timeout -k 10 400 python scripts/prof_host_api.py > $O/prof_host_api.log 2>&1; grep "^{" $O/prof_host_api.log
 bash scripts/profile_r5.sh > $O/profile_r5.log 2>&1; tail -5 $O/profile_r5.log
-bash scripts/fuzz_r5.sh
