@@ -11,6 +11,7 @@ import numpy as np
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wide", action="store_true", help="round 5: bias the draw towards the K = 128 family's pruned stages (62 <= d <= 128, clustered, >= 66 000 queries)")
     a = ap.parse_args()
     import torch
     from cellmapper_amd import _native
@@ -28,6 +29,13 @@ def main():
         dt = torch.float64 if rng.random() < 0.25 else torch.float32
         ncl = int(rng.choice([0, 0, 8, 40, 200]))
         sigma = float(rng.choice([0.05, 0.3, 1.0, 2.0]))
+        if a.wide:
+            d = int(rng.choice([62, 64, 72, 90, 100, 111, 128]))
+            n_ref = int(rng.choice([131_072, 200_000, 300_000, 500_000]))
+            nq = int(rng.choice([66_000, 100_000, 131_072, 200_000, 300_000]))
+            ncl = int(rng.choice([8, 40, 40, 200]))
+            sigma = float(rng.choice([0.05, 0.3, 0.6, 1.0]))
+            k = int(rng.choice([1, 10, 30, 50, 100]))
         def mk(n):
             x = torch.randn((n, d), generator=g, device=pipe.device, dtype=torch.float32)
             if ncl:
