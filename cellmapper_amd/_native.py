@@ -25,9 +25,12 @@ CM_F32, CM_F64 = 0, 1
 METRICS = {"euclidean": 0, "l2": 0, "minkowski": 0, "cosine": 1, "manhattan": 2, "cityblock": 2, "l1": 2, "chebyshev": 3, "infinity": 3, "sqeuclidean": 4, "correlation": 5,
            "canberra": 6, "braycurtis": 7,
            # the counting metrics sklearn takes without parameters (scipy cdist on boolean copies / DistanceMetric on a ball tree)
-           "hamming": 8, "jaccard": 9, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13, "sokalsneath": 14, "yule": 15}
+           "hamming": 8, "jaccard": 9, "dice": 10, "rogerstanimoto": 11, "russellrao": 12, "sokalmichener": 13, "sokalsneath": 14, "yule": 15,
+           # round 5: (latitude, longitude) rows in radians; NaN = missing coordinate
+           "haversine": 16, "nan_euclidean": 17}
+CM_REP_ALLOW_NAN = 1
 SUPPORTED_METRICS_TEXT = ("euclidean / l2 / minkowski (p = 2), sqeuclidean, cosine, correlation, manhattan / cityblock / l1, chebyshev / infinity, "
-                          "canberra, braycurtis, hamming, jaccard, dice, rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule")
+                          "canberra, braycurtis, hamming, jaccard, dice, rogerstanimoto, russellrao, sokalmichener, sokalsneath, yule, haversine, nan_euclidean")
 FORMS = {"auto": 0, "gemm": 1, "direct": 2}
 KERNELS = {"gaussian": 0, "scarches": 1, "inverse_distance": 2, "equal": 3, "_identity": 4}
 CM_KNN_SQUARED, CM_KNN_FORCE_FALLBACK, CM_KNN_F64_OUT = 1, 2, 4
@@ -44,7 +47,7 @@ EXPORTS = [
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
     "cm_set_profiling", "cm_stage_times", "cm_shared_neighbors", "cm_presence_scores", "cm_debug_mfma_f16", "cm_debug_mfma_f16_k32", "cm_graph_part_info",
     "cm_ingest_distances", "cm_expression_metrics", "cm_expression_metrics_dev",
-    "cm_rep_create", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
+    "cm_rep_create", "cm_rep_create_ex", "cm_rep_destroy", "cm_graph_knn", "cm_graph_destroy", "cm_graph_info", "cm_graph_knn_fetch",
     "cm_graph_mapping", "cm_graph_mapping_fetch", "cm_graph_label_vote", "cm_graph_spmm_dense", "cm_graph_spmm_csr_nnz",
     "cm_graph_spmm_csr", "cm_gram", "cm_project",
 ]
@@ -113,6 +116,7 @@ def load_library():
         lib.cm_debug_mfma_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         lib.cm_debug_mfma_f16_k32.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         lib.cm_rep_create.argtypes = [vp, vp, i64, i32, i32, C.POINTER(vp)]
+        lib.cm_rep_create_ex.argtypes = [vp, vp, i64, i32, i32, i32, C.POINTER(vp)]
         lib.cm_rep_destroy.argtypes = [vp, vp]
         lib.cm_graph_knn.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
         lib.cm_graph_destroy.argtypes = [vp, vp]
@@ -267,6 +271,8 @@ class Handle:
         idx = np.empty((nq, k), np.int64)
         self.call("cm_knn", _ptr(ref), n_ref, _ptr(qry), nq, d, CM_F64 if dt == np.float64 else CM_F32, k,
                   METRICS[metric], FORMS[form], _ptr(dist), _ptr(idx))
+        if metric == "nan_euclidean" and dt == np.float32:
+            dist = dist.astype(np.float32)   # (sklearn returns float32 for float32 data; the library's float64 values are float32-rounded already)
         return dist, idx
 
     def mapping_matrix(self, dist, idx, n_ref: int, kernel: str = "gaussian", epsilon: float = 1e-8, want_conn=False):
@@ -449,7 +455,9 @@ class Handle:
 class DeviceRep:
     """An embedding matrix uploaded once (``cm_rep_create``): ``xrep`` / ``yrep`` of ``Neighbors``."""
 
-    def __init__(self, handle: Handle, X: np.ndarray):
+    def __init__(self, handle: Handle, X: np.ndarray, allow_nan: bool = False):
+        """``allow_nan``: NaN entries are kept as missing coordinates (``cm_rep_create_ex`` with CM_REP_ALLOW_NAN) -- what sklearn
+        allows under ``metric="nan_euclidean"`` only; any other metric over such a representation raises like a plain upload."""
         X = np.ascontiguousarray(X)
         if X.ndim != 2:
             raise ValueError(f"Representation must be 2-D (got shape {X.shape}).")
@@ -458,7 +466,8 @@ class DeviceRep:
         # (NaN / infinity: screened by cm_rep_create on the device copy -> ValueError; numpy's isfinite cost more than the upload)
         self.h, self.shape, self.dtype = handle, X.shape, X.dtype
         r = C.c_void_p()
-        handle.call("cm_rep_create", _ptr(X), X.shape[0], X.shape[1], CM_F64 if X.dtype == np.float64 else CM_F32, C.byref(r))
+        handle.call("cm_rep_create_ex", _ptr(X), X.shape[0], X.shape[1], CM_F64 if X.dtype == np.float64 else CM_F32,
+                    CM_REP_ALLOW_NAN if allow_nan else 0, C.byref(r))
         self._r = r
 
     def close(self):
@@ -489,6 +498,7 @@ class DeviceGraph:
         self._g = g
         self.nq, self.n_ref, self.k = qry.shape[0], ref.shape[0], int(k)
         self.dist_dtype = np.float32 if (METRICS[metric] == 1 and ref.dtype == np.float32) else np.float64
+        self._cast_f32 = metric == "nan_euclidean" and ref.dtype == np.float32   # (sklearn returns float32 there; resident values are float64)
         self.nnz = None
         self.param = None
         self.map_tag = None
@@ -527,6 +537,8 @@ class DeviceGraph:
         dist = np.empty((self.nq, self.k), self.dist_dtype)
         idx = np.empty((self.nq, self.k), np.int64)
         self.h.call("cm_graph_knn_fetch", self._g, _ptr(dist), _ptr(idx))
+        if getattr(self, "_cast_f32", False):
+            dist = dist.astype(np.float32)
         return dist, idx
 
     def mapping(self, kernel: str = "gaussian", epsilon: float = 1e-8):

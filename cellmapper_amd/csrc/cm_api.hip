@@ -349,18 +349,21 @@ size_t device_budget(cm_handle_t h, long long knob_mb) {
 // numpy's single-threaded isfinite over the host array (17 ms per 300 MB: it was a third of the host-tier overhead).
 __global__ __launch_bounds__(256) void nonfinite_flag(const uint4 *__restrict__ x, size_t n16, const unsigned char *__restrict__ tail,
                                                       int n_tail_elems, int is_f64, int *__restrict__ flag) {
-    bool bad = false;
+    // verdict bits: 1 = an infinity, 2 = a NaN (round 5: CM_METRIC_NAN_EUCLIDEAN accepts NaN as "missing", nothing accepts infinities)
+    bool inf = false, nan = false;
+    auto f32 = [&](unsigned w) { if ((w & 0x7f800000u) == 0x7f800000u) { if (w & 0x007fffffu) nan = true; else inf = true; } };
+    auto f64 = [&](unsigned lo, unsigned hi) { if ((hi & 0x7ff00000u) == 0x7ff00000u) { if ((hi & 0x000fffffu) | lo) nan = true; else inf = true; } };
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 v = x[i];
-        if (is_f64) bad |= ((v.y & 0x7ff00000u) == 0x7ff00000u) | ((v.w & 0x7ff00000u) == 0x7ff00000u);
-        else bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
-                    ((v.w & 0x7f800000u) == 0x7f800000u);
+        if (is_f64) { f64(v.x, v.y); f64(v.z, v.w); }
+        else { f32(v.x); f32(v.y); f32(v.z); f32(v.w); }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail_elems) {   // the last < 16 bytes
-        if (is_f64) bad |= (reinterpret_cast<const uint2 *>(tail)[threadIdx.x].y & 0x7ff00000u) == 0x7ff00000u;
-        else bad |= (reinterpret_cast<const unsigned *>(tail)[threadIdx.x] & 0x7f800000u) == 0x7f800000u;
+        if (is_f64) { const uint2 w = reinterpret_cast<const uint2 *>(tail)[threadIdx.x]; f64(w.x, w.y); }
+        else f32(reinterpret_cast<const unsigned *>(tail)[threadIdx.x]);
     }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    const int bits = (__ballot(inf) != 0ull ? 1 : 0) | (__ballot(nan) != 0ull ? 2 : 0);
+    if (bits && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
 }
 // enqueue the screen of `bytes` of device memory at d_x (16-byte aligned) on the handle's stream; the verdict lands in
 // pinned word `slot` of the handle (read it after the next synchronisation)
@@ -377,6 +380,7 @@ cm_status nonfinite_enqueue(cm_handle_t h, const void *d_x, size_t bytes, int dt
     return CM_OK;
 }
 #define CM_NONFINITE_MSG "Input contains NaN or infinity."
+#define CM_INF_MSG "Input contains infinity or a value too large."
 
 // param for the graph kernel from the distances (device), honouring the reference's global statistics
 cm_status kernel_param_dev(cm_handle_t h, const double *d_dist, const int64_t *d_idx, int64_t n, int kernel, double *d_m3,
@@ -769,8 +773,9 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     if (!h->peers.empty()) {   // multi-device handle: the graph tier shards the reference rows over the devices (falls back to one by itself)
         cm_rep_t r = nullptr, q = nullptr;
         cm_graph_t g = nullptr;
-        cm_status rc = cm_rep_create(h, ref, n_ref, d, dtype, &r);
-        if (rc == CM_OK) rc = cm_rep_create(h, qry, nq, d, dtype, &q);
+        const int32_t rflags = metric == CM_METRIC_NAN_EUCLIDEAN ? CM_REP_ALLOW_NAN : 0;
+        cm_status rc = cm_rep_create_ex(h, ref, n_ref, d, dtype, rflags, &r);
+        if (rc == CM_OK) rc = cm_rep_create_ex(h, qry, nq, d, dtype, rflags, &q);
         if (rc == CM_OK) rc = cm_graph_knn(h, r, q, k, metric, form, &g);
         if (rc == CM_OK) rc = cm_graph_knn_fetch(h, g, out_dist, out_idx);
         const std::string keep = h->err;
@@ -798,7 +803,7 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
     CM_TRY(nonfinite_enqueue(h, dref.p, es * n_ref * d, dtype, dflag.as<int>(), 12));
     if (nq == 0) {   // no query chunk will read the reference's verdict: read it here (sklearn's check_array rejects the fit data before any query)
         CM_TRY(sync(h));
-        if (h->d_nflag_pinned[12]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
+        if (h->d_nflag_pinned[12] & (metric == CM_METRIC_NAN_EUCLIDEAN ? 1 : 3)) CM_FAIL(h, CM_E_INVALID, metric == CM_METRIC_NAN_EUCLIDEAN ? CM_INF_MSG : CM_NONFINITE_MSG);
     }
     int64_t nflag = 0;
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
@@ -807,7 +812,8 @@ cm_status cm_knn(cm_handle_t h, const void *ref, int64_t n_ref, const void *qry,
         CM_TRY(h2d(h, dq.p, (const char *)qry + es * q0 * d, es * nqc * d));
         CM_TRY(nonfinite_enqueue(h, dq.p, es * nqc * d, dtype, dflag.as<int>() + 1, 13));
         CM_TRY(sync(h));
-        if (h->d_nflag_pinned[12] || h->d_nflag_pinned[13]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
+        if ((h->d_nflag_pinned[12] | h->d_nflag_pinned[13]) & (metric == CM_METRIC_NAN_EUCLIDEAN ? 1 : 3))
+            CM_FAIL(h, CM_E_INVALID, metric == CM_METRIC_NAN_EUCLIDEAN ? CM_INF_MSG : CM_NONFINITE_MSG);
         CM_TRY(cm_knn_run(h, dref.p, n_ref, dq.p, nqc, d, dtype, k, metric, form, 0, 0, dd.p, di.as<int64_t>()));
         CM_TRY(d2h(h, (char *)out_dist + des * q0 * k, dd.p, des * nqc * k));
         CM_TRY(d2h(h, out_idx + q0 * k, di.p, 8 * (size_t)nqc * k));
@@ -1198,6 +1204,7 @@ struct cm_rep_s {
     std::vector<int64_t> lo, rows;
     int64_t n = 0;
     int32_t d = 0, dtype = 0;
+    bool has_nan = false;   // uploaded with CM_REP_ALLOW_NAN and holds at least one NaN: only CM_METRIC_NAN_EUCLIDEAN may search it
     size_t row_bytes() const { return (size_t)d * (dtype == CM_F64 ? 8 : 4); }
 };
 struct GraphPart {
@@ -1353,6 +1360,10 @@ cm_status cm_create_multi(const int *devices, int n, cm_handle_t *out) {
 }
 
 cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, cm_rep_t *out) {
+    return cm_rep_create_ex(h, X, n, d, dtype, 0, out);
+}
+
+cm_status cm_rep_create_ex(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, int32_t flags, cm_rep_t *out) {
     if (!h) return CM_E_INVALID;
     if (!out || !X || n < 1 || d < 1 || (dtype != CM_F32 && dtype != CM_F64)) CM_FAIL(h, CM_E_INVALID, "rep: bad arguments");
     cm_rep_s *r = new (std::nothrow) cm_rep_s();
@@ -1373,7 +1384,11 @@ cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int3
         h->d_nflag_pinned[12] = 0;
         CM_TRY(nonfinite_enqueue(h, r->bufs[0].p, bytes, dtype, d_flag, 12));
         CM_TRY(sync(h));
-        if (h->d_nflag_pinned[12]) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
+        const int verdict = h->d_nflag_pinned[12];
+        if (flags & CM_REP_ALLOW_NAN) {
+            if (verdict & 1) CM_FAIL(h, CM_E_INVALID, CM_INF_MSG);
+            r->has_nan = (verdict & 2) != 0;
+        } else if (verdict) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
         return CM_OK;
     }();
     if (rc != CM_OK) {
@@ -1455,6 +1470,7 @@ cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int
     if (!h) return CM_E_INVALID;
     if (!ref || !qry || !out) CM_FAIL(h, CM_E_INVALID, "graph: bad arguments");
     if (ref->d != qry->d || ref->dtype != qry->dtype) CM_FAIL(h, CM_E_INVALID, "graph: the two representations differ in width or dtype");
+    if ((ref->has_nan || qry->has_nan) && metric != CM_METRIC_NAN_EUCLIDEAN) CM_FAIL(h, CM_E_INVALID, CM_NONFINITE_MSG);
     if (k < 1 || k > ref->n)
         CM_FAIL(h, CM_E_INVALID, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k, (long long)ref->n);
     cm_graph_s *g = new (std::nothrow) cm_graph_s();

@@ -413,6 +413,16 @@ struct PairAcc {
                 } else if constexpr (MODE == 1) {
                     const double t = (double)qv - (double)yv;
                     a[g] = __dadd_rn(a[g], __dmul_rn(t, t));
+                } else if constexpr (MODE == 8) {   // haversine: column 0 = latitude, 1 = longitude (HaversineDistance.rdist)
+                    double df;
+                    if constexpr (F32) df = (double)__fsub_rn((float)qv, (float)yv);
+                    else df = (double)qv - (double)yv;
+                    const double sh = sin(__dmul_rn(0.5, df));
+                    if (c0 + i == 0) { a[g] = __dmul_rn(sh, sh); b[g] = __dmul_rn(cos((double)qv), cos((double)yv)); }
+                    else if (c0 + i == 1) c[g] = sh;
+                } else if constexpr (MODE == 9) {   // nan_euclidean: coordinates present (not NaN) in both rows
+                    const double qd = (double)qv, yd = (double)yv;
+                    if (qd == qd && yd == yd) { const double t = qd - yd; a[g] = __dadd_rn(a[g], __dmul_rn(t, t)); b[g] += 1.0; }
                 } else {
                     double t;
                     if constexpr (F32) t = (double)fabsf(__fsub_rn((float)qv, (float)yv));
@@ -450,6 +460,8 @@ struct PairAcc {
             case CM_METRIC_CANBERRA: if (f32) run_mode<4, true, UNR>(q, c0, n, yat); else run_mode<4, false, UNR>(q, c0, n, yat); return;
             case CM_METRIC_BRAYCURTIS: if (f32) run_mode<5, true, UNR>(q, c0, n, yat); else run_mode<5, false, UNR>(q, c0, n, yat); return;
             case CM_METRIC_HAMMING: run_mode<6, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_HAVERSINE: if (f32) run_mode<8, true, UNR>(q, c0, n, yat); else run_mode<8, false, UNR>(q, c0, n, yat); return;
+            case CM_METRIC_NAN_EUCLIDEAN: run_mode<9, false, UNR>(q, c0, n, yat); return;
             case CM_METRIC_JACCARD: case CM_METRIC_DICE: case CM_METRIC_ROGERSTANIMOTO: case CM_METRIC_RUSSELLRAO:
             case CM_METRIC_SOKALMICHENER: case CM_METRIC_SOKALSNEATH: case CM_METRIC_YULE: run_mode<7, false, UNR>(q, c0, n, yat); return;
             default: break;
@@ -462,7 +474,18 @@ struct PairAcc {
         const bool f32 = sizeof(T) == 4 && form != CM_FORM_DIRECT;
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
-            if (metric >= CM_METRIC_HAMMING) {
+            if (metric == CM_METRIC_HAVERSINE) {
+                // sin_0 * sin_0 + cos(x0) * cos(y0) * sin_1 * sin_1, evaluated left to right as the C source is; brute force on
+                // float32 data (HaversineDistance32.rdist returns its INPUT dtype) rounds the bracket to float32 before the
+                // conversion 2 asin(sqrt(.)) -- which ArgKmin applies in float64 at the end, on either path
+                double r = __dadd_rn(a[g], __dmul_rn(__dmul_rn(b[g], c[g]), c[g]));
+                if (f32) r = (double)(float)r;
+                out[g] = __dmul_rn(2.0, asin(sqrt(r)));
+            } else if (metric == CM_METRIC_NAN_EUCLIDEAN) {
+                // nan_euclidean_distances: clip at 0, / #present, * d, sqrt; no shared coordinate: NaN.  float32 data: float32 out
+                const double r = b[g] > 0.0 ? sqrt(__dmul_rn(__ddiv_rn(a[g], b[g]), (double)d)) : __longlong_as_double(0x7ff8000000000000LL);
+                out[g] = sizeof(T) == 4 ? (double)(float)r : r;
+            } else if (metric >= CM_METRIC_HAMMING) {
                 // scipy's cdist kernels (spatial/src/distance_impl.h) and sklearn's DistanceMetric classes: one float64 division
                 // of exact integer counts
                 const double n = (double)d, ntt = a[g], ntf = b[g], nft = c[g], R = ntf + nft, nff = n - ntt - R;
@@ -1133,7 +1156,7 @@ __global__ __launch_bounds__(XS_T, 2) void knn_exact_scan(const T *__restrict__ 
             const double v = s_v[(size_t)g * CAP + rk];
             double o = v;
             if (metric == CM_METRIC_EUCLIDEAN && !(flags & CM_KNN_SQUARED)) o = sqrt(v);
-            if ((metric == CM_METRIC_DICE || metric == CM_METRIC_SOKALSNEATH) && !(v < (double)INFINITY)) o = __longlong_as_double(0x7ff8000000000000LL);
+            if ((metric == CM_METRIC_DICE || metric == CM_METRIC_SOKALSNEATH || metric == CM_METRIC_NAN_EUCLIDEAN) && !(v < (double)INFINITY)) o = __longlong_as_double(0x7ff8000000000000LL);
             if (metric == CM_METRIC_COSINE && !(flags & CM_KNN_F64_OUT)) reinterpret_cast<T *>(out_dist)[io * k_total + k_off + rk] = (T)o;
             else reinterpret_cast<double *>(out_dist)[io * k_total + k_off + rk] = o;
             out_idx[io * k_total + k_off + rk] = (int64_t)s_i[(size_t)g * CAP + rk] + idx_offset;
@@ -3058,7 +3081,8 @@ cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void
         flags |= CM_KNN_SQUARED;
     }
     const bool ratio_metric = metric == CM_METRIC_CANBERRA || metric == CM_METRIC_BRAYCURTIS;
-    const bool count_metric = metric >= CM_METRIC_HAMMING && metric <= CM_METRIC_YULE;
+    const bool count_metric = metric >= CM_METRIC_HAMMING && metric <= CM_METRIC_NAN_EUCLIDEAN;   // (every metric of the exact scan: the counts, haversine, nan_euclidean)
+    if (metric == CM_METRIC_HAVERSINE && d != 2) CM_FAIL(h, CM_E_INVALID, "Haversine distance only valid in 2 dimensions");
     if (metric != CM_METRIC_EUCLIDEAN && metric != CM_METRIC_COSINE && metric != CM_METRIC_MANHATTAN && metric != CM_METRIC_CHEBYSHEV && !ratio_metric && !count_metric)
         CM_FAIL(h, CM_E_INVALID, "k-NN: unknown metric id %d", metric);
     if (ratio_metric && (dtype == CM_F32 || dtype == CM_F64) && nq > 0 && !needs_exact_scan(n_ref, nq, d, k, metric)) {

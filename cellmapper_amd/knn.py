@@ -200,7 +200,7 @@ class Neighbors:
         h = _native.default_handle()
         if metric not in _native.METRICS:
             raise ValueError(f"Metric '{metric}' is not supported by the hip backend (supported: {_native.SUPPORTED_METRICS_TEXT}).")
-        if _native.METRICS[metric] >= 9 and (self.xrep.dtype != bool or self.yrep.dtype != bool):
+        if 9 <= _native.METRICS[metric] <= 15 and (self.xrep.dtype != bool or self.yrep.dtype != bool):
             # the boolean metrics read `x != 0`; sklearn says so (metrics/pairwise.py: DataConversionWarning, a UserWarning)
             import warnings
             warnings.warn(f"Data was converted to boolean for metric {metric}", UserWarning, stacklevel=2)
@@ -208,8 +208,9 @@ class Neighbors:
         # both representations go to the device ONCE (same dtype rule as the host tier: float32 only if both are);
         # the results stay there (NeighborsResults materialises numpy arrays on first access)
         dt = np.float32 if (self.xrep.dtype == np.float32 and self.yrep.dtype == np.float32) else np.float64
-        xr = _native.DeviceRep(h, np.asarray(self.xrep).astype(dt, copy=False))
-        yr = xr if self.yrep is self.xrep else _native.DeviceRep(h, np.asarray(self.yrep).astype(dt, copy=False))
+        nan_ok = metric == "nan_euclidean"   # (sklearn validates with ensure_all_finite="allow-nan" under this metric only)
+        xr = _native.DeviceRep(h, np.asarray(self.xrep).astype(dt, copy=False), allow_nan=nan_ok)
+        yr = xr if self.yrep is self.xrep else _native.DeviceRep(h, np.asarray(self.yrep).astype(dt, copy=False), allow_nan=nan_ok)
         try:
             self.yx = NeighborsResults(n_targets=nx, _graph=_native.DeviceGraph(h, xr, yr, n_neighbors, metric))
             if only_yx:

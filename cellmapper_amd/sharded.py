@@ -210,7 +210,8 @@ def make_groups(dist_mod, world: int, n_groups: int, ref_shards: int, exchange: 
 
 
 SUPPORTED_METRICS = ("euclidean", "sqeuclidean", "cosine", "correlation", "manhattan", "chebyshev", "canberra", "braycurtis",
-                     "hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
+                     "hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule", "haversine",
+                     "nan_euclidean")
 
 
 class ExchangeState:

@@ -94,6 +94,20 @@ typedef enum {
 #define CM_METRIC_SOKALMICHENER 13
 #define CM_METRIC_SOKALSNEATH 14
 #define CM_METRIC_YULE 15
+/* Round 5: the last two metric names the reference can hand to sklearn without parameters.  Both run the exact scan; both are
+ * compared with the reference at a STATED tolerance, not bit for bit (tests/parity.py): their upstream values come out of libm /
+ * numpy transcendental functions and of BLAS products, whose last bits no device restatement reproduces.
+ *   haversine     rows are (latitude, longitude) in radians, d = 2 only (else CM_E_INVALID: sklearn's ValueError):
+ *                 2 asin(sqrt(sin^2((x0 - y0) / 2) + cos(x0) cos(y0) sin^2((x1 - y1) / 2))) -- sklearn's HaversineDistance.dist in float64
+ *                 on the ball tree (k < n_ref / 2); ArgKmin brute force otherwise, which ranks by the bracket (rounded to float32, the
+ *                 difference taken in float32, for float32 data: HaversineDistance32.rdist) and converts it at the end; float64 out.
+ *   nan_euclidean sklearn.metrics.pairwise.nan_euclidean_distances (brute force at every width): NaN marks a missing coordinate;
+ *                 sqrt(d / #present * sum over the coordinates present in BOTH rows of (x_j - y_j)^2), NaN when no coordinate is shared
+ *                 (such a pair ranks last); float32 out for float32 data.  The only metric whose inputs may hold NaN: upload them
+ *                 with cm_rep_create_ex(..., CM_REP_ALLOW_NAN) (cm_knn allows them by itself under this metric); infinities are
+ *                 refused as everywhere. */
+#define CM_METRIC_HAVERSINE 16
+#define CM_METRIC_NAN_EUCLIDEAN 17
 /* which exact float64 formula the returned distances follow (see DESIGN.md "K0"):
  *   AUTO   = what sklearn's algorithm="auto" would pick: GEMM form if d > 15 or k >= n_ref/2, else DIRECT
  *   GEMM   = sklearn brute / EuclideanArgKmin: (|q|^2 + (-2 q.y)) + |y|^2, clamp, sqrt
@@ -336,6 +350,11 @@ cm_status cm_payload_index_dev(cm_handle_t h, const int64_t *d_b_indptr, const i
 typedef struct cm_rep_s *cm_rep_t;
 typedef struct cm_graph_s *cm_graph_t;
 cm_status cm_rep_create(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, cm_rep_t *out);
+/* cm_rep_create with flags.  CM_REP_ALLOW_NAN: NaN entries are kept (missing coordinates of CM_METRIC_NAN_EUCLIDEAN: sklearn validates
+ * with ensure_all_finite="allow-nan" under that metric only, neighbors/_base.py); a graph of any other metric over a representation
+ * that holds a NaN fails with CM_E_INVALID like an upload without the flag.  Infinities are always refused. */
+#define CM_REP_ALLOW_NAN 1
+cm_status cm_rep_create_ex(cm_handle_t h, const void *X, int64_t n, int32_t d, int32_t dtype, int32_t flags, cm_rep_t *out);
 cm_status cm_rep_destroy(cm_handle_t h, cm_rep_t r);
 /* K0 (knn.py:428-440): same arguments and errors as cm_knn */
 cm_status cm_graph_knn(cm_handle_t h, cm_rep_t ref, cm_rep_t qry, int32_t k, int32_t metric, int32_t form, cm_graph_t *out);

@@ -267,6 +267,19 @@ def main():
         yb = (rb_.random((150, 40)) < 0.33).astype(np.float32) * rb_.uniform(0.5, 3.0, (150, 40)).astype(np.float32)
         xh = rb_.integers(0, 3, (1200, 40)).astype(np.float32)
         yh = rb_.integers(0, 3, (150, 40)).astype(np.float32)
+        rl_ = np.random.default_rng(26)
+        ll64 = np.c_[rl_.uniform(-np.pi / 2, np.pi / 2, 1400), rl_.uniform(-np.pi, np.pi, 1400)]
+        lq64 = np.c_[rl_.uniform(-np.pi / 2, np.pi / 2, 120), rl_.uniform(-np.pi, np.pi, 120)]
+        lq64[:10] = ll64[:10] + 1e-4          # near neighbours: tiny angles
+        lq64[10] = ll64[700]                  # an exact hit
+        rn_ = np.random.default_rng(27)
+        xn32, yn32 = synth_(28, 1200, 150, 30, np.float32)
+        xn32[rn_.random(xn32.shape) < 0.06] = np.nan
+        yn32[rn_.random(yn32.shape) < 0.06] = np.nan
+        xn10, yn10 = synth_(29, 900, 90, 10, np.float32)
+        xn10[rn_.random(xn10.shape) < 0.15] = np.nan
+        yn10[rn_.random(yn10.shape) < 0.15] = np.nan
+        yn10[3, :] = np.nan                   # a query with no coordinate at all: every distance NaN
         cases = {
             "synth_f32_manhattan_k15": (xr, yr, 15, "manhattan", "X_emb"),
             "synth_f64_manhattan_k30": (xr64, yr64, 30, "manhattan", "X_emb"),
@@ -306,12 +319,24 @@ def main():
             "bin40_yule_k15": (xb, yb, 15, "yule", "X_emb"),
             # (no d = 10 case for yule: no tree has the metric -- brute force at every width -- and at ten columns most of the k
             #  nearest distances are exactly 0, which the reference's gaussian kernel turns into NaN weights)
+            # round 5: haversine (latitude, longitude in radians; two columns only).  sklearn: ball_tree on float64 copies when
+            # k < n_ref / 2, ArgKmin brute force over HaversineDistance / HaversineDistance32 otherwise
+            "latlon64_haversine_k12": (ll64, lq64, 12, "haversine", "spatial"),
+            "latlon32_haversine_k12": (ll64.astype(np.float32), lq64.astype(np.float32), 12, "haversine", "spatial"),
+            "latlon64_haversine_brute_k40": (ll64[:64].copy(), lq64[:32].copy(), 40, "haversine", "spatial", 4),
+            "latlon32_haversine_brute_k40": (ll64[:64].astype(np.float32), lq64[:32].astype(np.float32), 40, "haversine", "spatial", 4),
+            # round 5: nan_euclidean (sklearn.metrics.pairwise.nan_euclidean_distances through brute force; NaN = missing)
+            "synth_f32_nan_euclidean_k15": (xn32, yn32, 15, "nan_euclidean", "X_emb"),
+            "synth_f64_nan_euclidean_k15": (xn32.astype(np.float64), yn32.astype(np.float64), 15, "nan_euclidean", "X_emb"),
+            "synth_d10_nan_euclidean_k10": (xn10, yn10, 10, "nan_euclidean", "X_emb"),
         }
         only = sys.argv[3] if len(sys.argv) > 3 else None   # e.g. `--only metrics sqeuclidean`: just the cases of one metric
-        for name, (a_, b_, k_, m_, key_) in cases.items():
+        for name, case_ in cases.items():
+            a_, b_, k_, m_, key_ = case_[:5]
+            ncat_ = case_[5] if len(case_) > 5 else 20   # (tiny references: few label classes, so that every class is observed)
             if only and m_ != only:
                 continue
-            np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_mapping_case(cm_mod, name, a_, b_, k_, metric=m_, rep_key=key_, G=24))
+            np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **run_mapping_case(cm_mod, name, a_, b_, k_, metric=m_, rep_key=key_, G=24, n_cat=ncat_))
             print(name, "written")
         return
     if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "expr_eval":

@@ -36,7 +36,8 @@ def test_knn_matches_reference_golden(name, hip):
     assert dist.dtype == g["yx_dist"].dtype and idx.dtype == np.int64
     assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
     if "dups" not in name:
-        assert len(tie_rows(idx, g["yx_idx"])) == 0
+        ok_rows = ~np.isnan(g["yx_dist"]).any(axis=1)   # (nan_euclidean: which rows fill an all-NaN list is arbitrary upstream)
+        assert len(tie_rows(idx[ok_rows], g["yx_idx"][ok_rows])) == 0
 
 
 @pytest.mark.parametrize("name", MAPPING_CASES)
@@ -925,6 +926,83 @@ def test_counting_metric_goldens(hip, name):
     dist, idx = hip.knn(xrep, yrep, int(g["k"]), metric=metric)
     assert np.array_equal(dist, g["yx_dist"], equal_nan=True)
     assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "haversine" in n or "nan_euclidean" in n])
+def test_haversine_and_nan_euclidean_goldens(hip, name):
+    """Round 5: the last two parameter-free metric names (`knn.py:343,429` hand any of them to sklearn).  Against the reference's
+    own output (tests/golden/latlon*, *nan_euclidean*) at the tolerances tests/parity.py states for them -- libm / numpy / device
+    transcendentals differ in the last bit; upstream's nan_euclidean is a float32 cancellation for float32 data -- with the NaN
+    pattern (pairs without a shared coordinate) identical."""
+    g = load_golden(name)
+    xrep, yrep = rep(g)
+    metric = str(g["metric"])
+    dist, idx = hip.knn(xrep, yrep, int(g["k"]), metric=metric)
+    assert dist.dtype == g["yx_dist"].dtype and hip.knn_stats()["lowd_path"] == 5
+    assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_haversine_and_nan_euclidean_match_the_oracle_and_the_class(hip, oracle, dtype):
+    """Larger random cases against the oracle's restatements (same tolerances), the error cases (haversine needs two columns;
+    NaN only under nan_euclidean; infinities never), the drop-in class and the sharded merge."""
+    import pandas as pd
+
+    from cellmapper_amd import CellMapper, MiniAnnData, _native
+
+    rng = np.random.default_rng(5 + (dtype == np.float64))
+    ll = np.c_[rng.uniform(-1.5, 1.5, 9000), rng.uniform(-3.1, 3.1, 9000)].astype(dtype)
+    lq = np.c_[rng.uniform(-1.5, 1.5, 700), rng.uniform(-3.1, 3.1, 700)].astype(dtype)
+    lq[:50] = ll[:50]                                   # exact hits: distance 0
+    for k in (10, 5000):                                # ball tree / brute force upstream (k >= n_ref / 2)
+        dist, idx = hip.knn(ll, lq[:(700 if k == 10 else 40)], k, metric="haversine")
+        od, oi = oracle.knn_haversine(ll, lq[:(700 if k == 10 else 40)], k)
+        assert_knn_parity(dist, idx, od, oi, ll, lq, "haversine")
+    with pytest.raises(ValueError, match="only valid in 2 dimensions"):
+        hip.knn(np.zeros((50, 3), dtype), np.zeros((5, 3), dtype), 3, metric="haversine")
+    x = rng.standard_normal((6000, 24)).astype(dtype)
+    q = rng.standard_normal((400, 24)).astype(dtype)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    q[rng.random(q.shape) < 0.1] = np.nan
+    q[7] = np.nan                                       # no coordinate at all: every distance NaN
+    x[11] = np.nan
+    dist, idx = hip.knn(x, q, 12, metric="nan_euclidean")
+    od, oi = oracle.knn_nan_euclidean(x, q, 12)
+    assert dist.dtype == dtype and np.isnan(dist[7]).all() and not np.isnan(np.delete(dist, 7, 0)).any() and 11 not in np.delete(idx, 7, 0)
+    assert_knn_parity(dist, idx, od, oi, x, q, "nan_euclidean")
+    with pytest.raises(ValueError, match="NaN"):
+        hip.knn(x, q, 12, metric="euclidean")
+    xi = x.copy(); xi[3, 3] = np.inf
+    with pytest.raises(ValueError, match="infinity"):
+        hip.knn(xi, q, 12, metric="nan_euclidean")
+    # the drop-in class: NaN representations are accepted under this metric only
+    labels = pd.Categorical([f"t{c}" for c in rng.integers(0, 5, x.shape[0])])
+    R = MiniAnnData(X=np.zeros((x.shape[0], 1), np.float32), obs=pd.DataFrame({"label": labels}), obsm={"X_emb": x})
+    Q = MiniAnnData(X=np.zeros((q.shape[0], 1), np.float32), obsm={"X_emb": q})
+    cm = CellMapper(Q, R)
+    cm.compute_neighbors(n_neighbors=12, use_rep="X_emb", metric="nan_euclidean", only_yx=True)
+    assert cm.knn.yx.distances.dtype == dtype
+    assert_knn_parity(cm.knn.yx.distances, cm.knn.yx.indices, od, oi, x, q, "nan_euclidean")
+    with pytest.raises(ValueError, match="NaN"):
+        CellMapper(Q, R).compute_neighbors(n_neighbors=12, use_rep="X_emb", metric="manhattan", only_yx=True)
+    # reference-sharded multi-device graph: NaN values travel through the merge and rank last
+    import os
+    os.environ["CELLMAP_MULTI_REF_SHARD"] = "1"
+    _native.reload_knobs()
+    try:
+        big = np.tile(x, (3, 1))[:3 * 4096 + 5].copy()
+        big += (1e-3 * rng.standard_normal(big.shape)).astype(dtype)
+        qq = np.tile(q, (3, 1))[:1100].copy()
+        hm = _native.Handle(devices=[0, 0, 0])
+        g = _native.DeviceGraph(hm, _native.DeviceRep(hm, big, allow_nan=True), _native.DeviceRep(hm, qq, allow_nan=True), 12, "nan_euclidean")
+        assert g.n_devices == 3
+        dm, im = g.fetch_knn()
+        d1, i1 = hip.knn(big, qq, 12, metric="nan_euclidean")
+        assert np.array_equal(dm, d1, equal_nan=True) and np.array_equal(im[~np.isnan(dm)], i1[~np.isnan(d1)])
+        g.close(); hm.close()
+    finally:
+        os.environ.pop("CELLMAP_MULTI_REF_SHARD", None)
+        _native.reload_knobs()
 
 
 @pytest.mark.parametrize("dtype,d,n_ref,nq,k", [(np.float32, 50, 12000, 700, 30), (np.float64, 33, 9000, 500, 15),

@@ -6,7 +6,7 @@ import scipy.sparse as sp
 
 from parity import (RTOL_FLOAT, assert_csr_close, assert_knn_parity, golden_csr, golden_names, load_golden, tie_rows)
 
-MAPPING_CASES = [n for n in golden_names() if n.startswith(("synth_", "spatial", "identity", "bin"))]
+MAPPING_CASES = [n for n in golden_names() if n.startswith(("synth_", "spatial", "identity", "bin", "latlon"))]
 COUNT_METRICS = ("hamming", "jaccard", "dice", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
 KERNELS = ["gaussian", "scarches", "inverse_distance", "equal"]
 
@@ -36,6 +36,10 @@ def test_oracle_matches_reference(name, oracle):
         assert np.array_equal(dist, g["yx_dist"], equal_nan=True)
     elif metric == "correlation":
         dist, idx = oracle.knn_correlation(xrep, yrep, k)
+    elif metric == "haversine":
+        dist, idx = oracle.knn_haversine(xrep, yrep, k)
+    elif metric == "nan_euclidean":
+        dist, idx = oracle.knn_nan_euclidean(xrep, yrep, k)
     elif metric == "sqeuclidean":
         dist, idx = oracle.knn_euclidean(xrep, yrep, k, squared=True)
         # the float64 GEMM of sklearn's chunks accumulates in BLAS order (OpenBLAS kernels), the oracle in a sequential fma chain:
@@ -48,7 +52,7 @@ def test_oracle_matches_reference(name, oracle):
     assert dist.dtype == g["yx_dist"].dtype
     n_tie = assert_knn_parity(dist, idx, g["yx_dist"], g["yx_idx"], xrep, yrep, metric)
     trows = tie_rows(idx, g["yx_idx"])
-    if "dups" not in name and metric not in COUNT_METRICS:
+    if "dups" not in name and metric not in COUNT_METRICS and metric not in ("haversine", "nan_euclidean"):
         assert len(trows) == 0, f"{n_tie} rows differ only by tie order, {len(trows)} by tie membership"
     # feed the GOLDEN graph into the downstream stages so each stage is pinned independently
     gd, gi = g["yx_dist"], g["yx_idx"]  # float32 for sklearn cosine on float32 input
