@@ -358,7 +358,9 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
     prev_stream = torch.cuda.current_stream()
     torch.cuda.set_stream(pipe.stream)
     try:
-        pipe.h.reserve(a.nref, a.nq, a.d, a.k, metric=a.metric)
+        t_r0 = time.perf_counter()
+        reserved = pipe.h.reserve(a.nref, a.nq, a.d, a.k, metric=a.metric, all_routes=True)   # (a caller that knows its embeddings are clustered)
+        reserve_ms = (time.perf_counter() - t_r0) * 1e3
         al0 = pipe.h.alloc_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -395,7 +397,9 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
                    f"within-cluster sigma {sigma}, reference and query share the centres; {a.nq} x {a.nref}, d={a.d}, k={a.k}",
            "ms_per_step": ms, "value": a.nq / (ms * 1e-3), "unit": "query cells/s", "steps": steps, "warmup": warmup,
            "first_call_ms": first_ms, "first_call_over_steady": first_ms / ms,
-           "first_call_allocator_ms": {"workspace": al1["workspace_ms"] - al0["workspace_ms"], "workspace_bytes_added_in_call": al1["workspace_bytes"] - al0["workspace_bytes"]},
+           "first_call_allocator_ms": {"workspace": al1["workspace_ms"] - al0["workspace_ms"], "workspace_bytes_added_in_call": al1["workspace_bytes"] - al0["workspace_bytes"],
+                                       "reserved_before_the_call_bytes": reserved, "reserve_ms": reserve_ms,
+                                       "note": "cm_workspace_bytes_all_routes: the common route + what bucket pruning and the centred level add (reserved when the handle is set up)"},
            "first_call_stage_ms": st_first, "stage_ms_mean": {kk: vv / steps for kk, vv in acc.items()},
            "filter_level": fb.get("filter_products"), "filter_kernel": fb.get("filter_kernel"), "tiles_visited_pct": fb.get("tiles_visited_pct"),
            "fallback_queries": fb.get("fallback_queries"), "candidates_per_query": fb.get("candidates"),

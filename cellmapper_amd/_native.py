@@ -41,7 +41,7 @@ _lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = [
-    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_pool_trim", "cm_workspace_bytes", "cm_reserve_workspace", "cm_alloc_stats", "cm_reload_knobs", "cm_last_error", "cm_set_stream", "cm_synchronize",
+    "cm_version", "cm_device_count", "cm_create", "cm_create_multi", "cm_destroy", "cm_pool_trim", "cm_workspace_bytes", "cm_workspace_bytes_all_routes", "cm_reserve_workspace", "cm_alloc_stats", "cm_reload_knobs", "cm_last_error", "cm_set_stream", "cm_synchronize",
     "cm_knn_stats", "cm_knn", "cm_knn_dev", "cm_knn_merge_dev", "cm_knn_merge_strided_dev", "cm_mapping_matrix", "cm_dist_moments_dev",
     "cm_kernel_param_dev", "cm_weights_dev", "cm_ell_to_csr_dev", "cm_label_vote", "cm_label_vote_dev",
     "cm_spmm_dense", "cm_spmm_dense_dev", "cm_spmm_csr_nnz", "cm_spmm_csr", "cm_spmm_csr_nnz_dev", "cm_spmm_csr_dev", "cm_spmm_csr_fused_dev", "cm_payload_index_len", "cm_payload_index_dev", "cm_locality_order_dev", "cm_map_labels_dev", "cm_csr_normalize",
@@ -74,6 +74,8 @@ def load_library():
         lib.cm_pool_trim.argtypes = [vp]
         lib.cm_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32]
         lib.cm_workspace_bytes.restype = i64
+        lib.cm_workspace_bytes_all_routes.argtypes = [i64, i64, i32, i32, i32, i32]
+        lib.cm_workspace_bytes_all_routes.restype = i64
         lib.cm_reserve_workspace.argtypes = [vp, i64]
         lib.cm_alloc_stats.argtypes = [vp, vp]
         lib.cm_reload_knobs.argtypes = []
@@ -135,7 +137,7 @@ def load_library():
         lib.cm_device_count.argtypes = []
         for name in EXPORTS:
             fn = getattr(lib, name)
-            if name not in ("cm_version", "cm_device_count", "cm_last_error", "cm_payload_index_len", "cm_workspace_bytes"):
+            if name not in ("cm_version", "cm_device_count", "cm_last_error", "cm_payload_index_len", "cm_workspace_bytes", "cm_workspace_bytes_all_routes"):
                 fn.restype = C.c_int
         _lib = lib
         return lib
@@ -203,11 +205,12 @@ class Handle:
         """Return the handle's cached device blocks to the HIP allocator (``cm_pool_trim``)."""
         self.call("cm_pool_trim")
 
-    def reserve(self, n_ref: int, nq: int, d: int, k: int, dtype=np.float32, metric: str = "euclidean"):
+    def reserve(self, n_ref: int, nq: int, d: int, k: int, dtype=np.float32, metric: str = "euclidean", all_routes: bool = False):
         """Allocate the device workspace of a problem of this shape NOW (``cm_reserve_workspace``): the first search of that
-        problem then allocates nothing.  Returns the bytes reserved."""
-        b = int(self.lib.cm_workspace_bytes(int(n_ref), int(nq), int(d), CM_F64 if np.dtype(dtype) == np.float64 else CM_F32,
-                                            int(k), METRICS[metric]))
+        problem then allocates nothing.  ``all_routes``: also what clustered embeddings add on demand (bucket pruning, the
+        bucket-centred level).  Returns the bytes reserved."""
+        fn = self.lib.cm_workspace_bytes_all_routes if all_routes else self.lib.cm_workspace_bytes
+        b = int(fn(int(n_ref), int(nq), int(d), CM_F64 if np.dtype(dtype) == np.float64 else CM_F32, int(k), METRICS[metric]))
         if b < 0:
             raise ValueError("reserve: bad problem shape")
         self.call("cm_reserve_workspace", b)

@@ -521,6 +521,12 @@ int64_t cm_workspace_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, 
     return (int64_t)(cm_knn_ws_bytes(n_ref, nq, d, k, dtype, metric) + cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024);
 }
 
+int64_t cm_workspace_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, int32_t k, int32_t metric) {
+    if (n_ref < 1 || nq < 0 || d < 1 || k < 1 || (dtype != CM_F32 && dtype != CM_F64)) return -1;
+    const size_t nk = (size_t)nq * (size_t)k;
+    return (int64_t)(cm_knn_ws_bytes_all_routes(n_ref, nq, d, k, dtype, metric) + cm_align(8 * nk) * 2 + cm_align(4 * nk) * 2 + cm_align(4 * (size_t)nq) + 64 * 1024);
+}
+
 cm_status cm_reserve_workspace(cm_handle_t h, int64_t bytes) {
     if (!h || bytes < 0) return CM_E_INVALID;
     h->err.clear();

@@ -129,6 +129,7 @@ static inline size_t cm_align(size_t b) { return (b + 255) & ~size_t(255); }
 // ---- k-NN (knn_kernels.hip) ----
 constexpr int CM_MERGE_NCMAX = 768;   // most (parts x k) entries the shard merge ranks per query (knn_merge's LDS lists)
 size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric = CM_METRIC_EUCLIDEAN);
+size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric);
 cm_status cm_knn_run(cm_handle_t h, const void *d_ref, int64_t n_ref, const void *d_qry, int64_t nq, int32_t d,
                      int32_t dtype, int32_t k, int32_t metric, int32_t form, int64_t idx_offset, int32_t flags,
                      void *d_out_dist, int64_t *d_out_idx);

@@ -3040,6 +3040,28 @@ size_t cm_knn_ws_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t 
     return b + (b >> 6) + (8u << 20);   // (+1.5 % and 8 MB: alignment of the many small allocations)
 }
 
+// The common route plus what the routes of CLUSTERED data add on demand (bucket pruning's candidate lists and plans, the
+// bucket-centred level's packed maps and side values): for callers that know their embeddings are clustered and want even the
+// first call to allocate nothing (cm_workspace_bytes with all_routes; bench.py's clustered leg).
+size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t k, int32_t dtype, int32_t metric) {
+    size_t b = cm_knn_ws_bytes(n_ref, nq, d, k, dtype, metric);
+    if (needs_exact_scan(n_ref, nq, d, k, metric) || metric == CM_METRIC_CORRELATION) return b;
+    if (!(use_f16_path(d, k) || d <= 128)) return b;
+    const int Kc = k + knn_slack_level(k, 1);
+    const int64_t nq_pad = (nq + 511) / 512 * 512;
+    if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
+        b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
+             cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
+    if (nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
+        const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 256 + 1;
+        b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
+             cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
+             cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
+        b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;
+    }
+    return b + (b >> 6);
+}
+
 // "correlation" (scipy.spatial.distance.cdist through sklearn's brute force): x - mean(x) per row, in float64.  One wave per row.
 template <typename T>
 __global__ __launch_bounds__(256) void center_rows(const T *__restrict__ x, int64_t n, int d, double *__restrict__ out) {

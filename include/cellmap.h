@@ -164,6 +164,9 @@ cm_status cm_reload_knobs(void);
  * host / graph tiers, 2 hipFree, 3 pinned host memory); out[12] = milliseconds cm_create took, out[13] of which the
  * code-object preload; out[14] = workspace capacity (all segments), out[15] = most workspace bytes any one call has carved.  (bench.py: first_call_breakdown_ms) */
 int64_t cm_workspace_bytes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, int32_t k, int32_t metric);
+/* ... plus what the routes of clustered embeddings add on demand (bucket pruning's lists, the bucket-centred level's side values:
+ * 7 GB more at 1.5 M x 1.5 M x 50): reserve this to keep even the first call on clustered data free of allocations. */
+int64_t cm_workspace_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t dtype, int32_t k, int32_t metric);
 cm_status cm_reserve_workspace(cm_handle_t h, int64_t bytes);
 cm_status cm_alloc_stats(cm_handle_t h, double out[16]);
 const char *cm_last_error(cm_handle_t h); /* h may be NULL: message of the last failed cm_create */
