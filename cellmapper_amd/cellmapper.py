@@ -168,7 +168,7 @@ class CellMapper(PresenceMixin, ExpressionEvaluationMixin, EmbeddingMixin):
                 raise ValueError("Jaccard and HNOCa methods require both x and y neighbors to be computed. "
                                  "Set only_yx=False.")
             knn = self.knn
-            if knn.xx is None or knn.yy is None or knn.xy is None or knn.yx is None:
+            if not (knn._has("xx") and knn._has("yy") and knn._has("xy") and knn._has("yx")):
                 raise ValueError("Neighbors must be computed before accessing adjacency matrices.")
             # (yx @ xx.T) + (yy @ xy.T) on the 0/1 adjacencies + the jaccard / hnoca transform, on the GPU
             indptr, cols, vals = _native.default_handle().shared_neighbors(

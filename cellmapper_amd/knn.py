@@ -160,11 +160,41 @@ class Neighbors:
     def __init__(self, xrep: np.ndarray, yrep: np.ndarray | None = None):
         self.xrep = xrep
         self.yrep = yrep if yrep is not None else xrep
-        self.xx: NeighborsResults | None = None
-        self.yy: NeighborsResults | None = None
-        self.xy: NeighborsResults | None = None
-        self.yx: NeighborsResults | None = None
+        self._res: dict = {"xx": None, "yy": None, "xy": None, "yx": None}
+        self._pending: dict | None = None   # search parameters of the graphs that are computed on first access (see compute_neighbors)
         self._is_self_mapping = yrep is None
+
+    # The four graphs.  Upstream `compute_neighbors(only_yx=False)` -- the DEFAULT of `CellMapper.map()` -- runs four searches
+    # (knn.py:441-457), of which the kernel mapping methods, every `map_*` transfer and the presence score read `yx` alone; only
+    # jaccard / hnoca and `get_adjacency_matrices` read the other three.  Here `yx` is searched at once and `xx` / `yy` / `xy` on
+    # their first access (same arrays, same errors -- the size check that would have failed upstream is made up front): the
+    # default `map()` of a 1.5 M x 1.5 M problem does one search instead of four.
+    def _get(self, name: str):
+        if self._res[name] is None and self._pending is not None and name != "yx":
+            self._compute_graph(name)
+        return self._res[name]
+
+    def _has(self, name: str) -> bool:
+        return self._res[name] is not None or (self._pending is not None and name != "yx")
+
+    xx = property(lambda self: self._get("xx"), lambda self, v: self._res.__setitem__("xx", v))
+    yy = property(lambda self: self._get("yy"), lambda self, v: self._res.__setitem__("yy", v))
+    xy = property(lambda self: self._get("xy"), lambda self, v: self._res.__setitem__("xy", v))
+    yx = property(lambda self: self._get("yx"), lambda self, v: self._res.__setitem__("yx", v))
+
+    def _compute_graph(self, name: str):
+        p = self._pending
+        h = _native.default_handle()
+        ref_host, qry_host = {"xx": (self.xrep, self.xrep), "yy": (self.yrep, self.yrep), "xy": (self.yrep, self.xrep)}[name]
+        ref = _native.DeviceRep(h, np.asarray(ref_host).astype(p["dt"], copy=False), allow_nan=p["nan_ok"])
+        qry = ref if qry_host is ref_host else _native.DeviceRep(h, np.asarray(qry_host).astype(p["dt"], copy=False), allow_nan=p["nan_ok"])
+        try:
+            n_targets = None if name in ("xx", "yy") else ref_host.shape[0]
+            self._res[name] = NeighborsResults(n_targets=n_targets, _graph=_native.DeviceGraph(h, ref, qry, p["k"], p["metric"]))
+        finally:
+            ref.close()
+            if qry is not ref:
+                qry.close()
 
     @classmethod
     def from_distances(cls, distances_matrix, include_self: bool | None = None) -> "Neighbors":
@@ -211,27 +241,29 @@ class Neighbors:
         nan_ok = metric == "nan_euclidean"   # (sklearn validates with ensure_all_finite="allow-nan" under this metric only)
         xr = _native.DeviceRep(h, np.asarray(self.xrep).astype(dt, copy=False), allow_nan=nan_ok)
         yr = xr if self.yrep is self.xrep else _native.DeviceRep(h, np.asarray(self.yrep).astype(dt, copy=False), allow_nan=nan_ok)
+        self._pending = None
+        self._res = {"xx": None, "yy": None, "xy": None, "yx": None}
+        if not only_yx and n_neighbors > min(nx, ny):
+            # (the yy / xy searches upstream would raise this before anything is returned: sklearn neighbors/_base.py:848-859)
+            raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {n_neighbors}, n_samples_fit = {min(nx, ny)}")
         try:
             self.yx = NeighborsResults(n_targets=nx, _graph=_native.DeviceGraph(h, xr, yr, n_neighbors, metric))
-            if only_yx:
-                return
-            self.xx = NeighborsResults(n_targets=None, _graph=_native.DeviceGraph(h, xr, xr, n_neighbors, metric))
-            self.yy = NeighborsResults(n_targets=None, _graph=_native.DeviceGraph(h, yr, yr, n_neighbors, metric))
-            self.xy = NeighborsResults(n_targets=ny, _graph=_native.DeviceGraph(h, yr, xr, n_neighbors, metric))
         finally:
             xr.close()
             if yr is not xr:
                 yr.close()
+        if not only_yx:   # xx / yy / xy: on first access (see the properties above)
+            self._pending = dict(k=int(n_neighbors), metric=metric, dt=dt, nan_ok=nan_ok)
 
     def get_adjacency_matrices(self):
         """Unweighted adjacency matrices ``(xx, yy, xy, yx)`` (reference knn.py:467-483)."""
-        if self.xx is None or self.yy is None or self.xy is None or self.yx is None:
+        if not (self._has("xx") and self._has("yy") and self._has("xy") and self._has("yx")):
             raise ValueError("Neighbors must be computed before accessing adjacency matrices.")
         return (self.xx.boolean_adjacency(), self.yy.boolean_adjacency(), self.xy.boolean_adjacency(),
                 self.yx.boolean_adjacency())
 
     def __repr__(self):
         return (f"Neighbors(xrep_shape={self.xrep.shape}, yrep_shape={self.yrep.shape}, "
-                f"xx={self.xx is not None}, yy={self.yy is not None}, "
-                f"xy={self.xy is not None}, yx={self.yx is not None}, "
+                f"xx={self._has('xx')}, yy={self._has('yy')}, "
+                f"xy={self._has('xy')}, yx={self._has('yx')}, "
                 f"self_mapping={self._is_self_mapping})")

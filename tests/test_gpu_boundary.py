@@ -694,3 +694,40 @@ def test_large_downloads_take_the_ring_by_default(monkeypatch):
     assert pinned == [(0, 0), (0, 1)], pinned
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_default_map_searches_yx_at_once_and_the_other_graphs_on_first_access(oracle):
+    """`CellMapper.map()` defaults to `only_yx=False` upstream: four searches (knn.py:441-457), three of which nothing reads unless
+    jaccard / hnoca / `get_adjacency_matrices` is used.  Here `yx` is searched at once, `xx` / `yy` / `xy` on first access: the
+    same arrays (oracle self-joins), the same early error when n_neighbors exceeds the smaller set."""
+    import pandas as pd
+
+    from cellmapper_amd import CellMapper, MiniAnnData
+    from cellmapper_amd.knn import Neighbors
+
+    rng = np.random.default_rng(21)
+    ref = rng.standard_normal((3000, 20)).astype(np.float32)
+    qry = rng.standard_normal((400, 20)).astype(np.float32)
+    labels = pd.Categorical([f"t{c}" for c in rng.integers(0, 5, ref.shape[0])])
+    R = MiniAnnData(X=np.zeros((ref.shape[0], 1), np.float32), obs=pd.DataFrame({"label": labels}), obsm={"X_emb": ref})
+    Q = MiniAnnData(X=np.zeros((qry.shape[0], 1), np.float32), obsm={"X_emb": qry})
+    cm = CellMapper(Q, R).map(obs_keys="label", use_rep="X_emb", n_neighbors=10)      # only_yx=False, the default
+    nb = cm.knn
+    assert nb._res["yx"] is not None and nb._res["xx"] is None and nb._res["yy"] is None and nb._res["xy"] is None
+    assert "xx=True" in repr(nb) and nb._res["xx"] is None                              # (asking does not compute)
+    for name, (a, b) in {"xx": (ref, ref), "yy": (qry, qry), "xy": (qry, ref), "yx": (ref, qry)}.items():
+        od, oi = oracle.knn_euclidean(a, b, 10)
+        res = getattr(nb, name)
+        assert np.array_equal(res.indices, oi) and np.array_equal(res.distances, od), name
+    assert all(nb._res[n] is not None for n in ("xx", "yy", "xy", "yx"))
+    xx, yy, xy, yx = nb.get_adjacency_matrices()
+    assert xx.shape == (3000, 3000) and yy.shape == (400, 400) and xy.shape == (3000, 400) and yx.shape == (400, 3000)
+    cm2 = CellMapper(Q, R)
+    cm2.compute_neighbors(n_neighbors=10, use_rep="X_emb")
+    cm2.compute_mapping_matrix("jaccard")                                              # reads all four: computed on demand
+    assert cm2.mapping_matrix.shape == (400, 3000)
+    with pytest.raises(ValueError, match="n_neighbors <= n_samples_fit"):
+        Neighbors(ref, qry).compute_neighbors(n_neighbors=500)                          # yy would need 500 <= 400
+    nb3 = Neighbors(ref, qry)
+    nb3.compute_neighbors(n_neighbors=500, only_yx=True)                                # yx alone is fine: 500 <= 3000
+    assert nb3.yx.indices.shape == (400, 500) and nb3.xx is None
