@@ -1609,16 +1609,21 @@ __global__ __launch_bounds__(256) void sg_overlap(const double *__restrict__ qce
 // (centred, cosine: normalised) query rows in float64.  cen_pack: packed query order in which no 512-query block
 // straddles two buckets (-1 = padding).  cen_side: for every bucket and every row of the (sorted, padded) reference
 // image the float32 value -2 sc^2 c_bucket . y'_row, accumulated in float64.
+// (round 5: a bucket's rows are summed in CEN_SLICES slices by as many workgroups -- one workgroup per bucket left a 40-cluster set
+//  with 40 busy workgroups, 4.5 ms for 1.5 M rows -- and combined in slice order by cen_centroid_final: deterministic)
+constexpr int CEN_SLICES = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void cen_centroid(const T *__restrict__ Q, int d, int metric, const double *__restrict__ mean,
                                                     const int *__restrict__ qperm, const int *__restrict__ bstart,
-                                                    double *__restrict__ cen) {
+                                                    double *__restrict__ part /* [C][CEN_SLICES][64] */) {
     __shared__ double s_acc[4][64];
-    const int j = blockIdx.x, e = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x, sl = blockIdx.y, e = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int lo = bstart[j], hi = bstart[j + 1];
+    const int per = (hi - lo + CEN_SLICES - 1) / CEN_SLICES;
+    const int r0 = lo + sl * per, r1 = r0 + per < hi ? r0 + per : hi;
     double acc = 0.0;
     if (e < d)
-        for (int r = lo + rl; r < hi; r += 4) {
+        for (int r = r0 + rl; r < r1; r += 4) {
             const T *x = Q + (int64_t)qperm[r] * d;
             double ns = 1.0;
             if (metric == CM_METRIC_COSINE) {
@@ -1631,7 +1636,16 @@ __global__ __launch_bounds__(256) void cen_centroid(const T *__restrict__ Q, int
         }
     s_acc[rl][e] = acc;
     __syncthreads();
-    if (rl == 0 && e < d) cen[(size_t)j * d + e] = hi > lo ? (s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]) / (double)(hi - lo) : 0.0;
+    if (rl == 0) part[((size_t)j * CEN_SLICES + sl) * 64 + e] = e < d ? (s_acc[0][e] + s_acc[1][e] + s_acc[2][e] + s_acc[3][e]) : 0.0;
+}
+__global__ __launch_bounds__(64) void cen_centroid_final(const double *__restrict__ part, const int *__restrict__ bstart, int d,
+                                                        double *__restrict__ cen) {
+    const int j = blockIdx.x, e = threadIdx.x;
+    if (e >= d) return;
+    double s = 0.0;
+    for (int sl = 0; sl < CEN_SLICES; ++sl) s += part[((size_t)j * CEN_SLICES + sl) * 64 + e];
+    const int n = bstart[j + 1] - bstart[j];
+    cen[(size_t)j * d + e] = n > 0 ? s / (double)n : 0.0;
 }
 
 __global__ void cen_pack(const int *__restrict__ qperm, const int *__restrict__ bstart, const int *__restrict__ pstart, int C,
@@ -1995,24 +2009,37 @@ __global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
 }
 
 // cen_side for the (bucket, reference row) pairs a work list visits only (bucket pruning): item = (query block, first
-// tile, end tile, .); same arithmetic as cen_side.  Blocks of one bucket write the same values (benign).
+// tile, end tile, .); same arithmetic as cen_side.  Round 5: a bucket holds ~11 query blocks whose runs overlap almost
+// entirely, and pass B revisits what pass A's neighbours computed -- 88 M (bucket, row) values per step at the 40-cluster
+// config-2 shape, 10 ms, most of them several times over.  A (bucket, tile) pair is now CLAIMED (one byte per pair, zeroed once
+// per call) by the first workgroup that reaches it; everybody else skips the tile.  The values of a pair are the same whoever
+// computes them.
 template <typename T>
-__global__ __launch_bounds__(256) void cen_side_items(const T *__restrict__ R, int64_t n_ref, int d, int metric,
+__global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, int64_t n_ref, int d, int metric,
                                                       const double *__restrict__ mean, const int *__restrict__ rperm,
                                                       const double *__restrict__ cen, const int *__restrict__ blk_bucket,
                                                       const int4 *__restrict__ wl, int n_items,
                                                       const float *__restrict__ scale3, int64_t stride,
-                                                      float *__restrict__ side) {
+                                                      float *__restrict__ side, unsigned *__restrict__ claimed, int n_tiles) {
     __shared__ double s_c[64];
+    __shared__ unsigned s_mine;
     if ((int)blockIdx.x >= n_items) return;
     const int4 w = wl[blockIdx.x];
     const int j = blk_bucket[w.x];
     if (threadIdx.x < 64) s_c[threadIdx.x] = (int)threadIdx.x < d ? cen[(size_t)j * d + threadIdx.x] : 0.0;
-    __syncthreads();
     const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
-    int64_t r1 = (int64_t)w.z * cmk2::BR;
-    if (r1 > stride) r1 = stride;
-    for (int64_t r = (int64_t)w.y * cmk2::BR + (int64_t)blockIdx.y * 256 + threadIdx.x; r < r1; r += 256 * (int64_t)gridDim.y) {
+    for (int t = w.y + (int)blockIdx.y; t < w.z; t += (int)gridDim.y) {
+        __syncthreads();   // (s_c is ready; the previous tile's readers of s_mine are done)
+        if (threadIdx.x == 0) {
+            // one bit per (bucket, tile) pair in 32-bit words: atomicOr returns the old word
+            const size_t bit = (size_t)j * (size_t)n_tiles + (size_t)t;
+            const unsigned m = 1u << (bit & 31);
+            s_mine = (atomicOr(&claimed[bit >> 5], m) & m) == 0u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_mine) continue;
+        const int64_t r = (int64_t)t * cmk2::BR + threadIdx.x;   // (BR = 128 rows per tile = one per thread)
+        if (r >= stride) continue;
         double dot = 0.0;
         if (r < n_ref) {
             const T *x = R + (int64_t)(rperm ? rperm[r] : r) * d;
@@ -2210,6 +2237,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
     int64_t n_packed = 0, side_stride = 0;
     bool side_full = false;   // side values computed for every (bucket, reference row) pair
+    unsigned *side_claimed = nullptr;   // (bucket, tile) pairs whose side values exist already (cen_side_items)
     // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
@@ -2534,9 +2562,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             }
             auto side_items = [&](const int4 *wl, int n_items) {   // centred level: side values of the pairs a list visits
                 if (!cenl || side_full || n_items < 1) return;
-                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, 4), dim3(256), 0, st, d_ref, n_ref, d, metric,
+                // (side_claimed: one bit per (bucket, tile) pair, allocated and zeroed with the side values in setup_centred)
+                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, 4), dim3(128), 0, st, d_ref, n_ref, d, metric,
                                    (const double *)d_mean, (const int *)rperm, (const double *)cen, (const int *)blk_bucket, wl,
-                                   n_items, (const float *)scale3, side_stride, side);
+                                   n_items, (const float *)scale3, side_stride, side, side_claimed, pf.n_tiles);
             };
             side_items(ivf_wla, p2.nqb);
             CM_TRY(launch(b));
@@ -2689,11 +2718,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         side = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)C * side_stride);
         qnc = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
         qcen = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
-        if (!pstart || !qpack || !blk_bucket || !cen || !side || !qnc || !qcen) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        const size_t claim_words = ((size_t)C * (size_t)pf.n_tiles + 31) / 32 + 1;   // one bit per (bucket, tile) pair: cen_side_items
+        side_claimed = (unsigned *)cm_ws_alloc(h, sizeof(unsigned) * claim_words);
+        if (!pstart || !qpack || !blk_bucket || !cen || !side || !qnc || !qcen || !side_claimed) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        CM_HIP(h, hipMemsetAsync(side_claimed, 0, sizeof(unsigned) * claim_words, st));
         CM_HIP(h, hipMemcpyAsync(pstart, hps, sizeof(int) * (C + 1), hipMemcpyHostToDevice, st));
         CM_HIP(h, hipStreamSynchronize(st));   // (hps lives on this stack frame)
-        hipLaunchKernelGGL(cen_centroid<T>, dim3(C), dim3(256), 0, st, d_qry, d, metric, (const double *)d_mean, (const int *)qperm,
-                           (const int *)q_bstart, cen);
+        double *cen_part = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * CEN_SLICES * 64);
+        if (!cen_part) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        hipLaunchKernelGGL(cen_centroid<T>, dim3(C, CEN_SLICES), dim3(256), 0, st, d_qry, d, metric, (const double *)d_mean, (const int *)qperm,
+                           (const int *)q_bstart, cen_part);
+        hipLaunchKernelGGL(cen_centroid_final, dim3(C), dim3(64), 0, st, (const double *)cen_part, (const int *)q_bstart, d, cen);
         hipLaunchKernelGGL(cen_pack, dim3((unsigned)((n_packed + 255) / 256)), dim3(256), 0, st, (const int *)qperm, (const int *)q_bstart,
                            (const int *)pstart, C, n_packed, qpack, blk_bucket);
         CM_HIP(h, hipGetLastError());
