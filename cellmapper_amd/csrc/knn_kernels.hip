@@ -1885,7 +1885,8 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
                                                   float c_eps, int level, const int4 *__restrict__ wl_a,
                                                   const int *__restrict__ jstar, int4 *__restrict__ wl_b,
-                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb, int qblk) {
+                                                  int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb, int qblk,
+                                                  int2 *__restrict__ runs /* chained mode: one item per block, its runs here */) {
     // sb <= IVF_SB: runs (candidate lists) per block this stage may use -- the re-rank holds (sb + 1) * K' candidates
     // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
     // relative error -c_eps and the float64 -> float32 input rounding dlt per coordinate (see knn_rerank)
@@ -1960,6 +1961,17 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
         if (u0 < a0) { p0[np] = u0; p1[np] = a0; ++np; }
         if (u1 > a1) { p0[np] = a1; p1[np] = u1; ++np; }
     }
+    if (runs) {   // chained mode (round 5): ONE work item and ONE candidate list for all the runs of the block
+        long long tiles_c = a1 - a0;
+        if (np > 0) {
+            const int head = atomicAdd(&counters[0], 1);
+            const int rbase = atomicAdd(&counters[1], np);
+            for (int i = 0; i < np; ++i) { runs[rbase + i] = make_int2(p0[i], p1[i]); tiles_c += p1[i] - p0[i]; }
+            wl_b[head] = make_int4(b, rbase, rbase + np, 1);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)tiles_c);
+        return;
+    }
     // at most IVF_SB runs: close the smallest gaps (never the one that holds the pass-A tiles)
     while (np > sb) {
         int bi = -1, bg = 0x7fffffff;
@@ -2020,7 +2032,8 @@ __global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, i
                                                       const double *__restrict__ cen, const int *__restrict__ blk_bucket,
                                                       const int4 *__restrict__ wl, int n_items,
                                                       const float *__restrict__ scale3, int64_t stride,
-                                                      float *__restrict__ side, unsigned *__restrict__ claimed, int n_tiles) {
+                                                      float *__restrict__ side, unsigned *__restrict__ claimed, int n_tiles,
+                                                      const int2 *__restrict__ runs /* chained items: (block, first run, end run, .) */) {
     __shared__ double s_c[64];
     __shared__ unsigned s_mine;
     if ((int)blockIdx.x >= n_items) return;
@@ -2028,7 +2041,10 @@ __global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, i
     const int j = blk_bucket[w.x];
     if (threadIdx.x < 64) s_c[threadIdx.x] = (int)threadIdx.x < d ? cen[(size_t)j * d + threadIdx.x] : 0.0;
     const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
-    for (int t = w.y + (int)blockIdx.y; t < w.z; t += (int)gridDim.y) {
+    const int n_runs = runs ? w.z - w.y : 1;
+    for (int rr = 0; rr < n_runs; ++rr) {
+    const int t_b = runs ? runs[w.y + rr].x : w.y, t_e = runs ? runs[w.y + rr].y : w.z;
+    for (int t = t_b + (int)blockIdx.y; t < t_e; t += (int)gridDim.y) {
         __syncthreads();   // (s_c is ready; the previous tile's readers of s_mine are done)
         if (threadIdx.x == 0) {
             // one bit per (bucket, tile) pair in 32-bit words: atomicOr returns the old word
@@ -2053,6 +2069,7 @@ __global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, i
             for (int c = 0; c < d; ++c) dot = fma(s_c[c], (double)x[c] * ns - mean[c], dot);
         }
         side[(size_t)j * stride + r] = (float)(m2 * dot);
+    }
     }
 }
 
@@ -2250,7 +2267,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
     int *ivf_rcnt = nullptr, *ivf_bcnt = nullptr, *ivf_jstar = nullptr, *ivf_ctr = nullptr, *ivf_cand = nullptr;
     int4 *ivf_wla = nullptr, *ivf_wlb = nullptr;
+    int2 *ivf_runs = nullptr;
     float *ivf_cthr = nullptr;
+    size_t ivf_list_cap = 0;   // candidate lists (entries of Kc_max ints) ivf_cand / ivf_cthr hold
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
     // sample-seeded thresholds of the plain full scan (see run_stage)
     char *seed_img = nullptr;
@@ -2420,7 +2439,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
+        a.dbg = dbg & ~(16 | 64 | 128 | 256); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
@@ -2507,13 +2526,30 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 ivf_wla = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max);
                 ivf_wlb = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max * IVF_SB);
                 ivf_ctr = (int *)cm_ws_alloc(h, 64);
-                ivf_cand = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)(nq_pad + pack_slack) * ivf_S * Kc_max);
-                ivf_cthr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)(nq_pad + pack_slack) * ivf_S);
+                ivf_runs = (int2 *)cm_ws_alloc(h, sizeof(int2) * (size_t)nqb_max * 136);   // (a block has at most C / 2 + 1 maximal runs)
                 if (!ivf_rcen || !ivf_rrad || !ivf_rcnt || !ivf_bcen || !ivf_brad || !ivf_bcnt || !ivf_jstar || !ivf_wla || !ivf_wlb ||
-                    !ivf_ctr || !ivf_cand || !ivf_cthr)
+                    !ivf_ctr || !ivf_runs)
                     CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
                 ivf_ball<T>(st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm, (const int *)r_bstart, n_ref, C, 32,
                             ivf_rcen, ivf_rrad, ivf_rcnt);
+            }
+            // Chained pass B (round 5): with four or more blocks per compute unit the blocks balance the chip by themselves, so a
+            // block's runs are scanned by ONE work item into ONE candidate list (knn_cand_f16, P1Args::wruns): 2 lists per query
+            // instead of 14 -- a seventh of the list memory (5.7 -> 0.8 GB at the config-2 shape) and of its 0xff fill, and the
+            // re-rank gathers 2 K' candidates instead of up to 6 K' (a cluster split over several buckets used to fill a list per
+            // bucket: 17 ms of re-rank at 1.5 M clustered queries).  Few blocks, the direct level and the K = 128 three-product
+            // kernel keep one list per run (runs halved for load balance).
+            const int res_ = h->n_cu > 0 ? h->n_cu : 256;
+            const bool chain = level != 4 && !w3 && (p2.nqb >= 4 * res_ || (dbg & 256)) && !(dbg & 128);   // (CELLMAP_DBG=128: one list per run everywhere -- A/B; 256: chained whatever the block count -- tests)
+            const int use_S = chain ? 2 : ivf_S;
+            {
+                const size_t need = (size_t)(p2.nq_pad + 1024) * (size_t)use_S;
+                if (need > ivf_list_cap) {
+                    ivf_cand = (int *)cm_ws_alloc(h, sizeof(int) * need * Kc_max);
+                    ivf_cthr = (float *)cm_ws_alloc(h, sizeof(float) * need);
+                    if (!ivf_cand || !ivf_cthr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                    ivf_list_cap = need;
+                }
             }
             ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
                         ivf_bcnt, qblk);
@@ -2537,12 +2573,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (ivf_try) {
             hipLaunchKernelGGL(ivf_plan_a, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_rcen,
                                (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, BRt, ivf_wla, ivf_jstar);
-            const int64_t n_ent = (int64_t)p2.nq_pad * ivf_S;
+            const int64_t n_ent = (int64_t)p2.nq_pad * use_S;
             CM_HIP(h, hipMemsetAsync(ivf_cand, 0xff, sizeof(int) * (size_t)n_ent * p2.Kc, st));
             hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, ivf_cthr, n_ent, INFINITY);
             hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
             cmk2::P1Args b = a;
-            b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = ivf_S; b.perm_mul = 1;
+            b.cand = ivf_cand; b.cthr = ivf_cthr; b.S = use_S; b.perm_mul = 1;
             b.wlist = ivf_wla; b.n_wlist = p2.nqb;
             b.wctr = ivf_ctr + 8;
             // subset stage: pass A starts from the bound its queries already have (see the unpruned case below): the
@@ -2556,25 +2592,30 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                 !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
             if (seed_a) {
                 hipLaunchKernelGGL(seed_scatter_slot0, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, st, (const float *)seedb,
-                                   (const double *)bound, qmap, nsub, ivf_S, level == 4 ? 1 : 0, metric == CM_METRIC_COSINE ? 1 : 0,
+                                   (const double *)bound, qmap, nsub, use_S, level == 4 ? 1 : 0, metric == CM_METRIC_COSINE ? 1 : 0,
                                    16.0 * (double)(d + 4) * 5.9604645e-8, ivf_cthr);
                 b.thr0_slot0 = 1;
             }
-            auto side_items = [&](const int4 *wl, int n_items) {   // centred level: side values of the pairs a list visits
+            auto side_items = [&](const int4 *wl, int n_items, const int2 *runs = nullptr) {   // centred level: side values of the pairs a list visits
                 if (!cenl || side_full || n_items < 1) return;
                 // (side_claimed: one bit per (bucket, tile) pair, allocated and zeroed with the side values in setup_centred)
-                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, 4), dim3(128), 0, st, d_ref, n_ref, d, metric,
+                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, runs ? 32 : 4), dim3(128), 0, st, d_ref, n_ref, d, metric,   // (a chained item holds all the runs of its block)
                                    (const double *)d_mean, (const int *)rperm, (const double *)cen, (const int *)blk_bucket, wl,
-                                   n_items, (const float *)scale3, side_stride, side, side_claimed, pf.n_tiles);
+                                   n_items, (const float *)scale3, side_stride, side, side_claimed, pf.n_tiles, runs);
             };
             side_items(ivf_wla, p2.nqb);
             CM_TRY(launch(b));
+            // long runs are halved for load balance -- but every half is one more candidate list per query for the re-rank to
+            // gather (a cluster split over six buckets filled all of them: 360 candidates per query, 17 ms of re-rank at the
+            // 40-cluster config-2 shape).  With four or more blocks per compute unit the blocks balance the chip by themselves.
+            const int split_len = level == 4 ? 32 : 256;
             hipLaunchKernelGGL(ivf_plan_b, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
                                (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, qmap, nsub,
-                               (const float *)ivf_cthr, ivf_S, (const float *)qnorm, (const float *)qlo,
+                               (const float *)ivf_cthr, use_S, (const float *)qnorm, (const float *)qlo,
                                cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
                                (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
-                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, level == 4 ? 32 : 256, ivf_sb, qblk);
+                               (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, split_len, ivf_sb, qblk,
+                               chain ? ivf_runs : (int2 *)nullptr);
             CM_HIP(h, hipGetLastError());
             int *hc = h->d_nflag_pinned + 4;
             CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2591,16 +2632,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             if (tiles * 8ull <= full) {
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
+                    b.wruns = chain ? ivf_runs : (const int2 *)nullptr;
                     b.wctr = ivf_ctr + 9;
-                    side_items(ivf_wlb, hc[0]);
+                    side_items(ivf_wlb, hc[0], chain ? (const int2 *)ivf_runs : (const int2 *)nullptr);
                     CM_TRY(launch(b));
                 }
                 pruned = true;
-                rr_cand = ivf_cand; rr_cthr = ivf_cthr; rr_S = ivf_S;
+                rr_cand = ivf_cand; rr_cthr = ivf_cthr; rr_S = use_S;
                 // re-rank capacity: the lists are mostly empty; a query that overflows it is left to the next level -- on
                 // the last level that would be the exact scan, so there the capacity covers every list
                 const bool last_level = level == 4 || (level == 3 && !have_direct);
-                rr_ncap = std::min(RR_NCMAX, (last_level ? ivf_sb + 1 : 6) * p2.Kc);
+                rr_ncap = std::min(RR_NCMAX, (chain ? 2 : (last_level ? ivf_sb + 1 : 6)) * p2.Kc);
                 if (marks) ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
@@ -3089,7 +3131,8 @@ size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t 
              cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
     if (nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
         const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 256 + 1;
-        b += cm_align(4 * nqp * (IVF_SB + 1) * (size_t)(Kc + 16)) + cm_align(4 * nqp * (IVF_SB + 1)) +
+        const size_t lists = nq_pad / 512 >= 1024 ? 2 : IVF_SB + 1;   // (chained pass B from four blocks per compute unit on)
+        b += cm_align(4 * nqp * lists * (size_t)(Kc + 16)) + cm_align(4 * nqp * lists) + cm_align(8 * nqb * 136) +
              cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
              cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
         b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;

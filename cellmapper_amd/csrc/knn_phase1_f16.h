@@ -109,6 +109,11 @@ struct P1Args {
     const int *n_wlist_dev = nullptr;
     int n_wlist = 0;
     int thr0_slot0 = 0;
+    // chained runs (round 5; knn_cand_f16 only): with wruns != nullptr an item is (query block, first run, end run, slot) and
+    // wruns[r] = (first tile, end tile): the workgroup scans the item's runs one after the other INTO ONE candidate list --
+    // thresholds, logs and kept lists carry over -- instead of one list per run.  A cluster that the locality sort split over
+    // six buckets then costs the re-rank one list of K' candidates, not six.
+    const int2 *wruns = nullptr;
     // sample-seeded thresholds (knn_run_staged): thr0[q] is an initial threshold per query row (any value is valid: only
     // rows below the running threshold are ever appended, so "every non-candidate has a filter value >= the final
     // threshold" holds whatever it started from).  no_sched: no scheduled threshold refreshes, merges only when a log fills.
@@ -602,10 +607,12 @@ __device__ __forceinline__ void knn_cand_f16_body(P1Args a_in) {
     };
     for (int work = blockIdx.x; work < n_work; work = next_work(work)) {
         int qb, split, t0, t1;
+        int run_b = 0, run_e = 1;   // chained runs of this item (one run unless a.wruns)
         if (a.wlist) {
             const int4 w_ = a.wlist[work];
             qb = __builtin_amdgcn_readfirstlane(w_.x); t0 = __builtin_amdgcn_readfirstlane(w_.y);
             t1 = __builtin_amdgcn_readfirstlane(w_.z); split = __builtin_amdgcn_readfirstlane(w_.w);
+            if (a.wruns) { run_b = t0; run_e = t1; }
         } else {
             qb = work / a.S; split = work - qb * a.S;
             t0 = split * a.tiles_per_split;
@@ -668,7 +675,13 @@ __device__ __forceinline__ void knn_cand_f16_body(P1Args a_in) {
         // LDS-latency bubble.  The DMA pieces of tile t+AHEAD (buffer of tile t-1) are spread over the sub-tiles of
         // tile t, so the wait at a tile boundary is a counted vmcnt that leaves the pieces of the AHEAD-2 youngest
         // tiles in flight.
-        __builtin_amdgcn_s_barrier();  // previous work item: every wave is done reading the ring
+        unsigned long long tw1_ = 0ull;
+        for (int run = run_b; run < run_e; ++run) {   // (chained runs: the candidate state above carries from run to run)
+        if (a.wruns) {
+            const int2 r_ = a.wruns[run];
+            t0 = __builtin_amdgcn_readfirstlane(r_.x); t1 = __builtin_amdgcn_readfirstlane(r_.y);
+        }
+        __builtin_amdgcn_s_barrier();  // previous work item / run: every wave is done reading the ring
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u)
             if (t0 + u < t1) CM2_DMA_TILE(CM2_PT(t0 + u), (t0 + u) % RING);
@@ -723,7 +736,7 @@ __device__ __forceinline__ void knn_cand_f16_body(P1Args a_in) {
         }
         int ptile = CM2_PT(t0), ptile_a = CM2_PT(t0 + AHEAD);
         const int pstep = a.perm_mul > 1u ? (int)(a.perm_mul % (unsigned)a.n_tiles) : 1;
-        const unsigned long long tw1_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (run == run_b) tw1_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int t = t0; t < t1; ++t) {
             unsigned long long tb0_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0 && (BT == 1 || (t - t0) % BT == 0)) {   // (the first tile synchronised above)
@@ -882,6 +895,7 @@ __device__ __forceinline__ void knn_cand_f16_body(P1Args a_in) {
         if (a.dbg & 2) asm volatile("" ::"v"(p0[0]), "v"(p1[0]), "v"(p0[15]), "v"(p1[15]));
 #undef CM2_LOAD_AH
 #undef CM2_LOAD_SIDE
+        }   // (runs of the item)
 
         const unsigned long long tw2_ = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
         if constexpr (SEEDL == 0) CM2_FINAL();

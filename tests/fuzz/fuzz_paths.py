@@ -47,6 +47,11 @@ def main():
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ.pop(v, None)
         os.environ["CELLMAP_Q4"] = "2" if case % 2 == 0 else "1"   # the four-accumulator filter wherever it exists / by its size rule
+        # round 5: pass B of a pruned stage chained into one list per block (the rule needs >= 1 024 blocks: forced in two cases of three)
+        if case % 3 != 2:
+            os.environ["CELLMAP_DBG"] = "256"
+        else:
+            os.environ.pop("CELLMAP_DBG", None)
         _native.reload_knobs()   # (the library latches the knobs in cm_create)
         t0 = time.perf_counter()
         d1, i1 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
@@ -55,6 +60,7 @@ def main():
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ[v] = "1"
         os.environ["CELLMAP_Q4"] = "0"
+        os.environ.pop("CELLMAP_DBG", None)
         _native.reload_knobs()
         d2, i2 = pipe.knn(ref, qry, k, metric=metric); pipe.h.call("cm_synchronize")
         t2 = time.perf_counter()

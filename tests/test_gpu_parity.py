@@ -457,6 +457,40 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
 
 
+@pytest.mark.parametrize("d,k,sigma,dtype,metric", [(50, 30, 1.0, np.float32, "euclidean"), (40, 10, 0.3, np.float64, "euclidean"),
+                                                    (50, 15, 0.6, np.float32, "cosine"), (24, 50, 1.0, np.float32, "euclidean")])
+def test_chained_pass_b_is_exact(hip, oracle, monkeypatch, d, k, sigma, dtype, metric):
+    """Round 5: with four or more query blocks per compute unit the runs of a block's pass B are scanned by ONE work item into
+    ONE candidate list (P1Args::wruns; 2 lists per query instead of 14).  Forced here at a test size (CELLMAP_DBG=256): identical
+    to one list per run (CELLMAP_DBG=128) and to the unpruned search on EVERY row, identical to the oracle on a sample."""
+    from parity import assert_knn_parity
+
+    rng = np.random.default_rng(166 + d)
+    n_ref, nq = 260_000, 150_000
+    cen = rng.standard_normal((40, d)) * 5.0
+    ref = (cen[rng.integers(0, 40, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(dtype)
+    qry = (cen[rng.integers(0, 40, nq)] + sigma * rng.standard_normal((nq, d))).astype(dtype)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    res = {}
+    for tag, dbg in (("chained", "256"), ("per_run", "128")):
+        monkeypatch.setenv("CELLMAP_DBG", dbg)
+        res[tag] = hip.knn(ref, qry, k, metric=metric) + (hip.knn_stats(),)
+    monkeypatch.delenv("CELLMAP_DBG")
+    monkeypatch.setenv("CELLMAP_NO_IVF", "1")
+    res["unpruned"] = hip.knn(ref, qry, k, metric=metric) + (hip.knn_stats(),)
+    assert res["chained"][2]["tiles_visited_pct"] > 0 and res["per_run"][2]["tiles_visited_pct"] > 0 and res["unpruned"][2]["tiles_visited_pct"] == 0, \
+        [r[2] for r in res.values()]
+    for tag in ("per_run", "unpruned"):
+        assert np.array_equal(res["chained"][1], res[tag][1]) and np.array_equal(res["chained"][0], res[tag][0]), tag
+    sel = rng.choice(nq, 300, replace=False)
+    if metric == "cosine":
+        od, oi = oracle.knn_cosine(ref, qry[sel], k)
+        assert_knn_parity(res["chained"][0][sel], res["chained"][1][sel], od, oi, ref, qry[sel], "cosine")
+    else:
+        od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+        assert np.array_equal(res["chained"][1][sel], oi) and np.array_equal(res["chained"][0][sel], od)
+
+
 @pytest.mark.parametrize("d,sigma,dtype", [(128, 1.0, np.float32), (100, 0.3, np.float32), (72, 2.5, np.float64)])
 def test_wide_family_bucket_pruning_is_exact(hip, oracle, monkeypatch, d, sigma, dtype):
     """Round 5: the K = 128 family (62 <= d <= 128) prunes (query block, reference bucket) pairs like the K <= 64 kernels -- the
