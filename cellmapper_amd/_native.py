@@ -250,7 +250,7 @@ class Handle:
         return dict(fallback_queries=int(out[0]), candidates=int(out[1]), ref_splits=int(out[2]) % 100,
                     filter_products=(int(out[2]) // 100) % 100, filter_kernel=int(out[2]) // 10000, lowd_path=int(out[3]) % 100,
                     # bucket pruning: (query block, reference tile) pairs visited, per cent of a full scan (0 = not used)
-                    tiles_visited_pct=int(out[3]) // 100,
+                    tiles_visited_pct=(int(out[3]) // 100) % 1000, pruning_passes=int(out[3]) // 100000,
                     # 1 = a query's exact-fallback list overflowed (results truncated): device-tier callers must check
                     fallback_overflow=int(out[4]))
 

@@ -28,6 +28,8 @@ void latch_knobs() {
     auto num = [](const char *n, long long dflt) { const char *e = getenv(n); return (e && *e) ? atoll(e) : dflt; };
     auto on = [](const char *n) { return getenv(n) != nullptr; };
     k.dbg = (int)num("CELLMAP_DBG", 0);
+    k.fb_max = (int)num("CELLMAP_FB_MAX", 64);
+    if (const char *e = getenv("CELLMAP_SEED_WIDEN")) k.seed_widen = (float)atof(e);
     k.filter_products = (int)num("CELLMAP_FILTER_PRODUCTS", 0);
     k.q4 = (int)num("CELLMAP_Q4", 1);
     k.r16 = (int)num("CELLMAP_R16", 0);

@@ -10,6 +10,8 @@
 // Diagnostics / test knobs (CELLMAP_* environment variables): read ONCE per cm_create (and by
 // cm_reload_knobs) into this process-wide record -- nothing on a call path reads the environment.
 struct cm_knobs {
+    float seed_widen = 0.5f;     // CELLMAP_SEED_WIDEN: sample-scan seeds of a more precise level are widened by this many plain hi*hi error bounds
+    int fb_max = 64;             // CELLMAP_FB_MAX: at most this many uncertified queries (all with a finite bound) go straight to the exact scan
     int dbg = 0;                 // CELLMAP_DBG: in-kernel timing modes / counters of the filter kernels
     int filter_products = 0;     // CELLMAP_FILTER_PRODUCTS: pin the filter level (no escalation)
     int r16 = 0;                 // CELLMAP_R16: 1 = the 128-queries-per-wave stage at K = 64 runs on the 16x16x32 re-tile (knn_cand_f16r) instead of the 32x32x16 kernel

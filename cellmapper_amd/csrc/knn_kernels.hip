@@ -21,6 +21,7 @@ cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, cons
 cm_status cm_p1f16r_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);   // 16x16x32 re-tile (knn_phase1_r16.h): experiment builds only
 #endif
 cm_status cm_p1f16_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
+cm_status cm_p1f16_seed10_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_launch(cm_handle_t h, int D, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1lowd_metric_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
 cm_status cm_p1direct_wide_launch(cm_handle_t h, int D, int op, int grid, size_t lds, const cmk2::P1Args &a);
@@ -723,6 +724,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
             if (seedb) {
                 const double b = fmin(bound[io], kth);
                 bound[io] = b;
+                if (!(b < INFINITY)) atomicAdd(flag_cnt + 20, 1);   // (words[22]: flagged without a finite bound -- fewer than k candidates so far)
                 float sv = INFINITY;
                 if (b < INFINITY && seed_eps >= 0.0) {
                     // (2 x the filter error: the next stage's certificate needs s_k + its own error below the threshold, and the
@@ -736,6 +738,7 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
                 seedb[io] = sv;
             } else {
                 bound[io] = kth;
+                if (!(kth < INFINITY)) atomicAdd(flag_cnt + 20, 1);
             }
         }
     }
@@ -1886,7 +1889,11 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   float c_eps, int level, const int4 *__restrict__ wl_a,
                                                   const int *__restrict__ jstar, int4 *__restrict__ wl_b,
                                                   int *__restrict__ counters, int BRt, int is_f64, int d_rows, int split_len, int sb, int qblk,
-                                                  int2 *__restrict__ runs /* chained mode: one item per block, its runs here */) {
+                                                  int2 *__restrict__ runs /* chained mode: one item per block, its runs here */,
+                                                  int seeds /* 1: single-pass stage -- cthr holds sample-scan seeds, no pass A */,
+                                                  const float *__restrict__ qn1, const float *__restrict__ qlo1, float c_eps1,
+                                                  float *__restrict__ thr_out /* seeds of a more precise level: widened here */,
+                                                  float widen_mul) {
     // sb <= IVF_SB: runs (candidate lists) per block this stage may use -- the re-rank holds (sb + 1) * K' candidates
     // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
     // relative error -c_eps and the float64 -> float32 input rounding dlt per coordinate (see knn_rerank)
@@ -1901,7 +1908,20 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     double dm = 0.0;
     for (int64_t i = (int64_t)b * qblk + tid; i < (int64_t)(b + 1) * qblk && i < nsub; i += 256) {   // (qblk: queries per block of the stage's filter kernel)
         if (qmap && qmap[i] < 0) continue;
-        const float tau = cthr[i * S];
+        float tau = cthr[i * S];
+        if (thr_out && tau < INFINITY) {
+            // The seed is a value of the PLAIN hi*hi filter; this stage's filter (bucket-centred / three products) is more
+            // precise, and on tight clusters the plain error is of the order of the gaps between neighbours: the threshold the
+            // stage starts from is the seed plus twice the plain bound, so that the rows at or below the seed on the plain
+            // filter stay at or below it here.  (Tightness only: D below is computed from the widened value, whatever it is.)
+            const double q1 = (double)qn1[i];
+            const double e1 = (double)c_eps1 * (ymax * ymax + 2.0 * q1 * ymax + 1e-30) + 2.0 * 1.001 * ymax * ((double)qlo1[i] + q1 * rho_y);
+            const double w = (double)tau + (double)widen_mul * e1 / (double)scale3[2];
+            float wf = (float)w;
+            if ((double)wf < w) wf = nextafterf(wf, INFINITY);
+            tau = wf;
+            thr_out[i] = wf;
+        }
         double D = INFINITY;
         if (tau < INFINITY && level == 4) {
             const double t = (double)tau;
@@ -1928,7 +1948,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
         __syncthreads();
     }
     const double Dmax = s_red[0];
-    const int js = jstar[b];
+    const int js = seeds ? 0 : jstar[b];
     bool need = false;
     if (tid < C && r_bstart[tid + 1] > r_bstart[tid]) {
         double s2 = 0.0;
@@ -1939,7 +1959,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     s_need[tid] = need ? 1 : 0;
     __syncthreads();
     if (tid != 0) return;
-    const int a0 = wl_a[b].y, a1 = wl_a[b].z;
+    const int a0 = seeds ? 0 : wl_a[b].y, a1 = seeds ? 0 : wl_a[b].z;   // (single-pass stage: nothing visited yet)
     if (js < 0) {   // pass A already visited every tile
         atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)(a1 - a0));
         return;
@@ -1967,7 +1987,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
             const int head = atomicAdd(&counters[0], 1);
             const int rbase = atomicAdd(&counters[1], np);
             for (int i = 0; i < np; ++i) { runs[rbase + i] = make_int2(p0[i], p1[i]); tiles_c += p1[i] - p0[i]; }
-            wl_b[head] = make_int4(b, rbase, rbase + np, 1);
+            wl_b[head] = make_int4(b, rbase, rbase + np, seeds ? 0 : 1);
         }
         atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)tiles_c);
         return;
@@ -2004,15 +2024,51 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
     atomicAdd(reinterpret_cast<unsigned long long *>(counters + 2), (unsigned long long)tiles);
 }
 
-// every R-th row of the (sorted) reference image: the sample whose scan seeds the thresholds of the main scan
-// The first tile of the sample image holds `head` rows and padding: the sample scan refreshes its thresholds once, after
-// that tile, so the rows it appends while its thresholds are still +inf are few.
-__global__ void sample_map(const int *__restrict__ rperm, int64_t n_s, int R, int head, int *__restrict__ sperm) {
+// every R-th row of the (sorted) reference image: the sample whose scan seeds the thresholds of the main scan.
+// Round 5: the sample is INTERLEAVED over the 32-row sub-tiles of its image -- sub-tile s holds the sample rows s, s + n_st,
+// s + 2 n_st, ... (n_st sub-tiles, rotated: below) -- because the seeding scan keeps sub-tile MINIMA: in sorted order the ~50 sample rows of a
+// small cluster sat in two sub-tiles, the lists saw two of them and the seed was the distance to the next cluster (useless as a
+// pruning radius: 90 % of the pairs left at 260 k rows in 40 clusters); spread out, every sub-tile holds its share of every
+// cluster and the 4th smallest minimum of a lane is its 4th or 5th nearest sample row.  Entries beyond the sample are -1
+// (padding rows: never candidates).  Any order is valid -- the seed only has to have sample rows at or below it.
+__global__ void sample_map(const int *__restrict__ rperm, int64_t n_s, int R, int64_t n_img, int *__restrict__ sperm) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // position in the sample image
-    const int64_t n_img = n_s + (cmk2::BR - head);
     if (p >= n_img) return;
-    int64_t i = p < head ? p : (p < cmk2::BR ? -1 : p - (cmk2::BR - head));
-    sperm[p] = i < 0 ? -1 : (rperm ? rperm[i * R] : (int)(i * R));
+    // (row r of sub-tile st holds sample row ((r - st) mod 32) n_st + st: consecutive sample rows go to consecutive sub-tiles AND
+    //  rotate through the 32 rows of a sub-tile, whose two 16-row halves belong to the two lanes of a query -- the seed is the
+    //  larger of the two lanes' 4th entries, so a cluster all of whose rows sat in one half would not seed at all)
+    const int64_t n_st = n_img / 32, st = p / 32, r = p % 32;
+    const int64_t i = ((r - st) & 31) * n_st + st;
+    sperm[p] = i < n_s ? (rperm ? rperm[i * R] : (int)(i * R)) : -1;
+}
+
+// Dense seeding scan of a single-pass pruned stage: every R2-th tile of each run of a chained item.  The seeding kernel walks
+// "strided tile numbers" u (tile = R2 u: P1Args::perm_mul), so run (t0, t1) becomes (ceil(t0 / R2), ceil(t1 / R2)): the
+// multiples of R2 inside [t0, t1) -- distinct tiles for distinct runs (the runs of a block are disjoint).
+__global__ void ivf_seed_runs(const int2 *__restrict__ runs, int n_runs, int R2, int2 *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const int2 t = runs[r];
+    out[r] = make_int2((t.x + R2 - 1) / R2, (t.y + R2 - 1) / R2);
+}
+
+// thr[i] = min(thr[i], dense seed [+ widen x the plain hi*hi bound: see ivf_plan_b]) -- the starting thresholds of the one pass
+__global__ void seed_combine(float *__restrict__ thr, const float *__restrict__ dense, int64_t n, const float *__restrict__ qn1,
+                             const float *__restrict__ qlo1, float c_eps1, float widen_mul, const unsigned *__restrict__ gmax,
+                             const float *__restrict__ scale3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = dense[i];
+    if (!(s < INFINITY)) return;
+    if (widen_mul > 0.f) {
+        const double ymax = (double)__uint_as_float(gmax[1]), rho_y = (double)__uint_as_float(gmax[5]);
+        const double q1 = (double)qn1[i];
+        const double e1 = (double)c_eps1 * (ymax * ymax + 2.0 * q1 * ymax + 1e-30) + 2.0 * 1.001 * ymax * ((double)qlo1[i] + q1 * rho_y);
+        const double w = (double)s + (double)widen_mul * e1 / (double)scale3[2];
+        s = (float)w;
+        if ((double)s < w) s = nextafterf(s, INFINITY);
+    }
+    thr[i] = fminf(thr[i], s);
 }
 
 __global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
@@ -2026,34 +2082,46 @@ __global__ void fill_f32(float *__restrict__ p, int64_t n, float v) {
 // config-2 shape, 10 ms, most of them several times over.  A (bucket, tile) pair is now CLAIMED (one byte per pair, zeroed once
 // per call) by the first workgroup that reaches it; everybody else skips the tile.  The values of a pair are the same whoever
 // computes them.
-template <typename T>
-__global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, int64_t n_ref, int d, int metric,
-                                                      const double *__restrict__ mean, const int *__restrict__ rperm,
-                                                      const double *__restrict__ cen, const int *__restrict__ blk_bucket,
-                                                      const int4 *__restrict__ wl, int n_items,
-                                                      const float *__restrict__ scale3, int64_t stride,
-                                                      float *__restrict__ side, unsigned *__restrict__ claimed, int n_tiles,
-                                                      const int2 *__restrict__ runs /* chained items: (block, first run, end run, .) */) {
-    __shared__ double s_c[64];
-    __shared__ unsigned s_mine;
+// (round 5, second form: MARK then COMPUTE.  The first form had every (item, slice) workgroup walk its tiles and claim each with
+//  an atomic behind two barriers -- 98 k workgroups x 9 tiles, 4 ms per call at the config-2 shape for 0.1 ms of arithmetic.)
+// cen_side_mark: one bit per (bucket, tile) pair the work list visits, in `want` (bits of a bucket start at a word boundary:
+// wpb words per bucket); pairs whose values exist (`done`) are left out.
+__global__ __launch_bounds__(128) void cen_side_mark(const int *__restrict__ blk_bucket, const int4 *__restrict__ wl, int n_items,
+                                                     const unsigned *__restrict__ done, unsigned *__restrict__ want, int wpb,
+                                                     const int2 *__restrict__ runs /* chained items: (block, first run, end run, .) */) {
     if ((int)blockIdx.x >= n_items) return;
     const int4 w = wl[blockIdx.x];
-    const int j = blk_bucket[w.x];
-    if (threadIdx.x < 64) s_c[threadIdx.x] = (int)threadIdx.x < d ? cen[(size_t)j * d + threadIdx.x] : 0.0;
-    const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
+    const size_t base = (size_t)blk_bucket[w.x] * (size_t)wpb;
     const int n_runs = runs ? w.z - w.y : 1;
     for (int rr = 0; rr < n_runs; ++rr) {
-    const int t_b = runs ? runs[w.y + rr].x : w.y, t_e = runs ? runs[w.y + rr].y : w.z;
-    for (int t = t_b + (int)blockIdx.y; t < t_e; t += (int)gridDim.y) {
-        __syncthreads();   // (s_c is ready; the previous tile's readers of s_mine are done)
-        if (threadIdx.x == 0) {
-            // one bit per (bucket, tile) pair in 32-bit words: atomicOr returns the old word
-            const size_t bit = (size_t)j * (size_t)n_tiles + (size_t)t;
-            const unsigned m = 1u << (bit & 31);
-            s_mine = (atomicOr(&claimed[bit >> 5], m) & m) == 0u ? 1u : 0u;
+        const int t_b = runs ? runs[w.y + rr].x : w.y, t_e = runs ? runs[w.y + rr].y : w.z;
+        // one thread per 32-tile word of the run
+        for (int wd = (t_b >> 5) + (int)(blockIdx.y * blockDim.x + threadIdx.x); wd <= ((t_e - 1) >> 5); wd += (int)(gridDim.y * blockDim.x)) {
+            const int lo = wd * 32 < t_b ? t_b - wd * 32 : 0, hi = (wd + 1) * 32 > t_e ? t_e - wd * 32 : 32;
+            unsigned m = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+            m &= ~done[base + wd];
+            if (m & ~want[base + wd]) atomicOr(&want[base + wd], m);
         }
-        __syncthreads();
-        if (!s_mine) continue;
+    }
+}
+
+// cen_side_compute: workgroup (word, bucket) computes the side values of the marked pairs of its word (same arithmetic as
+// cen_side), then moves the bits from `want` to `done` (it owns the word).
+template <typename T>
+__global__ __launch_bounds__(128) void cen_side_compute(const T *__restrict__ R, int64_t n_ref, int d, int metric,
+                                                        const double *__restrict__ mean, const int *__restrict__ rperm,
+                                                        const double *__restrict__ cen, const float *__restrict__ scale3, int64_t stride,
+                                                        float *__restrict__ side, unsigned *__restrict__ done,
+                                                        unsigned *__restrict__ want, int wpb) {
+    __shared__ double s_c[64];
+    const int j = blockIdx.y, wd = blockIdx.x;
+    const unsigned m = want[(size_t)j * wpb + wd];   // (uniform)
+    if (!m) return;
+    if (threadIdx.x < 64) s_c[threadIdx.x] = (int)threadIdx.x < d ? cen[(size_t)j * d + threadIdx.x] : 0.0;
+    __syncthreads();
+    const double m2 = -2.0 * (double)scale3[0] * (double)scale3[0];
+    for (unsigned rest = m; rest; rest &= rest - 1u) {
+        const int t = wd * 32 + __builtin_ctz(rest);
         const int64_t r = (int64_t)t * cmk2::BR + threadIdx.x;   // (BR = 128 rows per tile = one per thread)
         if (r >= stride) continue;
         double dot = 0.0;
@@ -2070,7 +2138,8 @@ __global__ __launch_bounds__(128) void cen_side_items(const T *__restrict__ R, i
         }
         side[(size_t)j * stride + r] = (float)(m2 * dot);
     }
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) { done[(size_t)j * wpb + wd] |= m; want[(size_t)j * wpb + wd] = 0u; }
 }
 
 __global__ void strided_rows(int *__restrict__ out, int n, int64_t stride) {
@@ -2254,7 +2323,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
     int64_t n_packed = 0, side_stride = 0;
     bool side_full = false;   // side values computed for every (bucket, reference row) pair
-    unsigned *side_claimed = nullptr;   // (bucket, tile) pairs whose side values exist already (cen_side_items)
+    unsigned *side_claimed = nullptr;   // (bucket, tile) pairs whose side values exist already + pairs wanted by the current work list (cen_side_mark)
     // bucket pruning (ivf_*): full-set stages of the K <= 64 MFMA levels; state built on first use
     const bool hint_same = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric;
     // (the "did not pay" memory belongs to one problem: same (d, k, metric) AND the same set sizes)
@@ -2271,10 +2340,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     float *ivf_cthr = nullptr;
     size_t ivf_list_cap = 0;   // candidate lists (entries of Kc_max ints) ivf_cand / ivf_cthr hold
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
+    int ivf_passes = 0;   // ... and its form: 1 = single pass from sample-scan seeds, 2 = pass A + pass B
     // sample-seeded thresholds of the plain full scan (see run_stage)
     char *seed_img = nullptr;
     int *seed_map = nullptr;
     float *seed_thr = nullptr;
+    float *seed2_thr = nullptr;  // dense seeds of a single-pass pruned stage (every R2-th tile of the block's runs)
+    int2 *seed2_runs = nullptr;
+    char *Qs = nullptr;          // plain query image / norms for the sample scan of a bucket-centred single-pass stage
+    float *qn_s = nullptr, *qlo_s = nullptr;
     bool last_seeded = false;   // the last stage ran from seeded thresholds: a failure may hold fewer than k candidates
     // level 0 state: the grid over the reference rows is built on first use
     void *grid_info = nullptr;
@@ -2439,7 +2513,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
@@ -2480,11 +2554,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             }
         }
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
+        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 22, 1);  // flagged queries without a finite bound
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
         const int *rr_cand = cand;
         const float *rr_cthr = cthr;
         int rr_S = p2.S, rr_ncap = 0;
-        bool pruned = false;
+        bool pruned = false, sample_done = false;
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
             const int op = lp_metric ? (metric == CM_METRIC_MANHATTAN ? 1 : (metric == CM_METRIC_CHEBYSHEV ? 2 : (metric == CM_METRIC_CANBERRA ? 3 : 4))) : 0;
@@ -2504,6 +2579,47 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 return cm_p1f16q_launch(h, p2.KSTEPS, (int)(nw < res ? nw : res), p2.lds, y);
             }
             return cm_p1f16_launch(h, p2.KSTEPS, p2.grid, p2.lds, x);
+        };
+        // Sample scan (threshold seeding): a value with at least m = 8 rows of a 1/R row sample at or below it, per query
+        // (knn_cand_f16 in seeding mode: two lanes per query, each keeping its 4 smallest sub-tile minima in registers -- no
+        // lists, no merges).  The number of sample rows among the query's k nearest is ~Binomial(k, 1/R) ~ Poisson(k/R); the
+        // seed is too tight (fewer than k rows below it) only if that number reaches m.  R = the smallest power of two from 16
+        // on with P(Poisson(k/R) >= m) < 1e-7 (k = 30: R = 64, seed at rank ~ 8*64 of the full set): a retry stage is then a
+        // rarity, and the result never depends on it (certificate + escalation).  Qimg: PLAIN (not bucket-centred) query rows.
+        auto sample_scan = [&](const cmk2::P1Args &base, const _Float16 *Qimg) -> cm_status {
+            const int m = 8, L = 4;
+            int R = 16;
+            for (; R < 4096; R *= 2) {
+                const double x = (double)k / R;
+                double pterm = exp(-x), cum = pterm;
+                for (int j = 1; j < m; ++j) { pterm *= x / j; cum += pterm; }
+                if (1.0 - cum < 1e-7) break;
+            }
+            const int64_t n_s = (n_ref + R - 1) / R;
+            const int n_s_tiles = (int)((n_s + cmk2::BR - 1) / cmk2::BR);
+            const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
+            if (!seed_img) {
+                seed_img = (char *)cm_ws_alloc(h, (size_t)n_s_tiles * tb1);
+                seed_map = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_s_tiles * cmk2::BR);
+                seed_thr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)(nq_pad + pack_slack + 1024));
+                if (!seed_img || !seed_map || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+            }
+            hipLaunchKernelGGL(sample_map, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R,
+                               (int64_t)n_s_tiles * cmk2::BR, seed_map);
+            hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), prep_lds, st, d_ref, (int64_t)n_s_tiles * cmk2::BR, d,
+                               p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
+                               (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr, (const double *)nullptr,
+                               (const int *)nullptr, (float *)nullptr, (float *)nullptr, (int)prep_lds);
+            cmk2::P1Args sa = base;
+            sa.Q = Qimg; sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1;
+            sa.cand = nullptr; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
+            sa.side = nullptr; sa.blk_bucket = nullptr;   // (a bucket-centred stage seeds from the plain hi*hi values)
+            sa.wlist = nullptr; sa.n_wlist = 0; sa.wruns = nullptr; sa.wctr = nullptr; sa.thr0 = nullptr; sa.thr0_slot0 = 0; sa.no_sched = 0;
+            sa.seed_len = L;
+            if (d_ctr) sa.ctr = d_ctr + 16;   // (diagnostics: the sample scan counts separately)
+            const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
+            CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, lds_s, sa));
+            return CM_OK;
         };
         // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
         // must never be dropped for holding too many (its only way out would be the exact scan with a loose bound)
@@ -2570,7 +2686,128 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                     if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
                 }
             }
-            if (ivf_try) {
+            auto side_items = [&](const int4 *wl, int n_items, const int2 *runs = nullptr) {   // centred level: side values of the pairs a list visits
+                if (!cenl || side_full || n_items < 1) return;
+                // (side_claimed: two bitmaps, one bit per (bucket, tile) pair each, allocated and zeroed with the side values in setup_centred)
+                const int wpb = (pf.n_tiles + 31) / 32 + 1;
+                hipLaunchKernelGGL(cen_side_mark, dim3((unsigned)n_items, 1), dim3(128), 0, st, (const int *)blk_bucket, wl, n_items,
+                                   (const unsigned *)side_claimed, side_claimed + (size_t)LS_CMAX * wpb, wpb, runs);
+                hipLaunchKernelGGL(cen_side_compute<T>, dim3((unsigned)wpb, LS_CMAX), dim3(128), 0, st, d_ref, n_ref, d, metric,
+                                   (const double *)d_mean, (const int *)rperm, (const double *)cen, (const float *)scale3, side_stride, side,
+                                   side_claimed, side_claimed + (size_t)LS_CMAX * wpb, wpb);
+            };
+            // Single-pass pruned stage (round 5): the radii of the plan come from a SAMPLE SCAN instead of pass A.  Pass A ran
+            // every block over its nearest bucket from +inf thresholds -- the start-up churn of a scan plus a list finalisation
+            // per block, as long as pass B itself (2 x 22.5 ms at the 40-cluster config-2 shape) -- only to learn a radius.
+            // The sample scan (every R-th row of the sorted reference, 2 ms) gives every query a value with >= 8 sample rows at
+            // or below it: in input units plus the hi*hi error bound that is a radius D_q with >= 8 reference rows inside, and
+            // the ONE chained pass that follows starts every query's threshold at its seed.
+            // Exactness: D_q = (the threshold the query STARTS from, in input units) + |q'|^2 + this level's filter error bound;
+            // a bucket is skipped for a block only if every row in it is farther than max D_q (+ margins) from every query of
+            // the block, i.e. its value on this level's filter exceeds the query's starting threshold -- such a row could not
+            // have entered a list that starts there, so the lists are those of an unpruned seeded scan, and a seed that was
+            // too tight ends, as there, with fewer than k candidates and the query moves on.  Where the seed came from does
+            // not enter the argument.
+            const bool single = chain && marks && ivf_try && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed &&
+                                !(dbg & 512);   // (CELLMAP_DBG=512: the two-pass form -- A/B, tests)
+            if (single) {
+                const _Float16 *Qplain = a.Q;
+                const float *qn_p = qnorm, *qlo_p = qlo;
+                if (cenl) {   // the centred stage's query image holds q' - c: the sample scan needs the plain rows
+                    if (!Qs) {
+                        Qs = (char *)cm_ws_alloc(h, (size_t)(nq_pad + pack_slack) * 256);
+                        qn_s = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));
+                        qlo_s = (float *)cm_ws_alloc(h, sizeof(float) * (nq_pad + pack_slack));
+                        if (!Qs || !qn_s || !qlo_s) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                    }
+                    hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)((p2.nq_pad + bs - 1) / bs)), dim3(bs), prep_lds, st, d_qry, nsub, d,
+                                       p2.KSTEPS, p2.nq_pad, 0, metric, scale3, (const double *)d_mean, Qs, qn_s, (unsigned *)nullptr,
+                                       wide ? 1 : 0, 0, qmap, qlo_s, (const double *)nullptr, (const int *)nullptr, (float *)nullptr,
+                                       (float *)nullptr, (int)prep_lds);
+                    Qplain = reinterpret_cast<const _Float16 *>(Qs); qn_p = qn_s; qlo_p = qlo_s;
+                }
+                CM_TRY(sample_scan(a, Qplain));
+                sample_done = !cenl;
+                hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
+                const float c_eps1 = (float)(16 * p2.KSTEPS + (wide ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // analytic hi*hi constant (below)
+                const bool widen = cenl || level != 1;   // a more precise filter than the seeds': see ivf_plan_b
+                hipLaunchKernelGGL(ivf_plan_b, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
+                                   (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, qmap, nsub,
+                                   (const float *)seed_thr, 1, (const float *)qnorm, (const float *)qlo,
+                                   cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
+                                   (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
+                                   (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, 256, ivf_sb, qblk, ivf_runs, 1,
+                                   qn_p, qlo_p, c_eps1, widen ? seed_thr : (float *)nullptr, cm_get_knobs().seed_widen);
+                CM_HIP(h, hipGetLastError());
+                int *hc = h->d_nflag_pinned + 4;
+                CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+                CM_HIP(h, hipStreamSynchronize(st));
+                unsigned long long tiles;
+                memcpy(&tiles, hc + 2, 8);
+                const unsigned long long full = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
+                if (dbg & 16)
+                    fprintf(stderr, "[cellmap dbg] bucket pruning (single pass): %llu of %llu (block, tile) pairs to visit, %d runs for %d of %d blocks\n",
+                            tiles, full, hc[1], hc[0], p2.nqb);
+                if (tiles * 8ull <= full) {
+                    // (a block without a run -- seeds too tight for any bucket -- writes nothing: empty lists for everybody first)
+                    CM_HIP(h, hipMemsetAsync(cand, 0xff, sizeof(int) * (size_t)p2.nq_pad * p2.Kc, st));
+                    hipLaunchKernelGGL(fill_f32, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, cthr, (int64_t)p2.nq_pad, INFINITY);
+                    if (hc[0] > 0) {
+                        // Dense seeds.  The sample-scan seed sits at rank ~8 R (512 at k = 30) of the full set; the pass over a
+                        // block's own cluster then appends that many rows per query before its lists tighten -- at the
+                        // 40-cluster config-2 shape 328 appends and 7 merges per query, 70 % of the pass (in-kernel counters),
+                        // for 2.4 % of the pairs.  So the items' runs are first walked in seeding mode over every R2-th TILE
+                        // (10-entry lists: >= 20 rows of a 1/R2 sample at or below the seed; R2 = the smallest power of two
+                        // with P(Poisson(k / R2) >= 20) < 1e-7 -- 8 at k = 30: rank ~160), no lists, no merges, 1/R2 of the
+                        // MFMA work of the pass; the pass starts from the smaller of the two seeds.  (The plan above used the
+                        // looser one, so nothing it ruled out can enter a list that starts lower still.)
+                        const bool dense = (level == 1 || cenl) && !wide && !(dbg & 1024);   // (hi-only tile image; CELLMAP_DBG=1024: off -- A/B)
+                        if (dense) {
+                            int R2 = 2;
+                            for (; R2 < 64; R2 *= 2) {
+                                const double x = (double)k / R2;
+                                double pterm = exp(-x), cum = pterm;
+                                for (int j = 1; j < 20; ++j) { pterm *= x / j; cum += pterm; }
+                                if (1.0 - cum < 1e-7) break;
+                            }
+                            if (!seed2_thr) {
+                                seed2_thr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)(nq_pad + pack_slack + 1024));
+                                seed2_runs = (int2 *)cm_ws_alloc(h, sizeof(int2) * (size_t)nqb_max * 136);
+                                if (!seed2_thr || !seed2_runs) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                            }
+                            hipLaunchKernelGGL(fill_f32, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, seed2_thr, (int64_t)p2.nq_pad, INFINITY);
+                            hipLaunchKernelGGL(ivf_seed_runs, dim3((unsigned)((hc[1] + 255) / 256)), dim3(256), 0, st, (const int2 *)ivf_runs, hc[1], R2, seed2_runs);
+                            cmk2::P1Args sd = a;
+                            sd.Q = Qplain; sd.S = 1; sd.cand = nullptr; sd.cthr = seed2_thr; sd.nprod = 1;
+                            sd.perm_mul = (unsigned)R2;
+                            sd.side = nullptr; sd.blk_bucket = nullptr;
+                            sd.wlist = ivf_wlb; sd.n_wlist = hc[0]; sd.wruns = seed2_runs; sd.wctr = ivf_ctr + 10;
+                            sd.thr0 = nullptr; sd.thr0_slot0 = 0; sd.no_sched = 0; sd.seed_len = 10;
+                            if (d_ctr) sd.ctr = d_ctr + 16;
+                            const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
+                            const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
+                            CM_TRY(cm_p1f16_seed10_launch(h, p2.KSTEPS, p2.grid, lds_s, sd));
+                            hipLaunchKernelGGL(seed_combine, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, seed_thr, (const float *)seed2_thr,
+                                               (int64_t)nsub, qn_p, qlo_p, c_eps1, widen ? cm_get_knobs().seed_widen : 0.f, (const unsigned *)words,
+                                               (const float *)scale3);
+                        }
+                        cmk2::P1Args b = a;
+                        b.S = 1; b.perm_mul = 1;
+                        b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.wruns = ivf_runs; b.wctr = ivf_ctr + 9;
+                        b.thr0 = seed_thr; b.thr0_slot0 = 0; b.no_sched = 1;
+                        side_items(ivf_wlb, hc[0], (const int2 *)ivf_runs);
+                        CM_TRY(launch(b));
+                    }
+                    pruned = true;
+                    rr_S = 1;
+                    last_seeded = !cenl;   // (failures of a plain level retry it unseeded, as after a seeded full scan; the centred level has no subset form)
+                    if (marks) { ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull)); ivf_passes = 1; }
+                } else if (tiles * 3ull > full) {   // hopeless; between an eighth and a third pass A's tighter radii (rank K' instead of ~8 R) may still get there
+                    ivf_try = false;
+                    if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
+                }
+            }
+            if (ivf_try && !pruned) {
             hipLaunchKernelGGL(ivf_plan_a, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_rcen,
                                (const int *)r_bstart, C, d, 2 * p2.Kc, p2.n_tiles, BRt, ivf_wla, ivf_jstar);
             const int64_t n_ent = (int64_t)p2.nq_pad * use_S;
@@ -2596,13 +2833,6 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                    16.0 * (double)(d + 4) * 5.9604645e-8, ivf_cthr);
                 b.thr0_slot0 = 1;
             }
-            auto side_items = [&](const int4 *wl, int n_items, const int2 *runs = nullptr) {   // centred level: side values of the pairs a list visits
-                if (!cenl || side_full || n_items < 1) return;
-                // (side_claimed: one bit per (bucket, tile) pair, allocated and zeroed with the side values in setup_centred)
-                hipLaunchKernelGGL(cen_side_items<T>, dim3((unsigned)n_items, runs ? 32 : 4), dim3(128), 0, st, d_ref, n_ref, d, metric,   // (a chained item holds all the runs of its block)
-                                   (const double *)d_mean, (const int *)rperm, (const double *)cen, (const int *)blk_bucket, wl,
-                                   n_items, (const float *)scale3, side_stride, side, side_claimed, pf.n_tiles, runs);
-            };
             side_items(ivf_wla, p2.nqb);
             CM_TRY(launch(b));
             // long runs are halved for load balance -- but every half is one more candidate list per query for the re-rank to
@@ -2615,7 +2845,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                cenl ? (const float *)qnc : (const float *)nullptr, cenl ? (const float *)qcen : (const float *)nullptr,
                                (const unsigned *)words, (const float *)scale3, c_eps, level, (const int4 *)ivf_wla,
                                (const int *)ivf_jstar, ivf_wlb, ivf_ctr, BRt, sizeof(T) == 8 ? 1 : 0, d, split_len, ivf_sb, qblk,
-                               chain ? ivf_runs : (int2 *)nullptr);
+                               chain ? ivf_runs : (int2 *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, 0.f, (float *)nullptr, 0.f);
             CM_HIP(h, hipGetLastError());
             int *hc = h->d_nflag_pinned + 4;
             CM_HIP(h, hipMemcpyAsync(hc, ivf_ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2643,7 +2873,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 // the last level that would be the exact scan, so there the capacity covers every list
                 const bool last_level = level == 4 || (level == 3 && !have_direct);
                 rr_ncap = std::min(RR_NCMAX, (chain ? 2 : (last_level ? ivf_sb + 1 : 6)) * p2.Kc);
-                if (marks) ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull));
+                if (marks) { ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull)); ivf_passes = 2; }
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
                 if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
@@ -2663,41 +2893,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                               !forced && !(flags & CM_KNN_FORCE_FALLBACK) &&   // (pinned levels do not escalate: a seed failure would have nowhere to go)
                               !cm_get_knobs().no_seed;
             if (seed) {
-                // Seed = a value with at least m = 8 rows of a 1/R row sample at or below it (knn_cand_f16 in seeding mode:
-                // two lanes per query, each keeping its 4 smallest sub-tile minima in registers -- no lists, no merges).
-                // The number of sample rows among the query's k nearest is ~Binomial(k, 1/R) ~ Poisson(k/R); the seed is
-                // too tight (fewer than k rows below it) only if that number reaches m.  R = the smallest power of two
-                // from 16 on with P(Poisson(k/R) >= m) < 1e-7 (k = 30: R = 64, seed at rank ~ 8*64 of the full set): a
-                // retry stage is then a rarity, and the result never depends on it (certificate + escalation).
-                const int m = 8, L = 4;
-                int R = 16;
-                for (; R < 4096; R *= 2) {
-                    const double x = (double)k / R;
-                    double pterm = exp(-x), cum = pterm;
-                    for (int j = 1; j < m; ++j) { pterm *= x / j; cum += pterm; }
-                    if (1.0 - cum < 1e-7) break;
-                }
-                const int64_t n_s = (n_ref + R - 1) / R;
-                const int n_s_tiles = (int)((n_s + cmk2::BR - 1) / cmk2::BR);
-                const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
-                if (!seed_img) {
-                    seed_img = (char *)cm_ws_alloc(h, (size_t)n_s_tiles * tb1);
-                    seed_map = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_s);
-                    seed_thr = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)p2.nq_pad);
-                    if (!seed_img || !seed_map || !seed_thr) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-                }
-                hipLaunchKernelGGL(sample_map, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, st, (const int *)rperm, n_s, R, cmk2::BR, seed_map);
-                hipLaunchKernelGGL(prep_rows_f16<T>, dim3((unsigned)(((int64_t)n_s_tiles * cmk2::BR + bs - 1) / bs)), dim3(bs), prep_lds, st, d_ref, n_s, d,
-                                   p2.KSTEPS, (int64_t)n_s_tiles * cmk2::BR, 1, metric, scale3, (const double *)d_mean, seed_img, (float *)nullptr,
-                                   (unsigned *)nullptr, wide ? 1 : 0, 1, (const int *)seed_map, (float *)nullptr, (const double *)nullptr,
-                                   (const int *)nullptr, (float *)nullptr, (float *)nullptr, (int)prep_lds);
-                cmk2::P1Args sa = a;
-                sa.R = seed_img; sa.n_tiles = n_s_tiles; sa.tiles_per_split = n_s_tiles; sa.S = 1;
-                sa.cand = nullptr; sa.cthr = seed_thr; sa.nprod = 1; sa.perm_mul = 1;
-                sa.seed_len = L;
-                if (d_ctr) sa.ctr = d_ctr + 16;   // (diagnostics: the sample scan counts separately)
-                const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
-                CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, lds_s, sa));
+                if (!sample_done) CM_TRY(sample_scan(a, a.Q));   // (a single-pass pruned attempt that did not pay left its seeds)
                 a.thr0 = seed_thr;
                 a.no_sched = 1;
             }
@@ -2734,10 +2930,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (marks) cm_mark(h, 3);
         return CM_OK;
     };
+    int64_t n_unbounded = 0;   // of the flagged queries of the last stage: those without a finite bound
     auto read_flags = [&](int64_t *n) -> cm_status {
         CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 15, words + 22, sizeof(int), hipMemcpyDeviceToHost, st));
         CM_HIP(h, hipStreamSynchronize(st));
         *n = h->d_nflag_pinned[0];
+        n_unbounded = h->d_nflag_pinned[15];
         return CM_OK;
     };
 
@@ -2760,7 +2959,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         side = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)C * side_stride);
         qnc = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
         qcen = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)n_packed);
-        const size_t claim_words = ((size_t)C * (size_t)pf.n_tiles + 31) / 32 + 1;   // one bit per (bucket, tile) pair: cen_side_items
+        const size_t claim_words = 2 * (size_t)C * (size_t)((pf.n_tiles + 31) / 32 + 1);   // one bit per (bucket, tile) pair, twice (done / wanted): cen_side_mark
         side_claimed = (unsigned *)cm_ws_alloc(h, sizeof(unsigned) * claim_words);
         if (!pstart || !qpack || !blk_bucket || !cen || !side || !qnc || !qcen || !side_claimed) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
         CM_HIP(h, hipMemsetAsync(side_claimed, 0, sizeof(unsigned) * claim_words, st));
@@ -2774,7 +2973,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         hipLaunchKernelGGL(cen_pack, dim3((unsigned)((n_packed + 255) / 256)), dim3(256), 0, st, (const int *)qperm, (const int *)q_bstart,
                            (const int *)pstart, C, n_packed, qpack, blk_bucket);
         CM_HIP(h, hipGetLastError());
-        return CM_OK;   // (the side values are computed by the stage that needs them: side_full_compute / cen_side_items)
+        return CM_OK;   // (the side values are computed by the stage that needs them: side_full_compute / cen_side_mark + cen_side_compute)
     };
 
     // ---- choose the level the whole set starts at
@@ -2836,14 +3035,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (dbg & 16) {
             unsigned gc[4] = {0, 0, 0, 0};
             (void)hipMemcpy(gc, words + 12, 16, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld queries uncertified (grid give-ups: <k %u, >cap %u, >K' %u)\n",
-                    stage, level, (long long)nf, (long long)nsub, gc[0], gc[1], gc[2]);
+            fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld queries uncertified, %lld without a bound (grid give-ups: <k %u, >cap %u, >K' %u)\n",
+                    stage, level, (long long)nf, (long long)nsub, (long long)n_unbounded, gc[0], gc[1], gc[2]);
         }
         if (nf == 0) break;
         // the sliced exact scan is cheaper than another stage for a handful of queries -- except after the grid stage,
         // whose give-ups carry no usable bound (no candidates were evaluated for them)
         // ... nor after a seeded stage: a query whose seed was too tight may hold fewer than k candidates (bound = inf)
-        if (nf <= 64 && level != 0 && !last_seeded) break;
+        // (round 5: counted, not assumed -- the re-rank counts the flagged queries whose bound is still +inf)
+        if (nf <= cm_get_knobs().fb_max && level != 0 && n_unbounded == 0) break;
         qmap = flag_out;
         nsub = nf;
         if (ivf_try && flag_s && nf >= 65536) {   // group the flagged queries by bucket: the next stage can prune as well
@@ -2900,7 +3100,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     h->knn_stats[1] = main_Kc;
     h->knn_stats[2] = main_S + 100 * start + 10000 * main_variant;
-    h->knn_stats[3] = (wide ? 4 : (lowp ? 3 : 2)) + 100 * ivf_pct;
+    h->knn_stats[3] = (wide ? 4 : (lowp ? 3 : 2)) + 100 * ivf_pct + 100000 * ivf_passes;
     return CM_OK;
 }
 
@@ -3136,6 +3336,8 @@ size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t 
              cm_align(8 * nqb * IVF_CSTR) + cm_align(8 * nqb) + 3 * cm_align(4 * nqb) + cm_align(16 * nqb) * (IVF_SB + 1) +
              cm_align(8 * (size_t)256 * IVF_CSTR) + 8192;
         b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;
+        if (d + cmk2::NORM_SLOTS <= 64)   // single-pass pruned stage at the bucket-centred level: plain query image + norms for the sample scan
+            b += cm_align(nqp * 256) + 2 * cm_align(4 * nqp) + cm_align(4 * (nqp + 1024));
     }
     return b + (b >> 6);
 }

@@ -1,0 +1,21 @@
+// Instantiations of the split-fp16 phase-1 kernel (knn_phase1_f16.h) in its threshold-seeding mode with 10-entry lists: the
+// dense seeding scan of a single-pass pruned stage (knn_kernels.hip, knn_run_staged: every R2-th tile of a block's own runs).
+// Own translation unit: build time.
+#include "cm_internal.h"
+#include "knn_phase1_f16.h"
+
+template <int KSTEPS>
+static cm_status launch_seed10(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
+    auto kern = cmk2::knn_cand_f16<KSTEPS, 1, false, 10>;
+    CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
+    CM_HIP(h, hipGetLastError());
+    return CM_OK;
+}
+
+cm_status cm_p1f16_seed10_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
+    if (a.seed_len != 10 || a.nprod != 1) CM_FAIL(h, CM_E_INTERNAL, "phase1/seed: 10-entry lists of the hi*hi level only");
+    if (KSTEPS == 2) return launch_seed10<2>(h, grid, lds, a);
+    if (KSTEPS == 4) return launch_seed10<4>(h, grid, lds, a);
+    CM_FAIL(h, CM_E_INTERNAL, "phase1/seed: no instantiation for KSTEPS=%d", KSTEPS);
+}

@@ -183,7 +183,8 @@ cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
  *          + 10000 * (filter kernel of the main stage: 1 two-accumulator split-fp16 (512-query blocks), 2 four-accumulator (1 024-query
  *          blocks), 3 its 16x16x32 re-tile, 4 the K = 128 three-product kernel, 5 direct VALU; 0 = grid / other families),
  * out[3] = filter family (1 f32-input MFMA, 2 split-fp16 MFMA K <= 64, 3 direct VALU / grid, 4 split-fp16 MFMA K = 128)
- *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning),
+ *          + 100 * (per cent of the (query block, reference tile) pairs the main stage visited; 0 = no bucket pruning)
+ *          + 100000 * (form of the pruned main stage: 1 = one pass from sample-scan seeds, 2 = pass A + pass B; 0 = not pruned),
  * out[4] = 1 if the exact fallback overflowed (more than 16 384 queries of one call each had more than 4 096 rows
  *          within their bound -- up to that many take a selection pass and are exact; beyond it lists are truncated:
  *          cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that synchronise the

@@ -461,8 +461,10 @@ def test_bucket_pruning_in_subset_stages_float64(hip, oracle, monkeypatch):
                                                     (50, 15, 0.6, np.float32, "cosine"), (24, 50, 1.0, np.float32, "euclidean")])
 def test_chained_pass_b_is_exact(hip, oracle, monkeypatch, d, k, sigma, dtype, metric):
     """Round 5: with four or more query blocks per compute unit the runs of a block's pass B are scanned by ONE work item into
-    ONE candidate list (P1Args::wruns; 2 lists per query instead of 14).  Forced here at a test size (CELLMAP_DBG=256): identical
-    to one list per run (CELLMAP_DBG=128) and to the unpruned search on EVERY row, identical to the oracle on a sample."""
+    ONE candidate list (P1Args::wruns; 2 lists per query instead of 14), and the main stage goes further: no pass A at all, the
+    plan's radii come from a sample scan and ONE chained pass starts from those seeds.  Both forced here at a test size
+    (CELLMAP_DBG=256; +512 = keep pass A): identical to one list per run (CELLMAP_DBG=128) and to the unpruned search on EVERY
+    row, identical to the oracle on a sample."""
     from parity import assert_knn_parity
 
     rng = np.random.default_rng(166 + d)
@@ -472,7 +474,7 @@ def test_chained_pass_b_is_exact(hip, oracle, monkeypatch, d, k, sigma, dtype, m
     qry = (cen[rng.integers(0, 40, nq)] + sigma * rng.standard_normal((nq, d))).astype(dtype)
     monkeypatch.setenv("CELLMAP_NO_HINT", "1")
     res = {}
-    for tag, dbg in (("chained", "256"), ("per_run", "128")):
+    for tag, dbg in (("chained", "768"), ("single", "256"), ("per_run", "128")):
         monkeypatch.setenv("CELLMAP_DBG", dbg)
         res[tag] = hip.knn(ref, qry, k, metric=metric) + (hip.knn_stats(),)
     monkeypatch.delenv("CELLMAP_DBG")
@@ -480,7 +482,8 @@ def test_chained_pass_b_is_exact(hip, oracle, monkeypatch, d, k, sigma, dtype, m
     res["unpruned"] = hip.knn(ref, qry, k, metric=metric) + (hip.knn_stats(),)
     assert res["chained"][2]["tiles_visited_pct"] > 0 and res["per_run"][2]["tiles_visited_pct"] > 0 and res["unpruned"][2]["tiles_visited_pct"] == 0, \
         [r[2] for r in res.values()]
-    for tag in ("per_run", "unpruned"):
+    assert [res[t][2]["pruning_passes"] for t in ("chained", "single", "per_run", "unpruned")] == [2, 1, 2, 0], [r[2] for r in res.values()]
+    for tag in ("single", "per_run", "unpruned"):
         assert np.array_equal(res["chained"][1], res[tag][1]) and np.array_equal(res["chained"][0], res[tag][0]), tag
     sel = rng.choice(nq, 300, replace=False)
     if metric == "cosine":
