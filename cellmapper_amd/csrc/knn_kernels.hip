@@ -1217,27 +1217,55 @@ __global__ void init_bounds(double *bound, float *seedb, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { bound[i] = INFINITY; seedb[i] = INFINITY; }
 }
-// thr0[pos] = seed of the query the packed position holds (positions beyond the subset: +inf)
+// thr0[pos] = seed of the query the packed position holds (positions beyond the subset: +inf).
+// qnorm != nullptr (round 5: seeds left by the bucket-centred level): the seed carries twice the error of the level that left
+// it, which bounds the next level's only where that level is the less precise one -- here the seed gets twice the TARGET
+// level's own bound (knn_rerank's, with the global |y'| maximum) on top, so the k rows behind the bound stay below it and
+// the certificate has its room whatever level the seed came from.
 __global__ void seed_gather(const float *__restrict__ seedb, const int *__restrict__ qmap, int64_t nsub, int64_t n_pad,
-                            float *__restrict__ thr0) {
+                            float *__restrict__ thr0, const float *__restrict__ qnorm = nullptr, const float *__restrict__ qlo = nullptr,
+                            const unsigned *__restrict__ gmax = nullptr, const float *__restrict__ scale3 = nullptr, float c_eps = 0.f,
+                            int level = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     float v = INFINITY;
     if (i < nsub) { const int q = qmap[i]; if (q >= 0) v = seedb[q]; }
+    if (qnorm && v < INFINITY) {
+        const double ymax = (double)__uint_as_float(gmax[1]), rho_y = (double)__uint_as_float(gmax[5]);
+        const double qn = (double)qnorm[i];
+        const double eps = (double)c_eps * (ymax * ymax + 2.0 * qn * ymax + 1e-30) +
+                           2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qn * rho_y : 0.0));
+        const double w = (double)v + 2.0 * eps / (double)scale3[2];
+        v = (float)w;
+        if ((double)v < w) v = nextafterf(v, INFINITY);
+    }
     thr0[i] = v;
 }
 // the same into slot 0 of the bucket-pruned stage's per-query threshold slots (stride S): pass A starts from it.  direct != 0:
 // the direct-difference filter ranks by the distance value itself (cosine rows are normalised: 2 x the cosine distance), so
 // its seed is the query's bound plus that filter's relative error.
 __global__ void seed_scatter_slot0(const float *__restrict__ seedb, const double *__restrict__ bound, const int *__restrict__ qmap,
-                                   int64_t nsub, int S, int direct, int is_cosine, double crel, float *__restrict__ cthr) {
+                                   int64_t nsub, int S, int direct, int is_cosine, double crel, float *__restrict__ cthr,
+                                   const float *__restrict__ qnorm = nullptr, const float *__restrict__ qlo = nullptr,
+                                   const unsigned *__restrict__ gmax = nullptr, const float *__restrict__ scale3 = nullptr,
+                                   float c_eps = 0.f, int level = 0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsub) return;
     const int q = qmap[i];
     if (q < 0) return;
     float v = INFINITY;
-    if (!direct) v = seedb[q];
-    else {
+    if (!direct) {
+        v = seedb[q];
+        if (qnorm && v < INFINITY) {   // (seeds of the bucket-centred level: + twice this level's own bound, as in seed_gather)
+            const double ymax = (double)__uint_as_float(gmax[1]), rho_y = (double)__uint_as_float(gmax[5]);
+            const double qn = (double)qnorm[i];
+            const double eps = (double)c_eps * (ymax * ymax + 2.0 * qn * ymax + 1e-30) +
+                               2.0 * 1.001 * ymax * ((level == 1 ? (double)qlo[i] : 0.0) + (level <= 2 ? qn * rho_y : 0.0));
+            const double w = (double)v + 2.0 * eps / (double)scale3[2];
+            v = (float)w;
+            if ((double)v < w) v = nextafterf(v, INFINITY);
+        }
+    } else {
         const double b = bound[q];
         if (b < INFINITY) {
             const double x = (is_cosine ? 2.0 * b : b) * (1.0 + crel) + 1e-30;
@@ -2182,7 +2210,17 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
 
     KnnPlan2 pf;   // plan of the full query set at level 1 (widest candidate lists): sizes the buffers
     CM_TRY(make_plan2(h, n_ref, nq, d, k, 1, 1, &pf));
-    const int Kc_max = pf.Kc + 16;   // (+16: the bucket-centred level uses k + max(30, k) candidates)
+    // Long lists at the bucket-centred level (round 5).  A single list of K' = k + max(k, 30) candidates certifies a query only if
+    // its k-th and K'-th neighbours lie farther apart than twice the filter error; on very tight clusters (sigma 0.1 at a
+    // spread of 5: 93 % of 1.5 M queries) they do not, the level was written off (hint -5) and the direct-difference level
+    // took the whole set: 297 ms.  With 80 more candidates the centred level certifies 97 % of that set and the call takes
+    // 86 ms -- at the price of a re-rank that gathers 140 candidates instead of 60 (19 ms instead of 6), which is why the
+    // long lists are not the default: the level is first tried with the short lists; if it fails for most queries the handle
+    // remembers "centred, long lists" (hint 6) for the next call of the same shape, and only if that fails too, -5.
+    const bool cen_long = !cm_get_knobs().no_hint && h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
+                          h->staged_hint_level == 6 && k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL <= 512;
+    const int kc5_extra = cen_long ? 80 : 0;
+    const int Kc_max = pf.Kc + 16 + kc5_extra;   // (+16: the bucket-centred level uses k + max(30, k) candidates)
     const int64_t nq_pad = pf.nq_pad;
     // subsets may use more reference splits than the full set: rows of the candidate buffers
     // (x up to 4 reference splits of the four-accumulator stage, see run_stage; bounded for very large query sets)
@@ -2382,6 +2420,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int last_Kc = Kc_max, last_S = 1, last_variant = 0;   // (variant: which filter kernel the stage launched, see cm_knn_stats)
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     int seeds_from_level = 0;   // level of the stage whose re-rank wrote the current per-query seeds (0: none)
+    int64_t n_unbounded = 0;   // of the flagged queries of the last stage: those without a finite bound (read_flags)
     auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
         int level = level_in;
         last_seeded = false;
@@ -2408,8 +2447,20 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         CM_TRY(make_plan2(h, n_ref, nsub, d, k, level == 4 ? 2 : (w3 ? 3 : 1), level == 4 ? 3 : level, &p2));
         if (wide) p2.KSTEPS = cmk2::KSTEPS_W;
         if (cenl) {   // the centred level keeps a wider candidate list: its residual error is dominated by bucket quality
-            const int kc2 = k + (k > 30 ? k : 30);
+            const int kc2 = k + (k > 30 ? k : 30) + kc5_extra;
             if (kc2 <= Kc_max && kc2 + 2 * cmk2::CL <= 512) p2.Kc = kc2;   // (every candidate buffer is sized for Kc_max)
+        }
+        // ... and so does the three-product stage that takes over its failures (round 5): those are queries of tight clusters
+        // whose k-th and K'-th neighbours lie closer together than the filter errors, and their seeds -- bounds plus error
+        // margins -- admit dozens of rows per list.  With k + 8 candidates (the plain three-product slack) 3 % of the 98 k
+        // queries the centred level left at sigma 0.2 failed again and took a direct-difference stage (45 ms in all); with the
+        // centred level's list length none did (11.5 ms).
+        if (!cenl && level == 3 && !w3 && !marks && !pilot && seeds_from_level == 5) {
+            const int kc2 = k + (k > 30 ? k : 30);
+            if (kc2 <= Kc_max && kc2 + 2 * cmk2::CL <= 512 && kc2 > p2.Kc) {
+                p2.Kc = kc2;
+                while (p2.S > 1 && p2.S * p2.Kc > RR_NCMAX) { p2.tps = (p2.n_tiles + p2.S - 2) / (p2.S - 1); p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps; }
+            }
         }
         // Four accumulators per wave (knn_phase1_q4.h) for large full-set scans of the hi*hi level at K = 64: 1 024-query
         // blocks, so the padded query count is rounded up accordingly (every buffer carries that slack) and the 512-query
@@ -2506,6 +2557,33 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * (p2.tileb + (cenl ? 1024 : 0)) + 64;
             }
         }
+        // Subset stages start from what their queries already know (see the unpruned launch below).  Seeds of the plain levels
+        // 1..3 serve a level at least as precise as the one that left them; seeds of the bucket-centred level (round 5) serve
+        // the plain MFMA levels with the target level's own error added (seed_gather).
+        const bool sub_seed_ok = !marks && !pilot && rerank && qmap && !cenl && level != 4 && !w3 && !forced &&
+                                 ((seeds_from_level >= 1 && seeds_from_level <= 3 && seeds_from_level <= level) || seeds_from_level == 5) &&
+                                 !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
+        // Small seeded subsets (round 5): a stage of one or a few query blocks used to split the reference 13 - 16 ways (what
+        // S x K' <= RR_NCMAX allows) -- 16 work items on 256 compute units, 8 ms for the 379 queries the centred level left
+        // at the 40-cluster config-2 shape (sigma 0.3).  Every query of such a subset starts from a FINITE seed (counted:
+        // n_unbounded == 0), so its lists hold a few rows beyond k in all: the reference is split as many ways as fills the
+        // chip and the re-rank compacts the S mostly empty lists into RR_NCMAX slots (as after a pruned stage; a query
+        // with more is left to the next level).
+        bool wide_split = false;
+        if (sub_seed_ok && n_unbounded == 0 && !q4 && !(dbg & 2048)) {   // (CELLMAP_DBG=2048: off -- A/B)
+            const int res = h->n_cu > 0 ? h->n_cu : 256;
+            const int resident = res * (8 / cmk2::NW);
+            int Sw = resident / std::max(p2.nqb, 1);
+            Sw = std::min(Sw, std::min(256, p2.n_tiles / 16));
+            while (Sw > p2.S && (int64_t)p2.nq_pad * Sw > cand_rows) --Sw;
+            if (Sw >= 2 * p2.S) {
+                p2.tps = (p2.n_tiles + Sw - 1) / Sw;
+                p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps;
+                const int64_t nw = (int64_t)p2.nqb * p2.S;
+                p2.grid = (int)(nw < resident ? nw : resident);
+                wide_split = true;
+            }
+        }
         if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
         cmk2::P1Args a;
         a.Q = reinterpret_cast<const _Float16 *>(Qp);
@@ -2513,7 +2591,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
@@ -2558,7 +2636,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
         const int *rr_cand = cand;
         const float *rr_cthr = cthr;
-        int rr_S = p2.S, rr_ncap = 0;
+        int rr_S = p2.S, rr_ncap = wide_split ? RR_NCMAX : 0;
         bool pruned = false, sample_done = false;
         const bool full_set = qmap && (qmap == (const int *)qperm || qmap == (const int *)qpack || qmap == (const int *)flag_s);
         auto launch = [&](const cmk2::P1Args &x) -> cm_status {
@@ -2624,7 +2702,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
         // must never be dropped for holding too many (its only way out would be the exact scan with a loose bound)
         const int ivf_sb = std::min(IVF_SB, RR_NCMAX / p2.Kc - 1);
-        if (ivf_try && full_set && !pilot && rerank && ivf_sb >= 2 && nsub >= 65536) {
+        if (ivf_try && full_set && !pilot && rerank && ivf_sb >= 2 && nsub >= (marks ? 65536 : cm_get_knobs().ivf_submin)) {
             const int qblk = (int)(p2.nq_pad / std::max(p2.nqb, 1));   // queries per work item of this stage's filter kernel (512; 256: knn_cand_f16w, direct rows beyond 64 floats)
             const int BRt = level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR;   // reference rows per tile of this level's image
 
@@ -2777,25 +2855,27 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                             }
                             hipLaunchKernelGGL(fill_f32, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, seed2_thr, (int64_t)p2.nq_pad, INFINITY);
                             hipLaunchKernelGGL(ivf_seed_runs, dim3((unsigned)((hc[1] + 255) / 256)), dim3(256), 0, st, (const int2 *)ivf_runs, hc[1], R2, seed2_runs);
+                            // (the scan runs THIS stage's filter -- for a bucket-centred stage the centred one, on the side values
+                            //  of the runs' tiles -- so its seeds are values the pass itself will compute: no widening, and none of
+                            //  the plain filter's noise, which on tight clusters (sigma <= 0.2 x the spread / 25) exceeds the gaps
+                            //  between the k-th and the K'-th neighbour: seeds from noisy values landed between the two for most
+                            //  queries, the lists ended short of K' with the seed as their threshold, and 93 % failed the certificate)
+                            side_items(ivf_wlb, hc[0], (const int2 *)ivf_runs);
                             cmk2::P1Args sd = a;
-                            sd.Q = Qplain; sd.S = 1; sd.cand = nullptr; sd.cthr = seed2_thr; sd.nprod = 1;
+                            sd.S = 1; sd.cand = nullptr; sd.cthr = seed2_thr; sd.nprod = 1;
                             sd.perm_mul = (unsigned)R2;
-                            sd.side = nullptr; sd.blk_bucket = nullptr;
                             sd.wlist = ivf_wlb; sd.n_wlist = hc[0]; sd.wruns = seed2_runs; sd.wctr = ivf_ctr + 10;
                             sd.thr0 = nullptr; sd.thr0_slot0 = 0; sd.no_sched = 0; sd.seed_len = 10;
                             if (d_ctr) sd.ctr = d_ctr + 16;
-                            const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
-                            const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
-                            CM_TRY(cm_p1f16_seed10_launch(h, p2.KSTEPS, p2.grid, lds_s, sd));
+                            CM_TRY(cm_p1f16_seed10_launch(h, p2.KSTEPS, p2.grid, p2.lds, sd));
                             hipLaunchKernelGGL(seed_combine, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, seed_thr, (const float *)seed2_thr,
-                                               (int64_t)nsub, qn_p, qlo_p, c_eps1, widen ? cm_get_knobs().seed_widen : 0.f, (const unsigned *)words,
-                                               (const float *)scale3);
+                                               (int64_t)nsub, qn_p, qlo_p, c_eps1, 0.f, (const unsigned *)words, (const float *)scale3);
                         }
                         cmk2::P1Args b = a;
                         b.S = 1; b.perm_mul = 1;
                         b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.wruns = ivf_runs; b.wctr = ivf_ctr + 9;
                         b.thr0 = seed_thr; b.thr0_slot0 = 0; b.no_sched = 1;
-                        side_items(ivf_wlb, hc[0], (const int2 *)ivf_runs);
+                        if (!dense) side_items(ivf_wlb, hc[0], (const int2 *)ivf_runs);
                         CM_TRY(launch(b));
                     }
                     pruned = true;
@@ -2825,12 +2905,14 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             //  error), float32 inputs only -- float64 inputs add a coordinate-rounding term the seed does not model)
             const bool seed_a = !marks && !pilot && rerank && qmap && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !w3 && !cenl &&
                                 seeds_from_level >= 1 && (level == 4 ? (sizeof(T) == 4 && seeds_from_level != 4)
-                                                                     : (seeds_from_level <= 3 && seeds_from_level <= level)) &&
+                                                                     : ((seeds_from_level <= 3 && seeds_from_level <= level) || seeds_from_level == 5)) &&
                                 !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
             if (seed_a) {
                 hipLaunchKernelGGL(seed_scatter_slot0, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, st, (const float *)seedb,
                                    (const double *)bound, qmap, nsub, use_S, level == 4 ? 1 : 0, metric == CM_METRIC_COSINE ? 1 : 0,
-                                   16.0 * (double)(d + 4) * 5.9604645e-8, ivf_cthr);
+                                   16.0 * (double)(d + 4) * 5.9604645e-8, ivf_cthr,
+                                   (level != 4 && seeds_from_level == 5) ? (const float *)qnorm : (const float *)nullptr, (const float *)qlo,
+                                   (const unsigned *)words, (const float *)scale3, c_eps, level);
                 b.thr0_slot0 = 1;
             }
             side_items(ivf_wla, p2.nqb);
@@ -2873,6 +2955,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 // the last level that would be the exact scan, so there the capacity covers every list
                 const bool last_level = level == 4 || (level == 3 && !have_direct);
                 rr_ncap = std::min(RR_NCMAX, (chain ? 2 : (last_level ? ivf_sb + 1 : 6)) * p2.Kc);
+                // (seeded subset stage: the seeds are bounds plus error margins, on tight clusters dozens of rows per list lie
+                //  below them -- 3 % of the 98 k queries the centred level left at sigma 0.2 overflowed 6 K' = 228 slots)
+                if (seed_a && !chain) rr_ncap = std::min(RR_NCMAX, std::max(rr_ncap, 512));
                 if (marks) { ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull)); ivf_passes = 2; }
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
@@ -2904,12 +2989,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // merges when a log fills.  Queries without a bound (fewer than k candidates so far) start from +inf.
             // (only after a level whose error bounds this level's from above: 1, 2, 3 -- not the bucket-centred level, whose
             //  error on tight clusters is far below the plain levels')
-            const bool sub_seed = !seed && !marks && !pilot && rerank && qmap && !cenl && level != 4 && !w3 && !forced &&
-                                  seeds_from_level >= 1 && seeds_from_level <= 3 && seeds_from_level <= level &&
-                                  !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
+            const bool sub_seed = !seed && sub_seed_ok;
             if (sub_seed) {
-                hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
-                                   (int64_t)p2.nq_pad, seed_sub);
+                if (seeds_from_level == 5)
+                    hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
+                                       (int64_t)p2.nq_pad, seed_sub, (const float *)qnorm, (const float *)qlo, (const unsigned *)words,
+                                       (const float *)scale3, c_eps, level);
+                else
+                    hipLaunchKernelGGL(seed_gather, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, (const float *)seedb, qmap, nsub,
+                                       (int64_t)p2.nq_pad, seed_sub);
                 a.thr0 = seed_sub;
                 a.no_sched = 1;
             }
@@ -2930,7 +3018,6 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (marks) cm_mark(h, 3);
         return CM_OK;
     };
-    int64_t n_unbounded = 0;   // of the flagged queries of the last stage: those without a finite bound
     auto read_flags = [&](int64_t *n) -> cm_status {
         CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 15, words + 22, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2980,12 +3067,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int start = lowp ? (have_grid ? 0 : 4) : 1;
     const bool hint_ok = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
                          !cm_get_knobs().no_hint;
-    const bool hinted = hint_ok && (h->staged_hint_level == 1 || (h->staged_hint_level == 5 && have_cen));
+    const bool hinted = hint_ok && (h->staged_hint_level == 1 || ((h->staged_hint_level == 5 || (h->staged_hint_level == 6 && cen_long)) && have_cen));
     const bool cen_bad = hint_ok && h->staged_hint_level == -5;   // the centred level failed for most queries last time
     if (lowp) {}   // grid or direct kernel: nothing to choose
     else if (forced) start = forced;
     else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
-    else if (hinted) start = h->staged_hint_level;   // that level certified most queries last time: no pilot
+    else if (hinted) start = h->staged_hint_level == 6 ? 5 : h->staged_hint_level;   // that level certified most queries last time: no pilot
     else if (no_structure) {}   // structure-free embeddings: nearest-neighbour distances are of the order of the data's spread, the
                                 // hi*hi level's error bound is far below the gaps it has to resolve -- and if not, the ladder escalates
     else if (n_pilot > 0 && !(dbg & 3)) {
@@ -3029,7 +3116,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (level == 5 && next == 3 && have_direct && nf * 5 > nsub && !cm_get_knobs().no_skip3) next_level = 4;
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
             const bool good = (level == 1 || level == 5) && nf * 2 <= nq;
-            h->staged_hint_level = good ? level : (level == 5 ? -5 : 0);
+            // (the centred level with short lists failed for most: next time with long lists; those failed too: not again)
+            h->staged_hint_level = good ? (level == 5 && cen_long ? 6 : level) : (level == 5 ? ((cen_long || k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL > 512) ? -5 : 6) : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
         }
         if (dbg & 16) {
@@ -3046,7 +3134,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (nf <= cm_get_knobs().fb_max && level != 0 && n_unbounded == 0) break;
         qmap = flag_out;
         nsub = nf;
-        if (ivf_try && flag_s && nf >= 65536) {   // group the flagged queries by bucket: the next stage can prune as well
+        if (ivf_try && flag_s && nf >= cm_get_knobs().ivf_submin) {   // group the flagged queries by bucket: the next stage can prune as well
             hipLaunchKernelGGL(zero_words, dim3(2), dim3(256), 0, st, (unsigned *)fl_cnt, 2 * LS_CMAX);
             hipLaunchKernelGGL(fl_labels, dim3((unsigned)((nf + LS_ROWS - 1) / LS_ROWS)), dim3(256), 0, st, (const int *)flag_out, nf,
                                (const int *)q_lab, fl_tmp, fl_cnt);
@@ -3328,7 +3416,8 @@ size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t 
     const int64_t nq_pad = (nq + 511) / 512 * 512;
     if (d + cmk2::NORM_SLOTS <= 64)   // bucket-centred level: packed maps, side values (LS_CMAX buckets)
         b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
-             cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192;
+             cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192 +
+             cm_align(8 * (size_t)256 * (size_t)(n_ref / (32 * cmk2::BR) + 2));   // (+ the two (bucket, tile) bitmaps of cen_side_mark)
     if (nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
         const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 256 + 1;
         const size_t lists = nq_pad / 512 >= 1024 ? 2 : IVF_SB + 1;   // (chained pass B from four blocks per compute unit on)
@@ -3338,6 +3427,7 @@ size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t 
         b += 3 * cm_align(4 * (size_t)(nq + 1)) + 8192;
         if (d + cmk2::NORM_SLOTS <= 64)   // single-pass pruned stage at the bucket-centred level: plain query image + norms for the sample scan
             b += cm_align(nqp * 256) + 2 * cm_align(4 * nqp) + cm_align(4 * (nqp + 1024));
+        b += cm_align(4 * (nqp + 1024)) + cm_align(8 * nqb * 136);   // dense seeds of the single-pass stage + their strided runs
     }
     return b + (b >> 6);
 }

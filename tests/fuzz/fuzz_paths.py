@@ -12,6 +12,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40); ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--wide", action="store_true", help="round 5: bias the draw towards the K = 128 family's pruned stages (62 <= d <= 128, clustered, >= 66 000 queries)")
+    ap.add_argument("--clustered", action="store_true", help="round 5: bias the draw towards pruned main stages of the K <= 64 family (30 - 60 clusters, >= 131 072 queries)")
     a = ap.parse_args()
     import torch
     from cellmapper_amd import _native
@@ -36,6 +37,13 @@ def main():
             ncl = int(rng.choice([8, 40, 40, 200]))
             sigma = float(rng.choice([0.05, 0.3, 0.6, 1.0]))
             k = int(rng.choice([1, 10, 30, 50, 100]))
+        if a.clustered:
+            d = int(rng.choice([16, 20, 24, 32, 40, 50, 61]))
+            n_ref = int(rng.choice([200_000, 300_000, 500_000]))
+            nq = int(rng.choice([131_072, 200_000, 300_000]))
+            ncl = int(rng.choice([30, 40, 60]))
+            sigma = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
+            k = int(rng.choice([1, 5, 10, 30, 50, 100]))
         def mk(n):
             x = torch.randn((n, d), generator=g, device=pipe.device, dtype=torch.float32)
             if ncl:
@@ -48,8 +56,9 @@ def main():
             os.environ.pop(v, None)
         os.environ["CELLMAP_Q4"] = "2" if case % 2 == 0 else "1"   # the four-accumulator filter wherever it exists / by its size rule
         # round 5: pass B of a pruned stage chained into one list per block (the rule needs >= 1 024 blocks: forced in two cases of three)
+        # ... and, in the main stage, no pass A at all (single pass from sample-scan seeds; +512 keeps pass A)
         if case % 3 != 2:
-            os.environ["CELLMAP_DBG"] = "256"
+            os.environ["CELLMAP_DBG"] = "256" if case % 3 == 0 else "768"
         else:
             os.environ.pop("CELLMAP_DBG", None)
         _native.reload_knobs()   # (the library latches the knobs in cm_create)
@@ -70,7 +79,7 @@ def main():
             ok = bool(torch.equal(d1, d2)) and bool((torch.sort(i1, 1).values == torch.sort(i2, 1).values).float().mean() > 0.9999)
         print(json.dumps(dict(case=case, d=d, k=k, n_ref=n_ref, nq=nq, metric=metric, f64=dt == torch.float64, clusters=ncl,
                               sigma=sigma, ok=ok, ms_default=round((t1 - t0) * 1e3, 1), ms_plain=round((t2 - t1) * 1e3, 1),
-                              level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], fb=st1["fallback_queries"],
+                              level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], passes=st1["pruning_passes"], fb=st1["fallback_queries"],
                               fb_plain=st2["fallback_queries"])), flush=True)
         if not ok:
             bad += 1
