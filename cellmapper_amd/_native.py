@@ -252,7 +252,9 @@ class Handle:
                     # bucket pruning: (query block, reference tile) pairs visited, per cent of a full scan (0 = not used)
                     tiles_visited_pct=(int(out[3]) // 100) % 1000, pruning_passes=int(out[3]) // 100000,
                     # 1 = a query's exact-fallback list overflowed (results truncated): device-tier callers must check
-                    fallback_overflow=int(out[4]))
+                    fallback_overflow=int(out[4]),
+                    # most reference splits a subset stage used (> 16: a small seeded subset split to fill the chip)
+                    subset_splits=int(out[5]))
 
     # ------------------------------------------------------------------ host tier (numpy in / numpy out)
     def knn(self, ref: np.ndarray, qry: np.ndarray, k: int, metric: str = "euclidean", form: str = "auto"):

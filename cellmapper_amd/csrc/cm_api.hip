@@ -612,7 +612,8 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]) {
     h->knn_stats[0] = h->d_nflag_pinned[0];
     for (int i = 0; i < 4; ++i) out[i] = h->knn_stats[i];
     out[4] = h->d_nflag_pinned[1];   // exact-fallback overflow (valid once the stream has been synchronised)
-    out[5] = out[6] = out[7] = 0;
+    out[5] = h->knn_sub_splits;
+    out[6] = out[7] = 0;
     return CM_OK;
 }
 

@@ -54,6 +54,7 @@ struct cm_handle_s {
     size_t ws_used = 0;   // bytes carved since the last reset
     size_t ws_peak = 0;   // ... largest value of that over the handle's life
     int64_t knn_stats[4] = {0, 0, 0, 0};
+    int64_t knn_sub_splits = 0;   // cm_knn_stats out[5]: most reference splits a subset stage of the last search used
     int n_cu = 0;   // compute units of the device (lazily queried)
     const void *a3_index = nullptr;   // last payload index whose header this handle has read (A3, wave-sliced kernel)
     int a3_max_slice = 0;             // ... its longest (payload row, column bucket) slice

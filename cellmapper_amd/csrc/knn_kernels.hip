@@ -2377,6 +2377,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int2 *ivf_runs = nullptr;
     float *ivf_cthr = nullptr;
     size_t ivf_list_cap = 0;   // candidate lists (entries of Kc_max ints) ivf_cand / ivf_cthr hold
+    h->knn_sub_splits = 0;
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
     int ivf_passes = 0;   // ... and its form: 1 = single pass from sample-scan seeds, 2 = pass A + pass B
     // sample-seeded thresholds of the plain full scan (see run_stage)
@@ -2569,8 +2570,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // n_unbounded == 0), so its lists hold a few rows beyond k in all: the reference is split as many ways as fills the
         // chip and the re-rank compacts the S mostly empty lists into RR_NCMAX slots (as after a pruned stage; a query
         // with more is left to the next level).
+        // (the direct-difference level too: its seed is the query's bound plus that filter's relative error, float32 inputs --
+        //  see seed_a below; 852 queries of the 40-cluster d = 128 shape took 38 ms on 16 work items)
+        const bool sub_seed4_ok = !marks && !pilot && rerank && qmap && level == 4 && !forced && sizeof(T) == 4 && seeds_from_level >= 1 &&
+                                  seeds_from_level != 4 && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
         bool wide_split = false;
-        if (sub_seed_ok && n_unbounded == 0 && !q4 && !(dbg & 2048)) {   // (CELLMAP_DBG=2048: off -- A/B)
+        if ((sub_seed_ok || sub_seed4_ok) && n_unbounded == 0 && !q4 && !(dbg & 2048)) {   // (CELLMAP_DBG=2048: off -- A/B)
             const int res = h->n_cu > 0 ? h->n_cu : 256;
             const int resident = res * (8 / cmk2::NW);
             int Sw = resident / std::max(p2.nqb, 1);
@@ -2585,6 +2590,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             }
         }
         if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
+        if (!marks && !pilot && p2.S > h->knn_sub_splits) h->knn_sub_splits = p2.S;
         cmk2::P1Args a;
         a.Q = reinterpret_cast<const _Float16 *>(Qp);
         a.R = Rp;
@@ -2989,6 +2995,14 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // merges when a log fills.  Queries without a bound (fewer than k candidates so far) start from +inf.
             // (only after a level whose error bounds this level's from above: 1, 2, 3 -- not the bucket-centred level, whose
             //  error on tight clusters is far below the plain levels')
+            if (sub_seed4_ok && wide_split) {   // direct level, small seeded subset: every split starts from slot 0 of the query's thresholds
+                const int64_t n_ent = (int64_t)p2.nq_pad * p2.S;
+                hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, cthr, n_ent, INFINITY);   // (padding rows: +inf)
+                hipLaunchKernelGGL(seed_scatter_slot0, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, st, (const float *)seedb,
+                                   (const double *)bound, qmap, nsub, p2.S, 1, metric == CM_METRIC_COSINE ? 1 : 0,
+                                   16.0 * (double)(d + 4) * 5.9604645e-8, cthr);
+                a.thr0_slot0 = 1;
+            }
             const bool sub_seed = !seed && sub_seed_ok;
             if (sub_seed) {
                 if (seeds_from_level == 5)
@@ -3067,7 +3081,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int start = lowp ? (have_grid ? 0 : 4) : 1;
     const bool hint_ok = h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
                          !cm_get_knobs().no_hint;
-    const bool hinted = hint_ok && (h->staged_hint_level == 1 || ((h->staged_hint_level == 5 || (h->staged_hint_level == 6 && cen_long)) && have_cen));
+    // (round 5: a set that STARTED on the three-product or the direct level and certified most of its queries there starts there
+    //  again -- its pilot, two sample stages over the whole reference, was 30 of the 230 ms of the 40-cluster d = 128 shape)
+    const bool hinted = hint_ok && (h->staged_hint_level == 1 || h->staged_hint_level == 3 || (h->staged_hint_level == 4 && have_direct) ||
+                                    ((h->staged_hint_level == 5 || (h->staged_hint_level == 6 && cen_long)) && have_cen));
     const bool cen_bad = hint_ok && h->staged_hint_level == -5;   // the centred level failed for most queries last time
     if (lowp) {}   // grid or direct kernel: nothing to choose
     else if (forced) start = forced;
@@ -3115,7 +3132,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         int next_level = next;
         if (level == 5 && next == 3 && have_direct && nf * 5 > nsub && !cm_get_knobs().no_skip3) next_level = 4;
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
-            const bool good = (level == 1 || level == 5) && nf * 2 <= nq;
+            const bool good = (level == 1 || level == 3 || level == 4 || level == 5) && nf * 2 <= nq;
             // (the centred level with short lists failed for most: next time with long lists; those failed too: not again)
             h->staged_hint_level = good ? (level == 5 && cen_long ? 6 : level) : (level == 5 ? ((cen_long || k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL > 512) ? -5 : 6) : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
@@ -3252,6 +3269,7 @@ cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_
     h->knn_stats[1] = CAP;
     h->knn_stats[2] = QG;
     h->knn_stats[3] = 5;
+    h->knn_sub_splits = 0;
     return CM_OK;
 }
 
@@ -3343,6 +3361,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     h->knn_stats[1] = Kc;
     h->knn_stats[2] = S;
     h->knn_stats[3] = 1;
+    h->knn_sub_splits = 0;
     return CM_OK;
 }
 

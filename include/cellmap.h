@@ -188,7 +188,9 @@ cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
  * out[4] = 1 if the exact fallback overflowed (more than 16 384 queries of one call each had more than 4 096 rows
  *          within their bound -- up to that many take a selection pass and are exact; beyond it lists are truncated:
  *          cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that synchronise the
- *          stream themselves must check it), out[5..7] reserved (0).  Read after the stream is idle. */
+ *          stream themselves must check it), out[5] = most reference splits a subset stage (uncertified queries on a
+ *          later filter level) used -- beyond 16: a small seeded subset split to fill the chip; out[6..7] reserved (0).
+ *          Read after the stream is idle. */
 cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
 
 /* ---------------------------------------------------------------- K0: exact k-NN ------------------

@@ -494,6 +494,59 @@ def test_chained_pass_b_is_exact(hip, oracle, monkeypatch, d, k, sigma, dtype, m
         assert np.array_equal(res["chained"][1][sel], oi) and np.array_equal(res["chained"][0][sel], od)
 
 
+def test_centred_level_retried_with_long_lists(hip, oracle, monkeypatch):
+    """Round 5: very tight clusters (sigma 0.1 at a spread of 5).  The bucket-centred level with its k + max(k, 30) candidates
+    certifies few queries (their k-th and K'-th neighbours lie closer together than the filter errors); the handle then
+    remembers "centred, long lists" and the NEXT call of the same shape runs the level with 80 more candidates, which
+    certifies most of them.  Both calls identical on every row, identical to the oracle on a sample."""
+    rng = np.random.default_rng(171)
+    d, k, n_ref, nq = 50, 30, 300_000, 150_000
+    cen = rng.standard_normal((40, d)) * 5.0
+    ref = (cen[rng.integers(0, 40, n_ref)] + 0.1 * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 40, nq)] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+    easy = rng.standard_normal((4096, d + 1)).astype(np.float32)
+    hip.knn(easy, easy[:512], k)            # (another shape: the handle forgets what it knew about this one)
+    monkeypatch.setenv("CELLMAP_DBG", "256")   # (single-pass pruned main stage at a test size)
+    d1, i1 = hip.knn(ref, qry, k)
+    st1 = hip.knn_stats()
+    d2, i2 = hip.knn(ref, qry, k)
+    st2 = hip.knn_stats()
+    assert st1["filter_products"] == 5 and st1["candidates"] == 60, st1
+    assert st2["filter_products"] == 5 and st2["candidates"] == 140 and st2["pruning_passes"] == 1, st2
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    sel = rng.choice(nq, 400, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(i2[sel], oi) and np.array_equal(d2[sel], od), st2
+
+
+@pytest.mark.parametrize("sigma", [2.0, 0.3])
+def test_small_seeded_subsets_split_the_reference_to_fill_the_chip(hip, oracle, monkeypatch, sigma):
+    """Round 5: the few hundred queries a main stage leaves uncertified all carry a finite bound (counted by the re-rank), so
+    their stage starts every list from a seed and splits the reference far beyond the 16 ways S x K' <= 1 024 allowed -- the
+    re-rank compacts the mostly empty lists.  Identical to the same search without the wide split (CELLMAP_DBG=2048) on every
+    row, identical to the oracle on a sample that contains the rows of that stage."""
+    rng = np.random.default_rng(173)
+    d, k, n_ref, nq = 50, 30, 400_000, 140_000
+    cen = rng.standard_normal((40, d)) * 5.0
+    ref = (cen[rng.integers(0, 40, n_ref)] + sigma * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 40, nq)] + sigma * rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    monkeypatch.setenv("CELLMAP_SLACK", "6")    # (short lists: a few hundred queries fail the first level's certificate)
+    monkeypatch.setenv("CELLMAP_DBG", "2048")
+    d0, i0 = hip.knn(ref, qry, k)
+    st0 = hip.knn_stats()
+    monkeypatch.delenv("CELLMAP_DBG")
+    d1, i1 = hip.knn(ref, qry, k)
+    st1 = hip.knn_stats()
+    assert 0 < st0["subset_splits"] <= 16 and st1["subset_splits"] >= st0["subset_splits"], (st0, st1)
+    if sigma == 2.0:   # (a few hundred failures: one or two query blocks; at sigma 0.3 the subset is too large for more splits)
+        assert st1["subset_splits"] > 16, (st0, st1)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    sel = rng.choice(nq, 300, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
+
+
 @pytest.mark.parametrize("d,sigma,dtype", [(128, 1.0, np.float32), (100, 0.3, np.float32), (72, 2.5, np.float64)])
 def test_wide_family_bucket_pruning_is_exact(hip, oracle, monkeypatch, d, sigma, dtype):
     """Round 5: the K = 128 family (62 <= d <= 128) prunes (query block, reference bucket) pairs like the K <= 64 kernels -- the
@@ -516,6 +569,15 @@ def test_wide_family_bucket_pruning_is_exact(hip, oracle, monkeypatch, d, sigma,
     st2 = hip.knn_stats()
     assert st2["tiles_visited_pct"] == 0, st2
     assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2), (st, st2)
+    # ... and the forms large sets take (chained runs; at the hi*hi level one pass from sample-scan seeds), forced at this size
+    monkeypatch.delenv("CELLMAP_NO_IVF")
+    monkeypatch.setenv("CELLMAP_DBG", "256")
+    dist3, idx3 = hip.knn(ref, qry, k)
+    st3 = hip.knn_stats()
+    monkeypatch.delenv("CELLMAP_DBG")
+    if sigma <= 1.0:
+        assert st3["tiles_visited_pct"] > 0 and st3["pruning_passes"] == (1 if st3["filter_products"] == 1 else 2), st3
+    assert np.array_equal(idx, idx3) and np.array_equal(dist, dist3), (st, st3)
     sel = rng.choice(nq, 400, replace=False)
     od, oi = oracle.knn_euclidean(ref, qry[sel], k)
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
