@@ -2670,7 +2670,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // seed is too tight (fewer than k rows below it) only if that number reaches m.  R = the smallest power of two from 16
         // on with P(Poisson(k/R) >= m) < 1e-7 (k = 30: R = 64, seed at rank ~ 8*64 of the full set): a retry stage is then a
         // rarity, and the result never depends on it (certificate + escalation).  Qimg: PLAIN (not bucket-centred) query rows.
-        auto sample_scan = [&](const cmk2::P1Args &base, const _Float16 *Qimg) -> cm_status {
+        auto sample_scan = [&](const cmk2::P1Args &base, const _Float16 *Qimg, int r_mul = 1) -> cm_status {
             const int m = 8, L = 4;
             int R = 16;
             for (; R < 4096; R *= 2) {
@@ -2679,6 +2679,9 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 for (int j = 1; j < m; ++j) { pterm *= x / j; cum += pterm; }
                 if (1.0 - cum < 1e-7) break;
             }
+            // (r_mul: a single-pass pruned stage with dense seeds needs this scan for the plan's radii only -- a 4 x coarser sample,
+            //  rank ~2 048 instead of ~512, widens the radii by 3 % at d = 50 and costs a quarter)
+            while (r_mul > 1 && R < 4096 && (n_ref + 2 * R - 1) / (2 * R) >= 64 * cmk2::BR) { R *= 2; r_mul /= 2; }
             const int64_t n_s = (n_ref + R - 1) / R;
             const int n_s_tiles = (int)((n_s + cmk2::BR - 1) / cmk2::BR);
             const size_t tb1 = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, true);
@@ -2810,7 +2813,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                        (float *)nullptr, (int)prep_lds);
                     Qplain = reinterpret_cast<const _Float16 *>(Qs); qn_p = qn_s; qlo_p = qlo_s;
                 }
-                CM_TRY(sample_scan(a, Qplain));
+                const bool dense_ok = (level == 1 || cenl) && !wide && !(dbg & 1024);   // (the dense seeding scan below exists for this stage)
+                CM_TRY(sample_scan(a, Qplain, dense_ok ? 4 : 1));
                 sample_done = !cenl;
                 hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
                 const float c_eps1 = (float)(16 * p2.KSTEPS + (wide ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // analytic hi*hi constant (below)
@@ -2845,7 +2849,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                         // with P(Poisson(k / R2) >= 20) < 1e-7 -- 8 at k = 30: rank ~160), no lists, no merges, 1/R2 of the
                         // MFMA work of the pass; the pass starts from the smaller of the two seeds.  (The plan above used the
                         // looser one, so nothing it ruled out can enter a list that starts lower still.)
-                        const bool dense = (level == 1 || cenl) && !wide && !(dbg & 1024);   // (hi-only tile image; CELLMAP_DBG=1024: off -- A/B)
+                        const bool dense = dense_ok;   // (hi-only tile image; CELLMAP_DBG=1024: off -- A/B)
                         if (dense) {
                             int R2 = 2;
                             for (; R2 < 64; R2 *= 2) {
