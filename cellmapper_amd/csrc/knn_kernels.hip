@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(256) void ivf_plan_a(const double *__restrict__ bce
 __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bcen, const double *__restrict__ brad,
                                                   const double *__restrict__ rcen, const double *__restrict__ rrad,
                                                   const int *__restrict__ r_bstart, int C, int d,
-                                                  const int *__restrict__ qmap, int64_t nsub, const float *__restrict__ cthr,
+                                                  const int *__restrict__ qmap, int64_t nsub, const float *cthr /* (may alias thr_out) */,
                                                   int S, const float *__restrict__ qnorm, const float *__restrict__ qlo,
                                                   const float *__restrict__ qnc, const float *__restrict__ qcen,
                                                   const unsigned *__restrict__ gmax, const float *__restrict__ scale3,
@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(256) void ivf_plan_b(const double *__restrict__ bce
                                                   int2 *__restrict__ runs /* chained mode: one item per block, its runs here */,
                                                   int seeds /* 1: single-pass stage -- cthr holds sample-scan seeds, no pass A */,
                                                   const float *__restrict__ qn1, const float *__restrict__ qlo1, float c_eps1,
-                                                  float *__restrict__ thr_out /* seeds of a more precise level: widened here */,
+                                                  float *thr_out /* seeds of a more precise level: widened here, in place (== cthr) */,
                                                   float widen_mul) {
     // sb <= IVF_SB: runs (candidate lists) per block this stage may use -- the re-rank holds (sb + 1) * K' candidates
     // level 4 (direct-difference fp32 filter): thresholds are full squared distances of the rows as given, with the
@@ -2597,7 +2597,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048); a.ctr = d_ctr;   // (bits 16 and 64 are host-side switches: the production kernel bodies stay selected)
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048);
+        a.ctr = d_ctr;   // (bits 16, 64, ... are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
         if (level != 4 && !w3 && p2.n_tiles > 8 && !cm_get_knobs().no_perm) {   // knn_cand_f16: scattered tile order
