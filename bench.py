@@ -404,6 +404,7 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
                                        "note": "cm_workspace_bytes_all_routes: the common route + what bucket pruning and the centred level add (reserved when the handle is set up)"},
            "first_call_stage_ms": st_first, "stage_ms_mean": {kk: vv / steps for kk, vv in acc.items()},
            "filter_level": fb.get("filter_products"), "filter_kernel": fb.get("filter_kernel"), "tiles_visited_pct": fb.get("tiles_visited_pct"),
+           "pruning_passes": fb.get("pruning_passes"),   # 1 = one pass from sample-scan seeds (round 5), 2 = pass A + pass B, 0 = not pruned
            "fallback_queries": fb.get("fallback_queries"), "candidates_per_query": fb.get("candidates"),
            "fallback_overflow": bool(overflow), "parity_check": rec}
     del ref, qry, out, code_t, conf_t, dist_t, idx_t
