@@ -2967,8 +2967,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 const bool last_level = level == 4 || (level == 3 && !have_direct);
                 rr_ncap = std::min(RR_NCMAX, (chain ? 2 : (last_level ? ivf_sb + 1 : 6)) * p2.Kc);
                 // (seeded subset stage: the seeds are bounds plus error margins, on tight clusters dozens of rows per list lie
-                //  below them -- 3 % of the 98 k queries the centred level left at sigma 0.2 overflowed 6 K' = 228 slots)
-                if (seed_a && !chain) rr_ncap = std::min(RR_NCMAX, std::max(rr_ncap, 512));
+                //  below them -- a fifth of the 42 k queries the long-list centred level left at sigma 0.1 overflowed 512 slots)
+                if (seed_a && !chain) rr_ncap = std::min(RR_NCMAX, (ivf_sb + 1) * p2.Kc);   // (every list in full: no overflow)
                 if (marks) { ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull)); ivf_passes = 2; }
             } else {
                 ivf_try = false;   // the buckets overlap too much: full scan, and do not try again for a while
