@@ -721,6 +721,8 @@ __global__ __launch_bounds__(256) void knn_rerank(const T *__restrict__ ref, con
         if (!certified || over || (flags & CM_KNN_FORCE_FALLBACK)) {
             int pos = atomicAdd(flag_cnt, 1);
             flag_list[pos] = (int)io;
+            if (over) atomicAdd(flag_cnt + 21, 1);            // (words[23], [24]: why -- diagnostics, CELLMAP_DBG=16)
+            else if (nc < k) atomicAdd(flag_cnt + 22, 1);
             if (seedb) {
                 const double b = fmin(bound[io], kth);
                 bound[io] = b;
@@ -2639,7 +2641,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             }
         }
         hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 2, 2);  // flag count, overflow
-        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 22, 1);  // flagged queries without a finite bound
+        hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, words + 22, 3);  // flagged queries without a finite bound; over capacity; fewer than k candidates
         if (marks) cm_mark(h, 1);   // everything before the main stage's filter launch (pilot included) counts as "prep"
         const int *rr_cand = cand;
         const float *rr_cthr = cthr;
@@ -3143,10 +3145,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
         }
         if (dbg & 16) {
-            unsigned gc[4] = {0, 0, 0, 0};
+            unsigned gc[4] = {0, 0, 0, 0}, why[2] = {0, 0};
             (void)hipMemcpy(gc, words + 12, 16, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld queries uncertified, %lld without a bound (grid give-ups: <k %u, >cap %u, >K' %u)\n",
-                    stage, level, (long long)nf, (long long)nsub, (long long)n_unbounded, gc[0], gc[1], gc[2]);
+            (void)hipMemcpy(why, words + 23, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld queries uncertified, %lld without a bound, %u over the re-rank's capacity, %u with fewer than k candidates (grid give-ups: <k %u, >cap %u, >K' %u)\n",
+                    stage, level, (long long)nf, (long long)nsub, (long long)n_unbounded, why[0], why[1], gc[0], gc[1], gc[2]);
         }
         if (nf == 0) break;
         // the sliced exact scan is cheaper than another stage for a handful of queries -- except after the grid stage,
