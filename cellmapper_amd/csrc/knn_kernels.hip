@@ -2424,6 +2424,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // one stage: filter `level` over the query subset qmap[0..nsub) (nullptr = all), re-rank + certify, failures -> flag_out
     int seeds_from_level = 0;   // level of the stage whose re-rank wrote the current per-query seeds (0: none)
     int64_t n_unbounded = 0;   // of the flagged queries of the last stage: those without a finite bound (read_flags)
+    int64_t n_over = 0;        // ... and those with more candidates than the re-rank's capacity
+    bool last_wide = false, no_wide = false;   // the last stage split the reference beyond 16 ways / no more such stages in this search
     auto run_stage = [&](int level_in, const int *qmap, int64_t nsub, int *flag_out, bool rerank, bool marks, bool pilot) -> cm_status {
         int level = level_in;
         last_seeded = false;
@@ -2577,7 +2579,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         const bool sub_seed4_ok = !marks && !pilot && rerank && qmap && level == 4 && !forced && sizeof(T) == 4 && seeds_from_level >= 1 &&
                                   seeds_from_level != 4 && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_subseed && !cm_get_knobs().no_seed;
         bool wide_split = false;
-        if ((sub_seed_ok || sub_seed4_ok) && n_unbounded == 0 && !q4 && !(dbg & 2048)) {   // (CELLMAP_DBG=2048: off -- A/B)
+        if ((sub_seed_ok || sub_seed4_ok) && n_unbounded == 0 && !q4 && !no_wide && !(dbg & 2048)) {   // (CELLMAP_DBG=2048: off -- A/B)
             const int res = h->n_cu > 0 ? h->n_cu : 256;
             const int resident = res * (8 / cmk2::NW);
             int Sw = resident / std::max(p2.nqb, 1);
@@ -2591,6 +2593,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 wide_split = true;
             }
         }
+        last_wide = wide_split;
         if ((int64_t)p2.nq_pad * p2.S > cand_rows) CM_FAIL(h, CM_E_INTERNAL, "k-NN: candidate buffer too small for a stage");
         if (!marks && !pilot && p2.S > h->knn_sub_splits) h->knn_sub_splits = p2.S;
         cmk2::P1Args a;
@@ -3041,10 +3044,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     };
     auto read_flags = [&](int64_t *n) -> cm_status {
         CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned, words + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 15, words + 22, sizeof(int), hipMemcpyDeviceToHost, st));
+        CM_HIP(h, hipMemcpyAsync(h->d_nflag_pinned + 14, words + 22, 2 * sizeof(int), hipMemcpyDeviceToHost, st));   // (pinned [14] is free between searches)
         CM_HIP(h, hipStreamSynchronize(st));
         *n = h->d_nflag_pinned[0];
-        n_unbounded = h->d_nflag_pinned[15];
+        n_unbounded = h->d_nflag_pinned[14];
+        n_over = h->d_nflag_pinned[15];
         return CM_OK;
     };
 
@@ -3124,6 +3128,23 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
         if (stage == 0) { main_Kc = last_Kc; main_S = last_S; main_variant = last_variant; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
+        // A wide split counts on lists that hold a few rows beyond k.  On very tight clusters the seeds' error margins admit
+        // hundreds of rows (sigma 0.1 at a spread of 5: more than the 1 024 the re-rank compacts, for 1 172 of 1 178 queries):
+        // those queries are not sent on to a coarser-grained level -- the stage is repeated for its flagged queries with the
+        // ordinary split count, whose lists the re-rank takes in full.
+        if (last_wide) {
+            int64_t nf0 = 0;
+            CM_TRY(read_flags(&nf0));
+            if (n_over > 0) {
+                if (dbg & 16) fprintf(stderr, "[cellmap dbg] stage %d level %d: %lld of %lld flagged queries over the re-rank's capacity after a wide split: the level again, ordinary splits\n",
+                                      stage, level, (long long)n_over, (long long)nf0);
+                qmap = flag_out; nsub = nf0;
+                flag_out = flag_out == flag_a ? flag_b : flag_a;
+                seeds_from_level = level;
+                no_wide = true;
+                continue;
+            }
+        }
         // (after a seeded stage the failures first get an unseeded pass of the same level: the image is in place, and
         // most of them only had a seed that was too tight)
         const int next = (forced || (flags & CM_KNN_FORCE_FALLBACK)) ? 0
