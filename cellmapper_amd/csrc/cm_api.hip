@@ -29,7 +29,7 @@ void latch_knobs() {
     auto on = [](const char *n) { return getenv(n) != nullptr; };
     k.dbg = (int)num("CELLMAP_DBG", 0);
     k.fb_max = (int)num("CELLMAP_FB_MAX", 64);
-    k.ivf_submin = (int)num("CELLMAP_IVF_SUBMIN", 65536);
+    k.ivf_submin = (int)num("CELLMAP_IVF_SUBMIN", 32768);
     if (const char *e = getenv("CELLMAP_SEED_WIDEN")) k.seed_widen = (float)atof(e);
     k.filter_products = (int)num("CELLMAP_FILTER_PRODUCTS", 0);
     k.q4 = (int)num("CELLMAP_Q4", 1);

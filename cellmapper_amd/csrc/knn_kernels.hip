@@ -2461,7 +2461,10 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // queries the centred level left at sigma 0.2 failed again and took a direct-difference stage (45 ms in all); with the
         // centred level's list length none did (11.5 ms).
         if (!cenl && level == 3 && !w3 && !marks && !pilot && seeds_from_level == 5) {
-            const int kc2 = k + (k > 30 ? k : 30);
+            // (+ the long lists' 80 when the centred stage ran with them: what even 140 candidates could not certify there -- the
+            //  hardest 3 % of the sigma 0.1 set -- fails a single list of 60 here for a fifth of the queries whenever the stage's
+            //  lists happen to hold a query's whole cluster in one: measured on the pruned form of the stage)
+            const int kc2 = k + (k > 30 ? k : 30) + (nsub >= cm_get_knobs().ivf_submin ? kc5_extra : 0);   // (small subsets certify with the short lists: 0 of 1 607 left at sigma 0.12)
             if (kc2 <= Kc_max && kc2 + 2 * cmk2::CL <= 512 && kc2 > p2.Kc) {
                 p2.Kc = kc2;
                 while (p2.S > 1 && p2.S * p2.Kc > RR_NCMAX) { p2.tps = (p2.n_tiles + p2.S - 2) / (p2.S - 1); p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps; }
@@ -3162,7 +3165,13 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         if (stage == 0 && !forced && !lowp) {   // remember whether the cheapest level is worth starting with next time
             const bool good = (level == 1 || level == 3 || level == 4 || level == 5) && nf * 2 <= nq;
             // (the centred level with short lists failed for most: next time with long lists; those failed too: not again)
-            h->staged_hint_level = good ? (level == 5 && cen_long ? 6 : level) : (level == 5 ? ((cen_long || k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL > 512) ? -5 : 6) : 0);
+            const bool long_ok = k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL <= 512;
+            if (level == 5 && !cen_long)
+                // (short lists: beyond a twelfth uncertified the long lists are cheaper than the stage that takes the failures --
+                //  measured at 1.5 M x 1.5 M: 6.5 % -> 12 ms for that stage against ~15 ms for the longer re-rank; 23 % -> 98 ms)
+                h->staged_hint_level = (nf * 12 > nq && long_ok) ? 6 : (good ? 5 : -5);
+            else
+                h->staged_hint_level = good ? (level == 5 ? 6 : level) : (level == 5 ? -5 : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
         }
         if (dbg & 16) {
