@@ -8,21 +8,21 @@ cd $R
 {
 echo "# Clustered route, round 5 (late): single-pass pruned main stage"
 echo
-echo "\`scripts/clustered_r5.sh\` on one MI355X box, library of commit $(cat $R/.build_commit 2>/dev/null || echo '(see PROVENANCE.json)').  40 Gaussian clusters, centres N(0, 5^2), within-cluster sigma as given,"
+echo "\`scripts/clustered_r5.sh\` on one MI355X box, library of the commit that carries this file.  40 Gaussian clusters, centres N(0, 5^2), within-cluster sigma as given,"
 echo "reference and queries share the centres; 1.5 M x 1.5 M, d = 50, k = 30, float32, \`scripts/bench_knn.py --reps 4\` (mean of the calls after the first;"
 echo "stage times of the last call).  \`CELLMAP_DBG=512\` keeps pass A + pass B (the round-4 form, chained pass B).  Stage lines: \`CELLMAP_DBG=16\`."
 echo
 echo "| sigma | form | k-NN ms | stages (ms) | main stage | uncertified after it | later stages |"
 echo "|---|---|---|---|---|---|---|"
 } > $O/report.md
-for sg in 2.0 1.0 0.5 0.3 0.2 0.1 0.05; do
+for sg in 2.0 1.0 0.5 0.3 0.2 0.17 0.15 0.12 0.1 0.05; do
 for dbg in 0 512; do
 CELLMAP_DBG=$((dbg+16)) timeout -k 10 300 python scripts/bench_knn.py --nq 1500000 --nref 1500000 --d 50 --k 30 --uniform 0 --clusters 40 --spread 5 --sigma $sg --reps 4 > $O/out.txt 2> $O/err.txt || exit 1
 python3 - "$sg" "$dbg" $O/out.txt $O/err.txt >> $O/report.md <<'PY'
 import sys, json, re
 sg, dbg, out, err = sys.argv[1:5]
 r = json.loads(open(out).read().strip().splitlines()[-1])
-lines = [l for l in open(err) if "cellmap dbg" in l and "stage " in l]
+lines = [l for l in open(err) if "cellmap dbg" in l and "stage " in l and "queries uncertified" in l]
 # the stage lines of the LAST call: from the last "stage 0" on
 last0 = max(i for i, l in enumerate(lines) if "stage 0 " in l)
 st = lines[last0:]
