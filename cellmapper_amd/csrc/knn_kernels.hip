@@ -2220,7 +2220,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // long lists are not the default: the level is first tried with the short lists; if it fails for most queries the handle
     // remembers "centred, long lists" (hint 6) for the next call of the same shape, and only if that fails too, -5.
     const bool cen_long = !cm_get_knobs().no_hint && h->staged_hint_d == d && h->staged_hint_k == k && h->staged_hint_metric == metric &&
-                          h->staged_hint_level == 6 && k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL <= 512;
+                          h->staged_hint_level == 6 && h->staged_long_nref == n_ref && h->staged_long_nq == nq &&   // (another data set of the same width starts with the short lists again)
+                          k + (k > 30 ? k : 30) + 80 + 2 * cmk2::CL <= 512;
     const int kc5_extra = cen_long ? 80 : 0;
     const int Kc_max = pf.Kc + 16 + kc5_extra;   // (+16: the bucket-centred level uses k + max(30, k) candidates)
     const int64_t nq_pad = pf.nq_pad;
@@ -3173,6 +3174,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             else
                 h->staged_hint_level = good ? (level == 5 ? 6 : level) : (level == 5 ? -5 : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
+            if (h->staged_hint_level == 6) { h->staged_long_nref = n_ref; h->staged_long_nq = nq; }
         }
         if (dbg & 16) {
             unsigned gc[4] = {0, 0, 0, 0}, why[2] = {0, 0};
