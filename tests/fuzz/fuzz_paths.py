@@ -44,14 +44,26 @@ def main():
             ncl = int(rng.choice([30, 40, 60]))
             sigma = float(rng.choice([0.1, 0.3, 0.6, 1.0]))
             k = int(rng.choice([1, 5, 10, 30, 50, 100]))
-        def mk(n):
+        # --clustered, odd cases: clusters of unequal size (Dirichlet weights), their own spread (0.3 .. 3 x sigma) and a random
+        # per-coordinate scale (anisotropic), queries drawn with OTHER weights than the reference
+        ragged = a.clustered and case % 2 == 1
+        def mk(n, w=None):
             x = torch.randn((n, d), generator=g, device=pipe.device, dtype=torch.float32)
             if ncl:
-                lab = torch.randint(0, ncl, (n,), generator=g, device=pipe.device)
-                x = cen[lab] + sigma * x
+                if ragged:
+                    lab = torch.multinomial(w, n, replacement=True, generator=g)
+                    x = cen[lab] + (sigma * csig[lab])[:, None] * x * aniso[None, :]
+                else:
+                    lab = torch.randint(0, ncl, (n,), generator=g, device=pipe.device)
+                    x = cen[lab] + sigma * x
             return x.to(dt)
         cen = torch.randn((max(ncl, 1), d), generator=g, device=pipe.device) * 5.0
-        ref, qry = mk(n_ref), mk(nq)
+        if ragged:
+            csig = torch.exp(torch.rand(ncl, generator=g, device=pipe.device) * 2.3 - 1.2)
+            aniso = torch.exp(torch.randn(d, generator=g, device=pipe.device) * 0.5)
+            wr = torch.distributions.Dirichlet(torch.full((ncl,), 0.7)).sample().to(pipe.device)
+            wq = torch.distributions.Dirichlet(torch.full((ncl,), 0.7)).sample().to(pipe.device)
+        ref, qry = (mk(n_ref, wr), mk(nq, wq)) if ragged else (mk(n_ref), mk(nq))
         for v in ("CELLMAP_NO_IVF", "CELLMAP_NO_SEED", "CELLMAP_NO_HINT"):
             os.environ.pop(v, None)
         os.environ["CELLMAP_Q4"] = "2" if case % 2 == 0 else "1"   # the four-accumulator filter wherever it exists / by its size rule
@@ -78,7 +90,7 @@ def main():
         if not ok and metric == "cosine":   # float32 cosine distances: ties at rounding level may swap equal-valued neighbours
             ok = bool(torch.equal(d1, d2)) and bool((torch.sort(i1, 1).values == torch.sort(i2, 1).values).float().mean() > 0.9999)
         print(json.dumps(dict(case=case, d=d, k=k, n_ref=n_ref, nq=nq, metric=metric, f64=dt == torch.float64, clusters=ncl,
-                              sigma=sigma, ok=ok, ms_default=round((t1 - t0) * 1e3, 1), ms_plain=round((t2 - t1) * 1e3, 1),
+                              sigma=sigma, ragged=bool(a.clustered and case % 2 == 1), ok=ok, ms_default=round((t1 - t0) * 1e3, 1), ms_plain=round((t2 - t1) * 1e3, 1),
                               level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], passes=st1["pruning_passes"], fb=st1["fallback_queries"],
                               fb_plain=st2["fallback_queries"])), flush=True)
         if not ok:
