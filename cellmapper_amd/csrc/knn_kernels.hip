@@ -2072,6 +2072,17 @@ __global__ void sample_map(const int *__restrict__ rperm, int64_t n_s, int R, in
     sperm[p] = i < n_s ? (rperm ? rperm[i * R] : (int)(i * R)) : -1;
 }
 
+// side values of the sample image's rows for the bucket-centred sample scan: row p of the image is sorted row i R (sample_map's
+// interleave), bucket j's value for it sits at side[j stride + i R]
+__global__ void side_sample_gather(const float *__restrict__ side, int64_t stride, int64_t n_s, int R, int64_t n_img,
+                                   float *__restrict__ side_s) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_img) return;
+    const int64_t n_st = n_img / 32, st = p / 32, r = p % 32;
+    const int64_t i = ((r - st) & 31) * n_st + st;
+    side_s[(size_t)blockIdx.y * n_img + p] = i < n_s ? side[(size_t)blockIdx.y * stride + i * R] : 0.f;
+}
+
 // Dense seeding scan of a single-pass pruned stage: every R2-th tile of each run of a chained item.  The seeding kernel walks
 // "strided tile numbers" u (tile = R2 u: P1Args::perm_mul), so run (t0, t1) becomes (ceil(t0 / R2), ceil(t1 / R2)): the
 // multiples of R2 inside [t0, t1) -- distinct tiles for distinct runs (the runs of a block are disjoint).
@@ -2387,6 +2398,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     char *seed_img = nullptr;
     int *seed_map = nullptr;
     float *seed_thr = nullptr;
+    float *side_s = nullptr;     // side values of the sample image's rows (bucket-centred sample scan)
     float *seed2_thr = nullptr;  // dense seeds of a single-pass pruned stage (every R2-th tile of the block's runs)
     int2 *seed2_runs = nullptr;
     char *Qs = nullptr;          // plain query image / norms for the sample scan of a bucket-centred single-pass stage
@@ -2606,7 +2618,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048);
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096);
         a.ctr = d_ctr;   // (bits 16, 64, ... are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
@@ -2680,7 +2692,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // seed is too tight (fewer than k rows below it) only if that number reaches m.  R = the smallest power of two from 16
         // on with P(Poisson(k/R) >= m) < 1e-7 (k = 30: R = 64, seed at rank ~ 8*64 of the full set): a retry stage is then a
         // rarity, and the result never depends on it (certificate + escalation).  Qimg: PLAIN (not bucket-centred) query rows.
-        auto sample_scan = [&](const cmk2::P1Args &base, const _Float16 *Qimg, int r_mul = 1) -> cm_status {
+        auto sample_scan = [&](const cmk2::P1Args &base, const _Float16 *Qimg, int r_mul = 1, bool cen_mode = false) -> cm_status {
             const int m = 8, L = 4;
             int R = 16;
             for (; R < 4096; R *= 2) {
@@ -2715,6 +2727,20 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             sa.seed_len = L;
             if (d_ctr) sa.ctr = d_ctr + 16;   // (diagnostics: the sample scan counts separately)
             const size_t lds_s = (size_t)cmk2::ring_depth(true, p2.KSTEPS) * tb1 + 64;
+            if (cen_mode) {
+                // bucket-centred sample scan (Qimg = the CENTRED query image): the sample rows' side values are gathered from the
+                // full side array, the seeds are values of the centred filter itself -- nothing to widen
+                const int64_t n_img = (int64_t)n_s_tiles * cmk2::BR;
+                if (!side_s) {
+                    side_s = (float *)cm_ws_alloc(h, sizeof(float) * (size_t)LS_CMAX * (size_t)n_img);
+                    if (!side_s) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                }
+                hipLaunchKernelGGL(side_sample_gather, dim3((unsigned)((n_img + 255) / 256), LS_CMAX), dim3(256), 0, st, (const float *)side,
+                                   side_stride, n_s, R, n_img, side_s);
+                sa.side = side_s; sa.side_stride = n_img; sa.blk_bucket = blk_bucket;
+                CM_TRY(cm_p1f16_seed10_launch(h, p2.KSTEPS, p2.grid, (size_t)cmk2::ring_depth(true, p2.KSTEPS) * (tb1 + 1024) + 64, sa));
+                return CM_OK;
+            }
             CM_TRY(cm_p1f16_launch(h, p2.KSTEPS, p2.grid, lds_s, sa));
             return CM_OK;
         };
@@ -2999,6 +3025,15 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                               !cm_get_knobs().no_seed;
             if (seed) {
                 if (!sample_done) CM_TRY(sample_scan(a, a.Q));   // (a single-pass pruned attempt that did not pay left its seeds)
+                a.thr0 = seed_thr;
+                a.no_sched = 1;
+            }
+            // ... and the unpruned bucket-centred stage (round 5, late: overlapping clusters -- ragged, anisotropic mixtures -- take the
+            // centred level WITHOUT pruning, 300 ms of unseeded scan at 1.5 M x 1.5 M) seeds from a centred scan of the same sample
+            const bool seed_c = marks && !pilot && rerank && cenl && p2.n_tiles >= 1024 && !forced && !(flags & CM_KNN_FORCE_FALLBACK) &&
+                                !cm_get_knobs().no_seed && !(dbg & 4096);   // (CELLMAP_DBG=4096: off -- A/B)
+            if (seed_c) {
+                CM_TRY(sample_scan(a, a.Q, 1, true));
                 a.thr0 = seed_thr;
                 a.no_sched = 1;
             }

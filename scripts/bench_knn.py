@@ -12,6 +12,8 @@ def main():
     ap.add_argument("--clusters", type=int, default=0, help="draw rows from this many Gaussian clusters (centres N(0, spread^2))")
     ap.add_argument("--spread", type=float, default=5.0); ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--sorted", action="store_true", help="reference rows sorted by cluster label (worst case for streaming thresholds)")
+    ap.add_argument("--ragged", action="store_true", help="clusters of unequal size (Dirichlet(0.7) weights, different on the two sides), their own spread "
+                                                          "(0.3 .. 3 x sigma) and a random per-coordinate scale: closer to real embeddings than equal isotropic blobs")
     a = ap.parse_args()
     import torch
     from cellmapper_amd.device import DevicePipeline
@@ -21,7 +23,16 @@ def main():
          (lambda n: torch.randn((n, a.d), generator=g, device=pipe.device))
     if a.clusters > 0:
         cen = torch.randn((a.clusters, a.d), generator=g, device=pipe.device) * a.spread
+        if a.ragged:
+            csig = torch.exp(torch.rand(a.clusters, generator=g, device=pipe.device) * 2.3 - 1.2)
+            aniso = torch.exp(torch.randn(a.d, generator=g, device=pipe.device) * 0.5)
+            torch.manual_seed(0)
+            wts = [torch.distributions.Dirichlet(torch.full((a.clusters,), 0.7)).sample().to(pipe.device) for _ in range(2)]
+        side = [0]
         def mk(n):
+            if a.ragged:
+                lab = torch.multinomial(wts[side[0] % 2], n, replacement=True, generator=g); side[0] += 1
+                return cen[lab] + (a.sigma * csig[lab])[:, None] * torch.randn((n, a.d), generator=g, device=pipe.device) * aniso[None, :]
             lab = torch.randint(0, a.clusters, (n,), generator=g, device=pipe.device)
             if a.sorted:
                 lab = torch.sort(lab).values

@@ -2,7 +2,7 @@
 # kernel-level breakdown of the clustered route (40-cluster mixture, 1.5 M x 1.5 M, d = 50, k = 30): rocprofv3 --kernel-trace --stats
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_clustered; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/scripts/bench_knn.py --nq 1500000 --nref 1500000 --d 50 --k 30 --uniform 0 --clusters 40 --spread 5 --sigma 1.0 --reps 4 > $O/line.json 2> $O/err.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/scripts/bench_knn.py --nq 1500000 --nref 1500000 --d 50 --k 30 --uniform 0 --clusters 40 --spread 5 --sigma ${SIGMA:-1.0} ${EXTRA:-} --reps 4 > $O/line.json 2> $O/err.log
 tail -1 $O/line.json | cut -c1-600
 python3 - <<PY
 import csv, glob, re

@@ -519,6 +519,34 @@ def test_centred_level_retried_with_long_lists(hip, oracle, monkeypatch):
     assert np.array_equal(i2[sel], oi) and np.array_equal(d2[sel], od), st2
 
 
+def test_unpruned_centred_stage_seeds_from_a_centred_sample_scan(hip, oracle, monkeypatch):
+    """Round 5 (late): overlapping clusters of unequal size and spread -- the bucket balls overlap, nothing is pruned, and the
+    bucket-centred level scans the whole reference.  Its thresholds start from a centred scan of the row sample (side values of
+    the sample rows gathered from the full side array).  Identical to the unseeded stage (CELLMAP_DBG=4096) on every row and to
+    the oracle on a sample."""
+    rng = np.random.default_rng(177)
+    d, k, n_ref, nq, ncl = 50, 20, 200_000, 140_000, 30
+    cen = rng.standard_normal((ncl, d)) * 5.0
+    csig = np.exp(rng.random(ncl) * 2.3 - 1.2)
+    aniso = np.exp(rng.standard_normal(d) * 0.5)
+    def draw(n, w):
+        lab = rng.choice(ncl, n, p=w)
+        return (cen[lab] + (0.25 * csig[lab])[:, None] * rng.standard_normal((n, d)) * aniso[None, :]).astype(np.float32)
+    ref, qry = draw(n_ref, rng.dirichlet(np.full(ncl, 0.7))), draw(nq, rng.dirichlet(np.full(ncl, 0.7)))
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    monkeypatch.setenv("CELLMAP_NO_IVF", "1")
+    d1, i1 = hip.knn(ref, qry, k)
+    st1 = hip.knn_stats()
+    monkeypatch.setenv("CELLMAP_DBG", "4096")
+    d0, i0 = hip.knn(ref, qry, k)
+    st0 = hip.knn_stats()
+    assert st1["filter_products"] == 5 and st1["tiles_visited_pct"] == 0 and st0["filter_products"] == 5, (st1, st0)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    sel = rng.choice(nq, 400, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
+
+
 @pytest.mark.parametrize("sigma", [2.0, 0.3])
 def test_small_seeded_subsets_split_the_reference_to_fill_the_chip(hip, oracle, monkeypatch, sigma):
     """Round 5: the few hundred queries a main stage leaves uncertified all carry a finite bound (counted by the re-rank), so
