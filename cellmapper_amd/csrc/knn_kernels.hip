@@ -2483,13 +2483,66 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 while (p2.S > 1 && p2.S * p2.Kc > RR_NCMAX) { p2.tps = (p2.n_tiles + p2.S - 2) / (p2.S - 1); p2.S = (p2.n_tiles + p2.tps - 1) / p2.tps; }
             }
         }
+        // Pruning gate of a stage (allocations and the reference buckets' balls once per search; then the balls of the stage's
+        // query blocks and the tiles of the (block, bucket) pairs whose balls overlap): clears ivf_try when nothing can be gained.
+        // Called by the pruned branch below -- and, for a bucket-centred main stage, BEFORE the kernel is chosen: an unpruned
+        // centred stage runs on the four-accumulator kernel, a pruned one on work lists.
+        bool gate_done = false;
+        auto ivf_gate = [&](int qblk, int BRt) -> cm_status {
+            const int C = LS_CMAX;
+            const int64_t nqb_max = (nq_pad + pack_slack) / (big_rows ? 256 : cmk2::QB) + 1;
+            if (!ivf_rcen) {
+                ivf_rcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * IVF_CSTR);
+                ivf_rrad = (double *)cm_ws_alloc(h, sizeof(double) * C);
+                ivf_rcnt = (int *)cm_ws_alloc(h, sizeof(int) * C);
+                ivf_bcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max * IVF_CSTR);
+                ivf_brad = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max);
+                ivf_bcnt = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
+                ivf_jstar = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
+                ivf_wla = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max);
+                ivf_wlb = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max * IVF_SB);
+                ivf_ctr = (int *)cm_ws_alloc(h, 64);
+                ivf_runs = (int2 *)cm_ws_alloc(h, sizeof(int2) * (size_t)nqb_max * 136);   // (a block has at most C / 2 + 1 maximal runs)
+                if (!ivf_rcen || !ivf_rrad || !ivf_rcnt || !ivf_bcen || !ivf_brad || !ivf_bcnt || !ivf_jstar || !ivf_wla || !ivf_wlb ||
+                    !ivf_ctr || !ivf_runs)
+                    CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+                ivf_ball<T>(st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm, (const int *)r_bstart, n_ref, C, 32,
+                            ivf_rcen, ivf_rrad, ivf_rcnt);
+            }
+            ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
+                        ivf_bcnt, qblk);
+            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
+            hipLaunchKernelGGL(ivf_overlap, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
+                               (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, BRt,
+                               reinterpret_cast<unsigned long long *>(ivf_ctr + 4));
+            {
+                int *ho = h->d_nflag_pinned + 10;
+                CM_HIP(h, hipMemcpyAsync(ho, ivf_ctr + 4, 8, hipMemcpyDeviceToHost, st));
+                CM_HIP(h, hipStreamSynchronize(st));
+                unsigned long long ov;
+                memcpy(&ov, ho, 8);
+                const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
+                if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
+                if (ov * 8ull > full0) {   // (see the threshold after the plan)
+                    ivf_try = false;
+                    if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
+                }
+            }
+            gate_done = true;
+            return CM_OK;
+        };
+        if (cenl && marks && ivf_try && !pilot && rerank && nsub >= 65536 && std::min(IVF_SB, RR_NCMAX / p2.Kc - 1) >= 2 && !(dbg & 8192))
+            CM_TRY(ivf_gate((int)(p2.nq_pad / std::max(p2.nqb, 1)), cmk2::BR));
         // Four accumulators per wave (knn_phase1_q4.h) for large full-set scans of the hi*hi level at K = 64: 1 024-query
         // blocks, so the padded query count is rounded up accordingly (every buffer carries that slack) and the 512-query
         // kernels of the same stage (seed scan) see an even number of blocks.
         // CELLMAP_Q4: 0 = never, 2 = whenever the kernel exists for the stage (tests), default = large sets only (a block is
         // 1 024 queries: below two blocks per CU the 512-query kernel fills the chip better).
         const int q4_env = cm_get_knobs().q4;
-        bool q4 = level == 1 && !cenl && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
+        // (round 5, late: the bucket-centred level too, once it is known that the stage will not be pruned -- pruned stages run on
+        //  work lists, which this kernel does not take; the first call of a shape still decides that inside the stage)
+        const bool cen_q4 = cenl && marks && !ivf_try && !(dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096)) && !(dbg & 8192);   // (CELLMAP_DBG=8192: off -- A/B)
+        bool q4 = level == 1 && (!cenl || cen_q4) && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
                   (q4_env == 2 || nsub >= 32768);
         if (q4) {
             // Work partitioning.  A stage is ceil(blocks x S / resident workgroups) rounds of work items, an item = one query
@@ -2575,7 +2628,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                                cenl ? qcen : (float *)nullptr, (int)prep_lds);
             if (!w3) {   // (knn_cand_f16w keeps the plan of make_plan2: 2-deep ring of full tiles)
                 p2.tileb = (size_t)cmk2::img_tile_bytes(p2.KSTEPS, want == 1);
-                p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * (p2.tileb + (cenl ? 1024 : 0)) + 64;
+                p2.lds = cmk2::ring_depth(want == 1, p2.KSTEPS) * (p2.tileb + (cenl ? (q4 ? 2048 : 1024) : 0)) + 64;   // (centred: + the side block(s) of a tile)
             }
         }
         // Subset stages start from what their queries already know (see the unpruned launch below).  Seeds of the plain levels
@@ -2618,7 +2671,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096);
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096 | 8192);
         a.ctr = d_ctr;   // (bits 16, 64, ... are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
@@ -2754,24 +2807,6 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // ---- bucket pruning: pass A over every block's nearest bucket, plan, pass B over what cannot be ruled out
             const int C = LS_CMAX;
             const int64_t nqb_max = (nq_pad + pack_slack) / (big_rows ? 256 : cmk2::QB) + 1;
-            if (!ivf_rcen) {
-                ivf_rcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)C * IVF_CSTR);
-                ivf_rrad = (double *)cm_ws_alloc(h, sizeof(double) * C);
-                ivf_rcnt = (int *)cm_ws_alloc(h, sizeof(int) * C);
-                ivf_bcen = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max * IVF_CSTR);
-                ivf_brad = (double *)cm_ws_alloc(h, sizeof(double) * (size_t)nqb_max);
-                ivf_bcnt = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
-                ivf_jstar = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nqb_max);
-                ivf_wla = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max);
-                ivf_wlb = (int4 *)cm_ws_alloc(h, sizeof(int4) * (size_t)nqb_max * IVF_SB);
-                ivf_ctr = (int *)cm_ws_alloc(h, 64);
-                ivf_runs = (int2 *)cm_ws_alloc(h, sizeof(int2) * (size_t)nqb_max * 136);   // (a block has at most C / 2 + 1 maximal runs)
-                if (!ivf_rcen || !ivf_rrad || !ivf_rcnt || !ivf_bcen || !ivf_brad || !ivf_bcnt || !ivf_jstar || !ivf_wla || !ivf_wlb ||
-                    !ivf_ctr || !ivf_runs)
-                    CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
-                ivf_ball<T>(st, d_ref, d, metric, (const double *)d_mean, (const int *)rperm, (const int *)r_bstart, n_ref, C, 32,
-                            ivf_rcen, ivf_rrad, ivf_rcnt);
-            }
             // Chained pass B (round 5): with four or more blocks per compute unit the blocks balance the chip by themselves, so a
             // block's runs are scanned by ONE work item into ONE candidate list (knn_cand_f16, P1Args::wruns): 2 lists per query
             // instead of 14 -- a seventh of the list memory (5.7 -> 0.8 GB at the config-2 shape) and of its 0xff fill, and the
@@ -2790,25 +2825,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                     ivf_list_cap = need;
                 }
             }
-            ivf_ball<T>(st, d_qry, d, metric, (const double *)d_mean, qmap, (const int *)nullptr, nsub, p2.nqb, 1, ivf_bcen, ivf_brad,
-                        ivf_bcnt, qblk);
-            hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
-            hipLaunchKernelGGL(ivf_overlap, dim3(p2.nqb), dim3(256), 0, st, (const double *)ivf_bcen, (const double *)ivf_brad,
-                               (const double *)ivf_rcen, (const double *)ivf_rrad, (const int *)r_bstart, C, d, BRt,
-                               reinterpret_cast<unsigned long long *>(ivf_ctr + 4));
-            {
-                int *ho = h->d_nflag_pinned + 10;
-                CM_HIP(h, hipMemcpyAsync(ho, ivf_ctr + 4, 8, hipMemcpyDeviceToHost, st));
-                CM_HIP(h, hipStreamSynchronize(st));
-                unsigned long long ov;
-                memcpy(&ov, ho, 8);
-                const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
-                if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
-                if (ov * 8ull > full0) {   // (see the threshold after the plan)
-                    ivf_try = false;
-                    if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
-                }
-            }
+            if (!gate_done) CM_TRY(ivf_gate(qblk, BRt));   // (a centred stage asked before it chose its kernel)
             auto side_items = [&](const int4 *wl, int n_items, const int2 *runs = nullptr) {   // centred level: side values of the pairs a list visits
                 if (!cenl || side_full || n_items < 1) return;
                 // (side_claimed: two bitmaps, one bit per (bucket, tile) pair each, allocated and zeroed with the side values in setup_centred)
@@ -3113,6 +3130,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         const size_t claim_words = 2 * (size_t)C * (size_t)((pf.n_tiles + 31) / 32 + 1);   // one bit per (bucket, tile) pair, twice (done / wanted): cen_side_mark
         side_claimed = (unsigned *)cm_ws_alloc(h, sizeof(unsigned) * claim_words);
         if (!pstart || !qpack || !blk_bucket || !cen || !side || !qnc || !qcen || !side_claimed) CM_FAIL(h, CM_E_NOMEM, "k-NN: device workspace exhausted");
+        CM_HIP(h, hipMemsetAsync(blk_bucket, 0, sizeof(int) * (size_t)(n_packed / cmk2::QB + 1), st));   // (the four-accumulator kernel pads to 1 024 queries: one more block, bucket 0)
         CM_HIP(h, hipMemsetAsync(side_claimed, 0, sizeof(unsigned) * claim_words, st));
         CM_HIP(h, hipMemcpyAsync(pstart, hps, sizeof(int) * (C + 1), hipMemcpyHostToDevice, st));
         CM_HIP(h, hipStreamSynchronize(st));   // (hps lives on this stack frame)

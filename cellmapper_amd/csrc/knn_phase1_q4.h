@@ -49,13 +49,16 @@ constexpr int QBQ = NW * 128;   // queries per workgroup pass of the four-accumu
 // DBG = false is the production body: the CELLMAP_DBG modes (adbg: 1 never append, 2 skip the filter, 4 in-kernel
 // counters) are compiled out -- they cost two vector and a dozen scalar instructions per accumulator and sub-tile, and
 // the counters' SGPRs spilled (round 3).  The host launches DBG = true only when CELLMAP_DBG is set.
-template <int KSTEPS, bool DBG>
+// CEN (round 5, late): the bucket-centred form -- the B operand holds q'' = q' - c, the accumulators start from the side values
+// -2 c.y' of the wave's bucket (knn_cand_f16, CEN).  A workgroup covers two bucket-aligned 512-query blocks (waves 0..3 / 4..7),
+// so a tile carries TWO side blocks of 1 KiB, copied by waves 0 and 4, and every wave reads its own half's.
+template <int KSTEPS, bool DBG, bool CEN = false>
 __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
     const int adbg = DBG ? a.dbg : 0;
     constexpr int K = KSTEPS * 16;
     constexpr int ROWB = img_row_bytes(KSTEPS, true);
     constexpr int GTILEB = img_tile_bytes(KSTEPS, true);
-    constexpr int TILEB = GTILEB;
+    constexpr int TILEB = GTILEB + (CEN ? 2048 : 0);   // stride of the LDS ring (CEN: + the two side blocks)
     constexpr int ROWS_B = BR * ROWB;
     constexpr int RING = ring_depth(true, KSTEPS);
     constexpr int BT = RING >= 8 ? CM2_BT : 1;
@@ -77,6 +80,10 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
     const unsigned ldsbase = (unsigned)(uintptr_t)(CM2_AS3 unsigned char *)ring;
     const unsigned dma_voff = wave * 1024 + lane * 16;
 
+#define CM2Q_DMA_SIDE(t_, buf_)                                                                                 \
+    __builtin_amdgcn_global_load_lds(                                                                           \
+        (const CM2_AS1 void *)(reinterpret_cast<const char *>(side_row + (size_t)(t_) * BR) + lane * 16),       \
+        (CM2_AS3 void *)(ring + (buf_) * TILEB + ROWS_B + (wave >> 2) * 1024), 16, 0, 0)
 #define CM2Q_DMA_TILE(t_, buf_)                                                                                 \
     {                                                                                                           \
         const char *gsrc_ = a.R + (size_t)(t_) * GTILEB;                                                        \
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         _Pragma("unroll") for (int q_ = 0; q_ < NPIECE; ++q_)                                                   \
             __builtin_amdgcn_global_load_lds((const CM2_AS1 void *)(gsrc_ + q_ * (NW * 1024) + dma_voff),       \
                                              (CM2_AS3 void *)(ldst_ + q_ * (NW * 1024)), 16, 0, 0);             \
+        if (CEN && sidew) CM2Q_DMA_SIDE(t_, buf_);                                                              \
     }
 #define CM2Q_DMA_PIECE(t_, buf_, q_)                                                                            \
     __builtin_amdgcn_global_load_lds(                                                                           \
@@ -101,6 +109,11 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         const int t1 = (t0 + a.tiles_per_split < a.n_tiles) ? t0 + a.tiles_per_split : a.n_tiles;
         const int64_t qbase = (int64_t)qb * QBQ + wave * 128;
         const unsigned long long tw0_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
+        // CEN: side values of this wave's bucket (one float per row of the padded reference image); waves 0 and 4 copy them
+        const float *side_row = nullptr;
+        if constexpr (CEN) side_row = a.side + (size_t)a.blk_bucket[__builtin_amdgcn_readfirstlane(qb * 2 + (wave >> 2))] * (size_t)a.side_stride;
+        const bool sidew = CEN && __builtin_amdgcn_readfirstlane(wave & 3) == 0;
+        (void)side_row; (void)sidew;
 
         // ---- query fragments (B operand) of the wave's 128 queries: hi halves only (hi*hi level)
         half8 qh[NJ][KSTEPS];
@@ -171,12 +184,22 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         half8 ah[KSTEPS], al[KSTEPS];   // the two fragment sets (current / next sub-tile, alternating)
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { ah[s] = half8{0, 0, 0, 0, 0, 0, 0, 0}; al[s] = ah[s]; }
+        // CEN: the lane's 16 side values of a sub-tile (rows 4*hh + {0..3} + 8*i), two sets alternating like the fragments
+        f32x4 ya[4], yb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ya[i] = f32x4{0.f, 0.f, 0.f, 0.f}; yb[i] = ya[i]; }
+        const unsigned yrow = ROWS_B + (wave >> 2) * 1024 + 16 * hh;
+        (void)yrow;
         if (t0 < t1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const unsigned tile0 = ldsbase + (t0 % RING) * TILEB;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) CM2_DSR128X(ah[s], arow, 32 * s, tile0, 0);
+            if constexpr (CEN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) CM2_DSR128X(ya[i], yrow, 0, tile0, 32 * i);
+            }
         }
         int ptile = CM2Q_PT(t0), ptile_a = CM2Q_PT(t0 + AHEAD);
         const int pstep = a.perm_mul > 1u ? (int)(a.perm_mul % (unsigned)a.n_tiles) : 1;
@@ -191,25 +214,33 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
         else TOT = vmin3(U[0], U[1], U[0]);                                                                    \
     }
         // One sub-tile: CUR holds its fragments, NXT receives those of the next sub-tile (base address NBASE).
-#define CM2Q_SUBTILE(CUR, NXT, ST)                                                                             \
+#define CM2Q_SUBTILE(CUR, NXT, YC, YN, ST)                                                                     \
     {                                                                                                          \
         const int nst_ = ((ST) + 1 < NST) ? (ST) + 1 : 0;                                                      \
         const unsigned nbase_ = (((ST) + 1 < NST) ? tile : tile_n) + nst_ * 32 * ROWB;                         \
+        const unsigned ybase_ = (((ST) + 1 < NST) ? tile : tile_n);                                            \
         rb_prev = rb_cur;                                                                                      \
         rb_cur = ptile * BR + (ST) * 32 + 4 * hh;                                                              \
         wait_lds<0>(CUR);                                                                                      \
+        f32x16 yc_;                                                                                            \
+        if constexpr (CEN) {                                                                                   \
+            asm volatile("" : "+v"(YC[0]), "+v"(YC[1]), "+v"(YC[2]), "+v"(YC[3]));   /* (ordered after the wait) */ \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { yc_[e] = YC[0][e]; yc_[4 + e] = YC[1][e]; yc_[8 + e] = YC[2][e]; yc_[12 + e] = YC[3][e]; } \
+        }                                                                                                      \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                       \
             constexpr int dummy_ = 0; (void)dummy_;                                                            \
             const int jp = (j + 2) & 3;             /* accumulator filtered in the shadow of accumulator j */ \
             float T_[5], U_[2], tot_ = INFINITY;                                                               \
             const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
             _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s) {                                               \
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CUR[s], qh[j][s], s == 0 ? zero_ : acc[j], 0, 0, 0); \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(CUR[s], qh[j][s], s == 0 ? (CEN ? yc_ : zero_) : acc[j], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
                 if (j == 0) CM2_DSR128X(NXT[s], arow, 32 * s, nbase_, 0);                                      \
+                if (CEN && j == 2) { _Pragma("unroll") for (int q_ = 0; q_ < 4 / KSTEPS; ++q_) CM2_DSR128X(YN[s * (4 / KSTEPS) + q_], yrow, 0, ybase_, nst_ * 128 + 32 * (s * (4 / KSTEPS) + q_)); } \
                 _Pragma("unroll") for (int q_ = 0; q_ < 8 / KSTEPS; ++q_)                                      \
                     CM2Q_TREE_STEP(s * (8 / KSTEPS) + q_, acc[jp], T_, U_, tot_)                               \
                 if (j == 1 && s == 0 && (ST) < NPIECE && t + AHEAD < t1) CM2Q_DMA_PIECE(ptile_a, (t + AHEAD) % RING, (ST)); \
+                if (CEN && j == 1 && s == 0 && (ST) == 0 && sidew && t + AHEAD < t1) CM2Q_DMA_SIDE(ptile_a, (t + AHEAD) % RING); \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                                  \
             if (!(adbg & 2)) {                                                                                 \
@@ -226,6 +257,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             unsigned long long tb0_ = (adbg & 4) ? __builtin_amdgcn_s_memtime() : 0ull;
             if (t > t0 && (BT == 1 || (t - t0) % BT == 0)) {
                 if (t + AHEAD - 1 >= t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (CEN && sidew) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * (NPIECE + 1)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((AHEAD - 1 - BT) * NPIECE) : "memory");
                 if (adbg & 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_dmacyc += t_ - tb0_; tb0_ = t_; }
                 __builtin_amdgcn_s_barrier();
@@ -235,8 +267,8 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
             const unsigned tile_n = ldsbase + ((t + 1) % RING) * TILEB;
 #pragma unroll
             for (int sp = 0; sp < NST; sp += 2) {
-                CM2Q_SUBTILE(ah, al, sp)
-                CM2Q_SUBTILE(al, ah, sp + 1)
+                CM2Q_SUBTILE(ah, al, ya, yb, sp)
+                CM2Q_SUBTILE(al, ah, yb, ya, sp + 1)
             }
             if (a.no_sched) {
                 // aligned merges of the seeded scan (see knn_cand_f16): a wave with a long log announces it, everybody merges
@@ -304,6 +336,7 @@ __global__ __launch_bounds__(NT, 2) void knn_cand_f16q(P1Args a) {
     }
 #undef CM2Q_DMA_TILE
 #undef CM2Q_DMA_PIECE
+#undef CM2Q_DMA_SIDE
 #undef CM2Q_PT
     if (DBG && (adbg & 4) && lane == 0) {
         atomicAdd(&a.ctr[0], c_br);

@@ -7,9 +7,9 @@
 #include "knn_phase1_q4.h"
 #endif
 
-template <int KSTEPS, bool DBG>
+template <int KSTEPS, bool DBG, bool CEN = false>
 static cm_status launch_q4(cm_handle_t h, int grid, size_t lds, const cmk2::P1Args &a) {
-    auto kern = cmk2::knn_cand_f16q<KSTEPS, DBG>;
+    auto kern = cmk2::knn_cand_f16q<KSTEPS, DBG, CEN>;
     CM_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(cmk2::NT), lds, h->stream, a);
     CM_HIP(h, hipGetLastError());
@@ -18,8 +18,16 @@ static cm_status launch_q4(cm_handle_t h, int grid, size_t lds, const cmk2::P1Ar
 
 // hi*hi level, K = 64 or 32, full-set scans without a work list.  a.dbg != 0 (CELLMAP_DBG) selects the diagnostics body.
 cm_status cm_p1f16q_launch(cm_handle_t h, int KSTEPS, int grid, size_t lds, const cmk2::P1Args &a) {
-    if ((KSTEPS != 4 && KSTEPS != 2) || a.nprod != 1 || a.side || a.wlist || a.seed_len)
+    if ((KSTEPS != 4 && KSTEPS != 2) || a.nprod != 1 || a.wlist || a.seed_len)
         CM_FAIL(h, CM_E_INTERNAL, "phase1/f16q: instantiated for the hi*hi level at K <= 64 without work lists");
+#ifndef CM_ABLATE
+    if (a.side) {   // bucket-centred form (production body only)
+        if (a.dbg) CM_FAIL(h, CM_E_INTERNAL, "phase1/f16q: the centred form has no diagnostics body");
+        return KSTEPS == 4 ? launch_q4<4, false, true>(h, grid, lds, a) : launch_q4<2, false, true>(h, grid, lds, a);
+    }
+#else
+    if (a.side) CM_FAIL(h, CM_E_INTERNAL, "phase1/f16q: the ablation copy has no centred form");
+#endif
     if (a.dbg) return KSTEPS == 4 ? launch_q4<4, true>(h, grid, lds, a) : launch_q4<2, true>(h, grid, lds, a);
     return KSTEPS == 4 ? launch_q4<4, false>(h, grid, lds, a) : launch_q4<2, false>(h, grid, lds, a);
 }

@@ -91,7 +91,7 @@ def main():
             ok = bool(torch.equal(d1, d2)) and bool((torch.sort(i1, 1).values == torch.sort(i2, 1).values).float().mean() > 0.9999)
         print(json.dumps(dict(case=case, d=d, k=k, n_ref=n_ref, nq=nq, metric=metric, f64=dt == torch.float64, clusters=ncl,
                               sigma=sigma, ragged=bool(a.clustered and case % 2 == 1), ok=ok, ms_default=round((t1 - t0) * 1e3, 1), ms_plain=round((t2 - t1) * 1e3, 1),
-                              level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], passes=st1["pruning_passes"], fb=st1["fallback_queries"],
+                              level=st1["filter_products"], pruned_pct=st1["tiles_visited_pct"], passes=st1["pruning_passes"], kernel=st1["filter_kernel"], fb=st1["fallback_queries"],
                               fb_plain=st2["fallback_queries"])), flush=True)
         if not ok:
             bad += 1

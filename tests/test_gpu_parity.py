@@ -542,6 +542,13 @@ def test_unpruned_centred_stage_seeds_from_a_centred_sample_scan(hip, oracle, mo
     st0 = hip.knn_stats()
     assert st1["filter_products"] == 5 and st1["tiles_visited_pct"] == 0 and st0["filter_products"] == 5, (st1, st0)
     assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    # ... and the kernel: with pruning known to be off the stage runs on the four-accumulator kernel's centred form (two side blocks
+    # per tile, one per 512-query half of its block); CELLMAP_DBG=8192 keeps the two-accumulator kernel
+    monkeypatch.setenv("CELLMAP_DBG", "8192")
+    d2, i2 = hip.knn(ref, qry, k)
+    st2 = hip.knn_stats()
+    assert (st1["filter_kernel"], st2["filter_kernel"]) == (2, 1), (st1, st2)
+    assert np.array_equal(i2, i1) and np.array_equal(d2, d1)
     sel = rng.choice(nq, 400, replace=False)
     od, oi = oracle.knn_euclidean(ref, qry[sel], k)
     assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
