@@ -254,7 +254,7 @@ class Handle:
                     # 1 = a query's exact-fallback list overflowed (results truncated): device-tier callers must check
                     fallback_overflow=int(out[4]),
                     # most reference splits a subset stage used (> 16: a small seeded subset split to fill the chip)
-                    subset_splits=int(out[5]))
+                    subset_splits=int(out[5]), wide_split_retries=int(out[6]))
 
     # ------------------------------------------------------------------ host tier (numpy in / numpy out)
     def knn(self, ref: np.ndarray, qry: np.ndarray, k: int, metric: str = "euclidean", form: str = "auto"):

@@ -613,7 +613,8 @@ cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]) {
     for (int i = 0; i < 4; ++i) out[i] = h->knn_stats[i];
     out[4] = h->d_nflag_pinned[1];   // exact-fallback overflow (valid once the stream has been synchronised)
     out[5] = h->knn_sub_splits;
-    out[6] = out[7] = 0;
+    out[6] = h->knn_wide_retries;
+    out[7] = 0;
     return CM_OK;
 }
 

@@ -55,6 +55,7 @@ struct cm_handle_s {
     size_t ws_peak = 0;   // ... largest value of that over the handle's life
     int64_t knn_stats[4] = {0, 0, 0, 0};
     int64_t knn_sub_splits = 0;   // cm_knn_stats out[5]: most reference splits a subset stage of the last search used
+    int64_t knn_wide_retries = 0; // cm_knn_stats out[6]: stages repeated with ordinary splits after a wide split overflowed the re-rank's capacity
     int n_cu = 0;   // compute units of the device (lazily queried)
     const void *a3_index = nullptr;   // last payload index whose header this handle has read (A3, wave-sliced kernel)
     int a3_max_slice = 0;             // ... its longest (payload row, column bucket) slice

@@ -2392,6 +2392,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     float *ivf_cthr = nullptr;
     size_t ivf_list_cap = 0;   // candidate lists (entries of Kc_max ints) ivf_cand / ivf_cthr hold
     h->knn_sub_splits = 0;
+    h->knn_wide_retries = 0;
     int ivf_pct = 0;   // tiles visited by the pruned main stage, per cent of a full scan (0: pruning not used)
     int ivf_passes = 0;   // ... and its form: 1 = single pass from sample-scan seeds, 2 = pass A + pass B
     // sample-seeded thresholds of the plain full scan (see run_stage)
@@ -3199,6 +3200,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 flag_out = flag_out == flag_a ? flag_b : flag_a;
                 seeds_from_level = level;
                 no_wide = true;
+                ++h->knn_wide_retries;
                 continue;
             }
         }
@@ -3363,6 +3365,7 @@ cm_status knn_run_scan(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_
     h->knn_stats[2] = QG;
     h->knn_stats[3] = 5;
     h->knn_sub_splits = 0;
+    h->knn_wide_retries = 0;
     return CM_OK;
 }
 
@@ -3455,6 +3458,7 @@ cm_status knn_run_t(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *d_qry
     h->knn_stats[2] = S;
     h->knn_stats[3] = 1;
     h->knn_sub_splits = 0;
+    h->knn_wide_retries = 0;
     return CM_OK;
 }
 

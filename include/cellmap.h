@@ -189,7 +189,8 @@ cm_status cm_stage_times(cm_handle_t h, float out_ms[8]);
  *          within their bound -- up to that many take a selection pass and are exact; beyond it lists are truncated:
  *          cm_synchronize and the host tier turn this into CM_E_UNSUPPORTED, device-tier callers that synchronise the
  *          stream themselves must check it), out[5] = most reference splits a subset stage (uncertified queries on a
- *          later filter level) used -- beyond 16: a small seeded subset split to fill the chip; out[6..7] reserved (0).
+ *          later filter level) used -- beyond 16: a small seeded subset split to fill the chip; out[6] = such stages repeated with ordinary
+ *          splits because their lists overflowed the re-rank's capacity (very tight clusters); out[7] reserved (0).
  *          Read after the stream is idle. */
 cm_status cm_knn_stats(cm_handle_t h, int64_t out[8]);
 

@@ -554,6 +554,31 @@ def test_unpruned_centred_stage_seeds_from_a_centred_sample_scan(hip, oracle, mo
     assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
 
 
+def test_wide_split_overflow_repeats_the_level(hip, oracle, monkeypatch):
+    """Round 5 (late): eight very tight clusters of 37 k rows.  The queries the long-list centred level leaves uncertified start
+    their three-product stage from finite seeds and split the reference ~250 ways -- but the seeds' error margins admit more
+    than the 1 024 rows the re-rank compacts: those queries repeat the level with ordinary splits (counted in cm_knn_stats)
+    instead of moving on to the direct-difference level.  Identical to the search without wide splits, identical to the oracle."""
+    rng = np.random.default_rng(181)
+    d, k, n_ref, nq = 50, 30, 300_000, 150_000
+    cen = rng.standard_normal((8, d)) * 5.0
+    ref = (cen[rng.integers(0, 8, n_ref)] + 0.1 * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, 8, nq)] + 0.1 * rng.standard_normal((nq, d))).astype(np.float32)
+    easy = rng.standard_normal((4096, d + 1)).astype(np.float32)
+    res = {}
+    for tag, dbg in (("wide", "768"), ("plain", "2816")):   # (256 + 512: chained pass A + B at a test size; + 2048: no wide splits)
+        hip.knn(easy, easy[:512], k)            # (another shape: the handle forgets what it knew about this one)
+        monkeypatch.setenv("CELLMAP_DBG", dbg)
+        hip.knn(ref, qry, k)                    # first call: short lists, most queries uncertified -> the handle switches to long lists
+        res[tag] = hip.knn(ref, qry, k) + (hip.knn_stats(),)
+    assert res["wide"][2]["candidates"] == 140 and res["wide"][2]["wide_split_retries"] >= 1 and res["wide"][2]["subset_splits"] > 16, res["wide"][2]
+    assert res["plain"][2]["wide_split_retries"] == 0 and res["plain"][2]["subset_splits"] <= 16, res["plain"][2]
+    assert np.array_equal(res["wide"][1], res["plain"][1]) and np.array_equal(res["wide"][0], res["plain"][0])
+    sel = rng.choice(nq, 300, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(res["wide"][1][sel], oi) and np.array_equal(res["wide"][0][sel], od)
+
+
 @pytest.mark.parametrize("sigma", [2.0, 0.3])
 def test_small_seeded_subsets_split_the_reference_to_fill_the_chip(hip, oracle, monkeypatch, sigma):
     """Round 5: the few hundred queries a main stage leaves uncertified all carry a finite bound (counted by the re-rank), so
