@@ -1761,6 +1761,16 @@ __global__ void fl_gather(const int *__restrict__ flag, const int *__restrict__ 
 constexpr int IVF_SB = 13;      // pass-B runs (candidate lists) per query block; slot 0 is pass A
 constexpr int IVF_CSTR = 128;   // doubles per centre (round 5: the K = 128 family prunes too, d <= 128)
 // the IVF_SB + 1 candidate lists per query are the one large buffer of the scheme: not worth more than 16 GiB of workspace
+// Largest share (per cent) of the (block, tile) pairs a pruned stage may have to visit.  Pass A + pass B pay a second threshold
+// history and several lists per query: an eighth (measured: slower than the full scan at 15 - 25 %).  The single-pass stage
+// (round 5) costs ~22 ms + 311 ms x share at 1.5 M x 1.5 M, d = 50 against 269 ms for the unpruned centred scan on the same box
+// (ragged 40-cluster mixture, sigma 0.5: 61 % of the pairs, 212 against 269 ms): break-even at 79 %, accepted up to 70 %; the
+// gate in front of it (pairs whose balls overlap: a lower bound of the plan's share) lets 60 % through.
+// CELLMAP_PRUNE_MAX overrides the 70 (the gate follows 10 below).
+static inline int prune_max_pct(bool single_pass, bool gate = false) {
+    static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX"); const int x = e ? atoi(e) : 70; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
+    return single_pass ? (gate ? std::max(12, v - 10) : v) : 12;
+}
 static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
     return (size_t)(nq_pad + 256 * 512) * (IVF_SB + 1) * (size_t)Kc_max * 4 <= ((size_t)16 << 30);
 }
@@ -2524,7 +2534,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 memcpy(&ov, ho, 8);
                 const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
                 if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
-                if (ov * 8ull > full0) {   // (see the threshold after the plan)
+                // (a stage that can run in a single pass: the same conditions as `single` below)
+                const bool single_ok_ = marks && level != 4 && !w3 && (p2.nqb >= 4 * (h->n_cu > 0 ? h->n_cu : 256) || (dbg & 256)) && !(dbg & (128 | 512)) &&
+                                        !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed;
+                const unsigned long long pmx_ = (unsigned long long)prune_max_pct(single_ok_, true);
+                if (ov * 100ull > full0 * pmx_) {   // (see the threshold after the plan)
                     ivf_try = false;
                     if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
                 }
@@ -2869,7 +2883,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 }
                 const bool dense_ok = (level == 1 || cenl) && !wide && !(dbg & 1024);   // (the dense seeding scan below exists for this stage)
                 CM_TRY(sample_scan(a, Qplain, dense_ok ? 4 : 1));
-                sample_done = !cenl;
+                sample_done = !cenl && !dense_ok;   // (the coarse sample's seeds are good enough for radii, not for an unpruned scan)
                 hipLaunchKernelGGL(zero_words, dim3(1), dim3(64), 0, st, (unsigned *)ivf_ctr, 16);
                 const float c_eps1 = (float)(16 * p2.KSTEPS + (wide ? 1 : 0) + 1) * 1.1920929e-7f * 1.001f + 8.4e-7f;   // analytic hi*hi constant (below)
                 const bool widen = cenl || level != 1;   // a more precise filter than the seeds': see ivf_plan_b
@@ -2890,7 +2904,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 if (dbg & 16)
                     fprintf(stderr, "[cellmap dbg] bucket pruning (single pass): %llu of %llu (block, tile) pairs to visit, %d runs for %d of %d blocks\n",
                             tiles, full, hc[1], hc[0], p2.nqb);
-                if (tiles * 8ull <= full) {
+                if (tiles * 100ull <= full * (unsigned long long)prune_max_pct(true)) {
                     // (a block without a run -- seeds too tight for any bucket -- writes nothing: empty lists for everybody first)
                     CM_HIP(h, hipMemsetAsync(cand, 0xff, sizeof(int) * (size_t)p2.nq_pad * p2.Kc, st));
                     hipLaunchKernelGGL(fill_f32, dim3((unsigned)((p2.nq_pad + 255) / 256)), dim3(256), 0, st, cthr, (int64_t)p2.nq_pad, INFINITY);
@@ -2946,7 +2960,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                     rr_S = 1;
                     last_seeded = !cenl;   // (failures of a plain level retry it unseeded, as after a seeded full scan; the centred level has no subset form)
                     if (marks) { ivf_pct = (int)std::max<unsigned long long>(1ull, tiles * 100ull / std::max<unsigned long long>(full, 1ull)); ivf_passes = 1; }
-                } else if (tiles * 3ull > full) {   // hopeless; between an eighth and a third pass A's tighter radii (rank K' instead of ~8 R) may still get there
+                } else if (tiles * 3ull > full) {   // hopeless (always, now that the single pass accepts up to 70 %; CELLMAP_PRUNE_MAX below 33: pass A + B gets its try)
                     ivf_try = false;
                     if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
                 }

@@ -554,6 +554,36 @@ def test_unpruned_centred_stage_seeds_from_a_centred_sample_scan(hip, oracle, mo
     assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
 
 
+def test_single_pass_stage_accepts_large_visited_shares(hip, oracle, monkeypatch):
+    """Round 5 (late): overlapping clusters of unequal size and spread.  Pass A + pass B only pay below an eighth of the (block,
+    tile) pairs; the single-pass stage pays up to ~79 % (measured break-even) and is accepted up to 70 %.  Forced at a test size
+    (CELLMAP_DBG=256): a stage that visits well over an eighth of the pairs, identical to the unpruned search on every row and to
+    the oracle on a sample."""
+    rng = np.random.default_rng(183)
+    d, k, n_ref, nq, ncl = 50, 20, 300_000, 200_000, 40
+    cen = rng.standard_normal((ncl, d)) * 5.0
+    csig = np.exp(rng.random(ncl) * 2.3 - 1.2)
+    aniso = np.exp(rng.standard_normal(d) * 0.5)
+    def draw(n, w):
+        lab = rng.choice(ncl, n, p=w)
+        return (cen[lab] + (0.3 * csig[lab])[:, None] * rng.standard_normal((n, d)) * aniso[None, :]).astype(np.float32)
+    ref, qry = draw(n_ref, rng.dirichlet(np.full(ncl, 0.7))), draw(nq, rng.dirichlet(np.full(ncl, 0.7)))
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    monkeypatch.setenv("CELLMAP_DBG", "256")
+    d1, i1 = hip.knn(ref, qry, k)
+    st1 = hip.knn_stats()
+    assert st1["pruning_passes"] == 1 and 13 < st1["tiles_visited_pct"] <= 70, st1
+    monkeypatch.delenv("CELLMAP_DBG")
+    monkeypatch.setenv("CELLMAP_NO_IVF", "1")
+    d0, i0 = hip.knn(ref, qry, k)
+    st0 = hip.knn_stats()
+    assert st0["tiles_visited_pct"] == 0, st0
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    sel = rng.choice(nq, 400, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
+
+
 def test_wide_split_overflow_repeats_the_level(hip, oracle, monkeypatch):
     """Round 5 (late): eight very tight clusters of 37 k rows.  The queries the long-list centred level leaves uncertified start
     their three-product stage from finite seeds and split the reference ~250 ways -- but the seeds' error margins admit more
