@@ -9,16 +9,18 @@ cd $R
 echo "# Clustered route, round 5 (late): single-pass pruned main stage"
 echo
 echo "\`scripts/clustered_r5.sh\` on one MI355X box, library of the commit that carries this file.  40 Gaussian clusters, centres N(0, 5^2), within-cluster sigma as given,"
-echo "reference and queries share the centres; 1.5 M x 1.5 M, d = 50, k = 30, float32, \`scripts/bench_knn.py --reps 4\` (mean of the calls after the first;"
+echo "reference and queries share the centres (rN = the ragged variant, \`--ragged\`: Dirichlet(0.7) cluster weights, different on the two sides, per-cluster spread 0.3 .. 3 x sigma, random per-coordinate scale);"
+echo "1.5 M x 1.5 M, d = 50, k = 30, float32, \`scripts/bench_knn.py --reps 4\` (mean of the calls after the first;"
 echo "stage times of the last call).  \`CELLMAP_DBG=512\` keeps pass A + pass B (the round-4 form, chained pass B).  Stage lines: \`CELLMAP_DBG=16\`."
 echo
 echo "| sigma | form | k-NN ms | stages (ms) | main stage | uncertified after it | later stages |"
 echo "|---|---|---|---|---|---|---|"
 } > $O/report.md
-for sg in 2.0 1.0 0.5 0.3 0.2 0.17 0.15 0.12 0.1 0.05; do
+for spec in 2.0 1.7 1.5 1.3 1.0 0.5 0.3 0.2 0.17 0.15 0.12 0.1 0.05 r1.0 r0.5 r0.3; do
+sg=${spec#r}; extra=""; [ "$spec" != "$sg" ] && extra="--ragged"
 for dbg in 0 512; do
-CELLMAP_DBG=$((dbg+16)) timeout -k 10 300 python scripts/bench_knn.py --nq 1500000 --nref 1500000 --d 50 --k 30 --uniform 0 --clusters 40 --spread 5 --sigma $sg --reps 4 > $O/out.txt 2> $O/err.txt || exit 1
-python3 - "$sg" "$dbg" $O/out.txt $O/err.txt >> $O/report.md <<'PY'
+CELLMAP_DBG=$((dbg+16)) timeout -k 10 300 python scripts/bench_knn.py --nq 1500000 --nref 1500000 --d 50 --k 30 --uniform 0 --clusters 40 --spread 5 --sigma $sg $extra --reps 4 > $O/out.txt 2> $O/err.txt || exit 1
+python3 - "$spec" "$dbg" $O/out.txt $O/err.txt >> $O/report.md <<'PY'
 import sys, json, re
 sg, dbg, out, err = sys.argv[1:5]
 r = json.loads(open(out).read().strip().splitlines()[-1])
