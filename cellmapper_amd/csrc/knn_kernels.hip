@@ -2535,7 +2535,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
                 if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
                 // (a stage that can run in a single pass: the same conditions as `single` below)
-                const bool single_ok_ = marks && level != 4 && !w3 && (p2.nqb >= 4 * (h->n_cu > 0 ? h->n_cu : 256) || (dbg & 256)) && !(dbg & (128 | 512)) &&
+                const bool single_ok_ = marks && level != 4 && !w3 && !(dbg & (128 | 512)) && (!(dbg & 16384) || p2.nqb >= 4 * (h->n_cu > 0 ? h->n_cu : 256) || (dbg & 256)) &&
                                         !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed;
                 const unsigned long long pmx_ = (unsigned long long)prune_max_pct(single_ok_, true);
                 if (ov * 100ull > full0 * pmx_) {   // (see the threshold after the plan)
@@ -2556,7 +2556,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         const int q4_env = cm_get_knobs().q4;
         // (round 5, late: the bucket-centred level too, once it is known that the stage will not be pruned -- pruned stages run on
         //  work lists, which this kernel does not take; the first call of a shape still decides that inside the stage)
-        const bool cen_q4 = cenl && marks && !ivf_try && !(dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096)) && !(dbg & 8192);   // (CELLMAP_DBG=8192: off -- A/B)
+        const bool cen_q4 = cenl && marks && !ivf_try && !(dbg & 7) && !(dbg & 8192);   // (CELLMAP_DBG=8192: off -- A/B)
         bool q4 = level == 1 && (!cenl || cen_q4) && !w3 && !wide && (p2.KSTEPS == 4 || p2.KSTEPS == 2) && !pilot && q4_env != 0 &&
                   (q4_env == 2 || nsub >= 32768);
         if (q4) {
@@ -2686,7 +2686,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         a.n_tiles = p2.n_tiles; a.tiles_per_split = p2.tps; a.S = p2.S; a.nqb = p2.nqb; a.Kc = p2.Kc;
         a.cand = cand; a.cthr = cthr; a.kept = kept; a.lbuf = lbuf;
         a.nprod = level == 4 ? 3 : level;
-        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096 | 8192);
+        a.dbg = dbg & ~(16 | 64 | 128 | 256 | 512 | 1024 | 2048 | 4096 | 8192 | 16384);
         a.ctr = d_ctr;   // (bits 16, 64, ... are host-side switches: the production kernel bodies stay selected)
         if (cenl) { a.side = side; a.blk_bucket = blk_bucket; a.side_stride = side_stride; }
         a.perm_mul = 1;
@@ -2829,7 +2829,11 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // bucket: 17 ms of re-rank at 1.5 M clustered queries).  Few blocks, the direct level and the K = 128 three-product
             // kernel keep one list per run (runs halved for load balance).
             const int res_ = h->n_cu > 0 ? h->n_cu : 256;
-            const bool chain = level != 4 && !w3 && (p2.nqb >= 4 * res_ || (dbg & 256)) && !(dbg & 128);   // (CELLMAP_DBG=128: one list per run everywhere -- A/B; 256: chained whatever the block count -- tests)
+            // (round 5, late: the MAIN stage chains -- and takes the single pass below -- whatever its block count: measured against pass A + B
+            //  at 375 k / 187.5 k / 100 k / 66 k queries x 1.5 M rows, 40 clusters: 26.0 / 18.3 / 52.6 / 51.0 -> 16.5 / 11.5 / 45.4 / 45.0 ms;
+            //  CELLMAP_DBG=16384: the four-blocks-per-CU rule for the main stage too -- A/B)
+            const bool single_able = marks && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed && !(dbg & (512 | 16384));
+            const bool chain = level != 4 && !w3 && (p2.nqb >= 4 * res_ || single_able || (dbg & 256)) && !(dbg & 128);   // (CELLMAP_DBG=128: one list per run everywhere -- A/B; 256: chained whatever the block count -- tests)
             const int use_S = chain ? 2 : ivf_S;
             {
                 const size_t need = (size_t)(p2.nq_pad + 1024) * (size_t)use_S;
