@@ -2379,7 +2379,14 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     }
     // bucket-centred hi*hi level (level 5): state built on first use
     // (worth it from ~131k queries on: every bucket is padded to whole 512-query blocks; smaller sets only when forced)
-    const bool have_cen = rperm && !wide && !lowp && !cm_get_knobs().no_centre && (nq >= 131072 || forced == 5);
+    // The bucket-centred level exists from 65 536 queries on (round 5, late; 131 072 before): that is where bucket pruning starts, and
+    // a centred stage whose blocks are bucket-aligned prunes an order of magnitude better than the plain levels' locality-sorted
+    // blocks (100 k x 1.5 M, 40 clusters: 45.1 -> 10.4 ms; 70 k queries at sigma 0.2: 50.9 -> 15.6 ms).  Below 131 072 queries the
+    // bucket-aligned packing pads the set by up to a factor of two, so there the level is only kept if the pruning gate says it
+    // will pay (cen_abandon below): overlapping clusters go back to the three-product level at the price of the gate (~2 ms).
+    const int64_t cen_min_nq = []{ const char *e = getenv("CELLMAP_CEN_MIN"); return e ? atoll(e) : 65536LL; }();
+    const bool have_cen = rperm && !wide && !lowp && !cm_get_knobs().no_centre && (nq >= cen_min_nq || forced == 5);
+    bool cen_abandon = false;
     int *qpack = nullptr, *blk_bucket = nullptr;
     double *cen = nullptr;
     float *side = nullptr, *qnc = nullptr, *qcen = nullptr;
@@ -2499,6 +2506,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // Called by the pruned branch below -- and, for a bucket-centred main stage, BEFORE the kernel is chosen: an unpruned
         // centred stage runs on the four-accumulator kernel, a pruned one on work lists.
         bool gate_done = false;
+        int gate_ov_pct = 100;   // share of the (block, tile) pairs whose balls overlap, as the gate counted it
         auto ivf_gate = [&](int qblk, int BRt) -> cm_status {
             const int C = LS_CMAX;
             const int64_t nqb_max = (nq_pad + pack_slack) / (big_rows ? 256 : cmk2::QB) + 1;
@@ -2534,6 +2542,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 memcpy(&ov, ho, 8);
                 const unsigned long long full0 = (unsigned long long)p2.nqb * (unsigned long long)p2.n_tiles;
                 if (dbg & 16) fprintf(stderr, "[cellmap dbg] bucket pruning: balls overlap for %llu of %llu (block, tile) pairs\n", ov, full0);
+                gate_ov_pct = (int)(ov * 100ull / std::max<unsigned long long>(full0, 1ull));
                 // (a stage that can run in a single pass: the same conditions as `single` below)
                 const bool single_ok_ = marks && level != 4 && !w3 && !(dbg & (128 | 512)) && (!(dbg & 16384) || p2.nqb >= 4 * (h->n_cu > 0 ? h->n_cu : 256) || (dbg & 256)) &&
                                         !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed;
@@ -2548,6 +2557,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         };
         if (cenl && marks && ivf_try && !pilot && rerank && nsub >= 65536 && std::min(IVF_SB, RR_NCMAX / p2.Kc - 1) >= 2 && !(dbg & 8192))
             CM_TRY(ivf_gate((int)(p2.nq_pad / std::max(p2.nqb, 1)), cmk2::BR));
+        // (the padded set visits its share of the pairs twice over: kept below 30 % overlap -- ragged mixtures at 50 % measured
+        //  15 - 24 % slower centred and pruned than unpruned on the three-product level, equal blobs at 2 - 20 % four times faster)
+        if (cenl && marks && !pilot && rerank && (!ivf_try || gate_ov_pct > 30) && nq < 131072 && !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !(dbg & 8192)) {
+            cen_abandon = true;   // (nothing has been launched for the stage yet: the caller starts over on the three-product level)
+            return CM_OK;
+        }
         // Four accumulators per wave (knn_phase1_q4.h) for large full-set scans of the hi*hi level at K = 64: 1 024-query
         // blocks, so the padded query count is rounded up accordingly (every buffer carries that slack) and the 512-query
         // kernels of the same stage (seed scan) see an even number of blocks.
@@ -3202,6 +3217,14 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     int level = start, main_Kc = Kc_max, main_S = 1, main_variant = 0;
     for (int stage = 0;; ++stage) {
         CM_TRY(run_stage(level, qmap, nsub, flag_out, !(dbg & 3), stage == 0, false));
+        if (cen_abandon) {   // a small set on the centred level that cannot be pruned: the padding is not worth it
+            cen_abandon = false;
+            if (dbg & 16) fprintf(stderr, "[cellmap dbg] centred level abandoned (%lld queries, nothing to prune): three-product level\n", (long long)nq);
+            h->staged_hint_level = -5; h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
+            level = start = 3; qmap = (const int *)qperm; nsub = nq;
+            --stage;
+            continue;
+        }
         if (stage == 0) { main_Kc = last_Kc; main_S = last_S; main_variant = last_variant; }
         if (dbg & 3) break;   // timing experiments: phase 1 only
         // A wide split counts on lists that hold a few rows beyond k.  On very tight clusters the seeds' error margins admit

@@ -584,6 +584,31 @@ def test_single_pass_stage_accepts_large_visited_shares(hip, oracle, monkeypatch
     assert np.array_equal(i1[sel], oi) and np.array_equal(d1[sel], od), st1
 
 
+@pytest.mark.parametrize("prunable", [True, False])
+def test_centred_level_from_65536_queries_if_it_can_be_pruned(hip, oracle, monkeypatch, prunable):
+    """Round 5 (late): between 65 536 and 131 072 queries the bucket-centred level (whose bucket-aligned blocks prune an order of
+    magnitude better than locality-sorted ones) is used when the pruning gate says it will pay, and abandoned for the three-product
+    level when it will not (the packing pads such a set by up to a factor of two) -- here: pruning switched off.  Both outcomes
+    identical to the oracle."""
+    rng = np.random.default_rng(187)
+    d, k, n_ref, nq, ncl = 50, 20, 300_000, 90_000, 40
+    cen = rng.standard_normal((ncl, d)) * 5.0
+    ref = (cen[rng.integers(0, ncl, n_ref)] + 0.5 * rng.standard_normal((n_ref, d))).astype(np.float32)
+    qry = (cen[rng.integers(0, ncl, nq)] + 0.5 * rng.standard_normal((nq, d))).astype(np.float32)
+    monkeypatch.setenv("CELLMAP_NO_HINT", "1")
+    if not prunable:
+        monkeypatch.setenv("CELLMAP_NO_IVF", "1")
+    dist, idx = hip.knn(ref, qry, k)
+    st = hip.knn_stats()
+    if prunable:
+        assert st["filter_products"] == 5 and st["pruning_passes"] == 1 and st["tiles_visited_pct"] <= 10, st
+    else:
+        assert st["filter_products"] == 3 and st["pruning_passes"] == 0, st      # (abandoned before anything was launched for it)
+    sel = rng.choice(nq, 400, replace=False)
+    od, oi = oracle.knn_euclidean(ref, qry[sel], k)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od), st
+
+
 def test_wide_split_overflow_repeats_the_level(hip, oracle, monkeypatch):
     """Round 5 (late): eight very tight clusters of 37 k rows.  The queries the long-list centred level leaves uncertified start
     their three-product stage from finite seeds and split the reference ~250 ways -- but the seeds' error margins admit more
