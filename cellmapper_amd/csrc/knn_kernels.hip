@@ -1771,6 +1771,14 @@ static inline int prune_max_pct(bool single_pass, bool gate = false) {
     static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX"); const int x = e ? atoi(e) : 70; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
     return single_pass ? (gate ? std::max(12, v - 10) : v) : 12;
 }
+// Fewest queries of a search whose main stage may be pruned / bucket-centred: 16 384 (65 536 until late in round 5 -- a limit of the
+// pass A + B form, whose per-run lists needed many blocks to balance; the single chained pass does not: 40 k x 1.5 M, 40 clusters:
+// 28.3 -> 9.3 ms, 40 k x 300 k at sigma 0.3: 9.0 -> 5.5 ms, overlapping clusters and structure-free sets unchanged).
+// CELLMAP_PRUNE_MIN_NQ overrides it.
+static inline int64_t prune_min_nq() {
+    static const int64_t v = []{ const char *e = getenv("CELLMAP_PRUNE_MIN_NQ"); return e ? atoll(e) : 16384LL; }();
+    return v;
+}
 static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
     return (size_t)(nq_pad + 256 * 512) * (IVF_SB + 1) * (size_t)Kc_max * 4 <= ((size_t)16 << 30);
 }
@@ -2347,7 +2355,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         rperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)n_ref);
         qperm = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)nq);
         r_bstart = (int *)cm_ws_alloc(h, sizeof(int) * (LS_CMAX + 1));
-        if (nq >= 65536) {
+        if (nq >= prune_min_nq()) {
             flag_s = (int *)cm_ws_alloc(h, sizeof(int) * (size_t)(nq + 1));
             fl_tmp = (int *)cm_ws_alloc(h, sizeof(int) * 2 * (size_t)(nq + 1));
             fl_cnt = (int *)cm_ws_alloc(h, sizeof(int) * 2 * LS_CMAX);
@@ -2384,7 +2392,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // blocks (100 k x 1.5 M, 40 clusters: 45.1 -> 10.4 ms; 70 k queries at sigma 0.2: 50.9 -> 15.6 ms).  Below 131 072 queries the
     // bucket-aligned packing pads the set by up to a factor of two, so there the level is only kept if the pruning gate says it
     // will pay (cen_abandon below): overlapping clusters go back to the three-product level at the price of the gate (~2 ms).
-    const int64_t cen_min_nq = []{ const char *e = getenv("CELLMAP_CEN_MIN"); return e ? atoll(e) : 65536LL; }();
+    const int64_t cen_min_nq = []{ const char *e = getenv("CELLMAP_CEN_MIN"); return e ? atoll(e) : prune_min_nq(); }();
     const bool have_cen = rperm && !wide && !lowp && !cm_get_knobs().no_centre && (nq >= cen_min_nq || forced == 5);
     bool cen_abandon = false;
     int *qpack = nullptr, *blk_bucket = nullptr;
@@ -2399,7 +2407,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     if (!hint_same || h->staged_ivf_nref != n_ref || h->staged_ivf_nq != nq) h->staged_ivf_skip = 0;
     // (round 5: the K = 128 family prunes too -- its hi*hi level on 512-query blocks like the K <= 64 kernels, its three-product
     //  level on the 256-query blocks of knn_cand_f16w)
-    bool ivf_try = rperm && !lowp && nq >= 65536 && ivf_fits(nq_pad, Kc_max) && !forced && !cm_get_knobs().no_ivf;
+    bool ivf_try = rperm && !lowp && nq >= prune_min_nq() && ivf_fits(nq_pad, Kc_max) && !forced && !cm_get_knobs().no_ivf;
     if (ivf_try && h->staged_ivf_skip > 0 && !cm_get_knobs().no_hint) { --h->staged_ivf_skip; ivf_try = false; }   // (it did not pay last time)
     const int ivf_S = IVF_SB + 1;
     double *ivf_rcen = nullptr, *ivf_rrad = nullptr, *ivf_bcen = nullptr, *ivf_brad = nullptr;
@@ -2555,7 +2563,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             gate_done = true;
             return CM_OK;
         };
-        if (cenl && marks && ivf_try && !pilot && rerank && nsub >= 65536 && std::min(IVF_SB, RR_NCMAX / p2.Kc - 1) >= 2 && !(dbg & 8192))
+        if (cenl && marks && ivf_try && !pilot && rerank && nsub >= prune_min_nq() && std::min(IVF_SB, RR_NCMAX / p2.Kc - 1) >= 2 && !(dbg & 8192))
             CM_TRY(ivf_gate((int)(p2.nq_pad / std::max(p2.nqb, 1)), cmk2::BR));
         // (the padded set visits its share of the pairs twice over: kept below 30 % overlap -- ragged mixtures at 50 % measured
         //  15 - 24 % slower centred and pruned than unpruned on the three-product level, equal blobs at 2 - 20 % four times faster)
@@ -2830,7 +2838,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
         // candidate lists per block: the re-rank ranks at most RR_NCMAX candidates per query, and on the last level a query
         // must never be dropped for holding too many (its only way out would be the exact scan with a loose bound)
         const int ivf_sb = std::min(IVF_SB, RR_NCMAX / p2.Kc - 1);
-        if (ivf_try && full_set && !pilot && rerank && ivf_sb >= 2 && nsub >= (marks ? 65536 : cm_get_knobs().ivf_submin)) {
+        if (ivf_try && full_set && !pilot && rerank && ivf_sb >= 2 && nsub >= (marks ? prune_min_nq() : (int64_t)cm_get_knobs().ivf_submin)) {
             const int qblk = (int)(p2.nq_pad / std::max(p2.nqb, 1));   // queries per work item of this stage's filter kernel (512; 256: knn_cand_f16w, direct rows beyond 64 floats)
             const int BRt = level == 4 ? cmk2::lowd_rows(dl) : cmk2::BR;   // reference rows per tile of this level's image
 
@@ -3575,7 +3583,7 @@ size_t cm_knn_ws_bytes_all_routes(int64_t n_ref, int64_t nq, int32_t d, int32_t 
         b += cm_align(4 * (size_t)(nq + 256 * 512)) * 3 + cm_align(4 * (size_t)(nq / 512 + 300)) + cm_align(8 * (size_t)256 * d) +
              cm_align(4 * (size_t)256 * (size_t)(n_ref + 512)) + cm_align(4 * (size_t)256 * 512) * 2 + cm_align((size_t)256 * 512 * 256) + 8192 +
              cm_align(8 * (size_t)256 * (size_t)(n_ref / (32 * cmk2::BR) + 2));   // (+ the two (bucket, tile) bitmaps of cen_side_mark)
-    if (nq >= 65536 && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
+    if (nq >= prune_min_nq() && n_ref >= 65536 && ivf_fits(nq_pad, Kc + 16)) {   // bucket pruning: IVF_SB + 1 candidate lists per query, plans
         const size_t nqp = (size_t)(nq_pad + 256 * 512), nqb = nqp / 256 + 1;
         const size_t lists = nq_pad / 512 >= 1024 ? 2 : IVF_SB + 1;   // (chained pass B from four blocks per compute unit on)
         b += cm_align(4 * nqp * lists * (size_t)(Kc + 16)) + cm_align(4 * nqp * lists) + cm_align(8 * nqb * 136) +

@@ -586,7 +586,7 @@ def test_single_pass_stage_accepts_large_visited_shares(hip, oracle, monkeypatch
 
 @pytest.mark.parametrize("prunable", [True, False])
 def test_centred_level_from_65536_queries_if_it_can_be_pruned(hip, oracle, monkeypatch, prunable):
-    """Round 5 (late): between 65 536 and 131 072 queries the bucket-centred level (whose bucket-aligned blocks prune an order of
+    """Round 5 (late): between 16 384 and 131 072 queries the bucket-centred level (whose bucket-aligned blocks prune an order of
     magnitude better than locality-sorted ones) is used when the pruning gate says it will pay, and abandoned for the three-product
     level when it will not (the packing pads such a set by up to a factor of two) -- here: pruning switched off.  Both outcomes
     identical to the oracle."""
