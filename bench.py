@@ -340,7 +340,7 @@ def gpu_clock_mhz(index=0):
     return None
 
 
-def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.0, check=2048):
+def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.0, check=2048, ragged=False):
     """Secondary leg of config 2, OUTSIDE the headline: the same shape (nq x n_ref, d, k, label transfer) on a Gaussian mixture
     -- what `.obsm["X_pca"]` of an atlas looks like (cellmapper.py:237-251 takes the representation as given; SURVEY.md 8d
     allows "a Gaussian mixture to mimic cell-type structure -- report which") -- on a FRESH handle, so that `first_call_ms`
@@ -352,8 +352,8 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
     from cellmapper_amd.device import DevicePipeline
 
     a, torch, dev = ctx.a, ctx.torch, ctx.dev
-    ref = bd.mixture_rows(torch, bd.STREAM_REF, 0, a.nref, a.d, dev, n_clusters, spread, sigma)
-    qry = bd.mixture_rows(torch, bd.STREAM_QRY, 0, a.nq, a.d, dev, n_clusters, spread, sigma)
+    ref = bd.mixture_rows(torch, bd.STREAM_REF, 0, a.nref, a.d, dev, n_clusters, spread, sigma, ragged=ragged)
+    qry = bd.mixture_rows(torch, bd.STREAM_QRY, 0, a.nq, a.d, dev, n_clusters, spread, sigma, ragged=ragged)
     torch.cuda.synchronize()
     pipe = DevicePipeline(dev.index or 0)
     pipe.h.set_profiling(True)
@@ -392,11 +392,13 @@ def clustered_leg(ctx, codes, steps, warmup, n_clusters=40, spread=5.0, sigma=1.
         ctx2.a = a2
         rec, _, ok = parity_gate(ctx2, dist_t, idx_t, code_t, conf_t, 0, a.nq, False,
                                  ref_host_fn=lambda: ref.cpu().numpy(),
-                                 qry_rows_fn=lambda ids: bd.mixture_rows_at(torch, bd.STREAM_QRY, ids, a.d, dev, n_clusters, spread, sigma))
+                                 qry_rows_fn=lambda ids: bd.mixture_rows_at(torch, bd.STREAM_QRY, ids, a.d, dev, n_clusters, spread, sigma, ragged))
     finally:
         torch.cuda.set_stream(prev_stream)
     res = {"data": f"Gaussian mixture from the counter-based streams (bench_data.mixture_rows): {n_clusters} clusters, centres N(0, {spread}^2), "
-                   f"within-cluster sigma {sigma}, reference and query share the centres; {a.nq} x {a.nref}, d={a.d}, k={a.k}",
+                   f"within-cluster sigma {sigma}, reference and query share the centres; {a.nq} x {a.nref}, d={a.d}, k={a.k}"
+                   + ("; RAGGED: log-normal cluster weights (different on the two sides), per-cluster spread 0.3 .. 3 x sigma, a random scale per "
+                      "coordinate (bench_data.ragged_params) -- overlapping clusters: the slow case of this route" if ragged else ""),
            "ms_per_step": ms, "value": a.nq / (ms * 1e-3), "unit": "query cells/s", "steps": steps, "warmup": warmup,
            "first_call_ms": first_ms, "first_call_over_steady": first_ms / ms,
            "first_call_allocator_ms": {"workspace": al1["workspace_ms"] - al0["workspace_ms"], "workspace_bytes_added_in_call": al1["workspace_bytes"] - al0["workspace_bytes"],
@@ -967,6 +969,10 @@ def main_rank(a):
             and a.nq == CONFIGS[2]["nq"] and a.nref == CONFIGS[2]["nref"]):
         crec, c_ok = clustered_leg(ctx, codes, steps=max(3, a.steps // 4), warmup=max(1, min(2, a.warmup)))
         result["clustered"] = crec
+        if c_ok:   # (round 5, late) ... and what equal blobs do not show: clusters of unequal size and spread that overlap
+            rrec, r_ok = clustered_leg(ctx, codes, steps=max(2, a.steps // 8), warmup=1, sigma=0.5, ragged=True)
+            result["clustered_ragged"] = rrec
+            c_ok = c_ok and r_ok
         parity_ok = parity_ok and c_ok
     if rank == 0 and a.cpu_sample > 0 and a.metric == "euclidean":
         from oracle import oracle as orc

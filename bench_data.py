@@ -102,25 +102,47 @@ def mixture_centres(torch, n_clusters: int, width: int, device, spread: float = 
     return normal_block(torch, STREAM_CENTRE, 0, n_clusters, 0, width, device) * spread
 
 
-def mixture_rows_at(torch, stream: int, row_ids, width: int, device, n_clusters: int = 40, spread: float = 5.0, sigma: float = 1.0):
+STREAM_RAGGED = 40         # ragged mixtures: cluster weights (+ the side's stream), per-cluster spread, per-coordinate scale
+
+
+def ragged_params(torch, stream: int, n_clusters: int, width: int, device):
+    """Ragged mixture (round 5, late): clusters of unequal size -- log-normal weights, DIFFERENT on the two sides (a query set
+    over-represents other cell types than the atlas) --, each with its own spread (0.3 .. 3 x sigma, log-uniform) and a random
+    per-coordinate scale shared by all clusters (anisotropy).  Returns (cumulative weights of `stream`, spread factors, scales)."""
+    w = torch.exp(1.2 * normal_block(torch, STREAM_RAGGED + stream, 0, 1, 0, n_clusters, device)[0].double())
+    cw = torch.cumsum(w / w.sum(), 0)
+    u = normal_block(torch, STREAM_RAGGED, 1, 2, 0, n_clusters, device)[0]
+    csig = torch.exp((0.5 * (1.0 + torch.erf(u / 2 ** 0.5))) * 2.3 - 1.2)          # uniform through the normal CDF
+    aniso = torch.exp(0.5 * normal_block(torch, STREAM_RAGGED, 2, 3, 0, width, device)[0])
+    return cw, csig, aniso
+
+
+def mixture_rows_at(torch, stream: int, row_ids, width: int, device, n_clusters: int = 40, spread: float = 5.0, sigma: float = 1.0,
+                    ragged: bool = False):
     """Mixture rows at arbitrary row numbers: row i of `stream` = centre[member(i)] + sigma * N(0, 1) -- a pure function of
     (stream, i, column), like every other stream here, so any rank can draw its shard and the parity gate can re-draw its
-    sample.  Reference and query share the centres (a query maps onto the atlas' cell types)."""
+    sample.  Reference and query share the centres (a query maps onto the atlas' cell types).  ragged: see ragged_params."""
     rows = torch.as_tensor(row_ids, dtype=torch.int32, device=device)
     cen = mixture_centres(torch, n_clusters, width, device, spread)
     zero = torch.zeros(1, dtype=torch.int32, device=device)
-    member = (_lsr(hash_grid(torch, STREAM_MEMBER + stream, rows, zero)[:, 0], 8) % n_clusters).to(torch.int64)
-    return cen[member] + rows_at(torch, "normal", stream, rows, width, device) * sigma
+    h = _lsr(hash_grid(torch, STREAM_MEMBER + stream, rows, zero)[:, 0], 8)
+    if not ragged:
+        member = (h % n_clusters).to(torch.int64)
+        return cen[member] + rows_at(torch, "normal", stream, rows, width, device) * sigma
+    cw, csig, aniso = ragged_params(torch, stream, n_clusters, width, device)
+    u = (h.to(torch.float64) + 0.5) / float(1 << 24)
+    member = torch.clamp(torch.searchsorted(cw, u), max=n_clusters - 1)
+    return cen[member] + rows_at(torch, "normal", stream, rows, width, device) * (sigma * csig[member])[:, None] * aniso[None, :]
 
 
 def mixture_rows(torch, stream: int, r0: int, r1: int, width: int, device, n_clusters: int = 40, spread: float = 5.0,
-                 sigma: float = 1.0, chunk_rows: int = 500_000):
+                 sigma: float = 1.0, chunk_rows: int = 500_000, ragged: bool = False):
     """Rows [r0, r1) of the mixture as one float32 tensor, in row chunks."""
     out = torch.empty((r1 - r0, width), dtype=torch.float32, device=device)
     for a in range(r0, r1, chunk_rows):
         b = min(r1, a + chunk_rows)
         out[a - r0:b - r0] = mixture_rows_at(torch, stream, torch.arange(a, b, dtype=torch.int32, device=device), width, device,
-                                             n_clusters, spread, sigma)
+                                             n_clusters, spread, sigma, ragged)
     return out
 
 
