@@ -1767,6 +1767,13 @@ constexpr int IVF_CSTR = 128;   // doubles per centre (round 5: the K = 128 fami
 // (ragged 40-cluster mixture, sigma 0.5: 61 % of the pairs, 212 against 269 ms): break-even at 79 %, accepted up to 70 %; the
 // gate in front of it (pairs whose balls overlap: a lower bound of the plan's share) lets 60 % through.
 // CELLMAP_PRUNE_MAX overrides the 70 (the gate follows 10 below).
+// ... and pass A + B of a SEEDED subset stage (its pass A starts from the queries' bounds, not from +inf: no start-up churn): 60 %
+// -- 93 k flagged queries of the ragged bench leg, 57 % of the pairs: 57.1 -> 43.2 ms; 53 k at 1.5 M x 1.5 M: 34.8 -> 23.2 ms; a plan
+// rejected after pass A costs ~7 ms (CELLMAP_PRUNE_MAX_SUB).
+static inline int prune_max_sub_pct() {
+    static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX_SUB"); const int x = e ? atoi(e) : 60; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
+    return v;
+}
 static inline int prune_max_pct(bool single_pass, bool gate = false) {
     static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX"); const int x = e ? atoi(e) : 70; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
     return single_pass ? (gate ? std::max(12, v - 10) : v) : 12;
@@ -2554,7 +2561,8 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                 // (a stage that can run in a single pass: the same conditions as `single` below)
                 const bool single_ok_ = marks && level != 4 && !w3 && !(dbg & (128 | 512)) && (!(dbg & 16384) || p2.nqb >= 4 * (h->n_cu > 0 ? h->n_cu : 256) || (dbg & 256)) &&
                                         !forced && !(flags & CM_KNN_FORCE_FALLBACK) && !cm_get_knobs().no_seed;
-                const unsigned long long pmx_ = (unsigned long long)prune_max_pct(single_ok_, true);
+                unsigned long long pmx_ = (unsigned long long)prune_max_pct(single_ok_, true);
+                if (!marks && seeds_from_level >= 1) pmx_ = std::max<unsigned long long>(pmx_, (unsigned long long)prune_max_sub_pct());   // (seeded subset stage)
                 if (ov * 100ull > full0 * pmx_) {   // (see the threshold after the plan)
                     ivf_try = false;
                     if (marks) { h->staged_ivf_skip = 15; h->staged_ivf_nref = n_ref; h->staged_ivf_nq = nq; }
@@ -3046,7 +3054,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             // Pruning pays when little is left: every list starts its own threshold history (pass A from +inf) and the
             // re-rank ranks several lists per query, so at 15-25 % of the pairs the pruned stage measured SLOWER than the
             // full scan (tests/fuzz/fuzz_paths.py); at an eighth and below it wins.
-            if (tiles * 8ull <= full) {
+            if (tiles * 100ull <= full * (unsigned long long)(seed_a ? prune_max_sub_pct() : 12)) {
                 if (hc[0] > 0) {
                     b.wlist = ivf_wlb; b.n_wlist = hc[0]; b.thr0_slot0 = 1;
                     b.wruns = chain ? ivf_runs : (const int2 *)nullptr;
