@@ -30,6 +30,9 @@ void latch_knobs() {
     k.dbg = (int)num("CELLMAP_DBG", 0);
     k.fb_max = (int)num("CELLMAP_FB_MAX", 64);
     k.ivf_submin = (int)num("CELLMAP_IVF_SUBMIN", 32768);
+    k.prune_max = (int)std::min<long long>(95, std::max<long long>(12, num("CELLMAP_PRUNE_MAX", 70)));
+    k.prune_max_sub = (int)std::min<long long>(95, std::max<long long>(12, num("CELLMAP_PRUNE_MAX_SUB", 60)));
+    k.prune_min_nq = (int)std::max<long long>(4096, num("CELLMAP_PRUNE_MIN_NQ", 16384));
     if (const char *e = getenv("CELLMAP_SEED_WIDEN")) k.seed_widen = (float)atof(e);
     k.filter_products = (int)num("CELLMAP_FILTER_PRODUCTS", 0);
     k.q4 = (int)num("CELLMAP_Q4", 1);

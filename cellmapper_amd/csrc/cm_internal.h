@@ -11,6 +11,9 @@
 // cm_reload_knobs) into this process-wide record -- nothing on a call path reads the environment.
 struct cm_knobs {
     float seed_widen = 2.0f;     // CELLMAP_SEED_WIDEN: sample-scan seeds of a more precise level are widened by this many plain hi*hi error bounds
+    int prune_max = 70;          // CELLMAP_PRUNE_MAX: largest share (%) of the (block, tile) pairs a single-pass pruned stage may visit (its gate: 10 below)
+    int prune_max_sub = 60;      // CELLMAP_PRUNE_MAX_SUB: ... and pass A + B of a seeded subset stage
+    int prune_min_nq = 16384;    // CELLMAP_PRUNE_MIN_NQ: fewest queries of a search whose main stage may be pruned / bucket-centred
     int ivf_submin = 32768;      // CELLMAP_IVF_SUBMIN: smallest set of flagged queries that is regrouped by bucket and pruned (42 k queries at sigma 0.1: 35 -> 20 ms pruned)
     int fb_max = 64;             // CELLMAP_FB_MAX: at most this many uncertified queries (all with a finite bound) go straight to the exact scan
     int dbg = 0;                 // CELLMAP_DBG: in-kernel timing modes / counters of the filter kernels

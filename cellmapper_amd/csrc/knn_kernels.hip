@@ -1771,11 +1771,10 @@ constexpr int IVF_CSTR = 128;   // doubles per centre (round 5: the K = 128 fami
 // -- 93 k flagged queries of the ragged bench leg, 57 % of the pairs: 57.1 -> 43.2 ms; 53 k at 1.5 M x 1.5 M: 34.8 -> 23.2 ms; a plan
 // rejected after pass A costs ~7 ms (CELLMAP_PRUNE_MAX_SUB).
 static inline int prune_max_sub_pct() {
-    static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX_SUB"); const int x = e ? atoi(e) : 60; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
-    return v;
+    return cm_get_knobs().prune_max_sub;
 }
 static inline int prune_max_pct(bool single_pass, bool gate = false) {
-    static const int v = []{ const char *e = getenv("CELLMAP_PRUNE_MAX"); const int x = e ? atoi(e) : 70; return x < 12 ? 12 : (x > 95 ? 95 : x); }();
+    const int v = cm_get_knobs().prune_max;
     return single_pass ? (gate ? std::max(12, v - 10) : v) : 12;
 }
 // Fewest queries of a search whose main stage may be pruned / bucket-centred: 16 384 (65 536 until late in round 5 -- a limit of the
@@ -1783,8 +1782,7 @@ static inline int prune_max_pct(bool single_pass, bool gate = false) {
 // 28.3 -> 9.3 ms, 40 k x 300 k at sigma 0.3: 9.0 -> 5.5 ms, overlapping clusters and structure-free sets unchanged).
 // CELLMAP_PRUNE_MIN_NQ overrides it.
 static inline int64_t prune_min_nq() {
-    static const int64_t v = []{ const char *e = getenv("CELLMAP_PRUNE_MIN_NQ"); return e ? atoll(e) : 16384LL; }();
-    return v;
+    return (int64_t)cm_get_knobs().prune_min_nq;
 }
 static inline bool ivf_fits(int64_t nq_pad, int Kc_max) {
     return (size_t)(nq_pad + 256 * 512) * (IVF_SB + 1) * (size_t)Kc_max * 4 <= ((size_t)16 << 30);
@@ -2399,7 +2397,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
     // blocks (100 k x 1.5 M, 40 clusters: 45.1 -> 10.4 ms; 70 k queries at sigma 0.2: 50.9 -> 15.6 ms).  Below 131 072 queries the
     // bucket-aligned packing pads the set by up to a factor of two, so there the level is only kept if the pruning gate says it
     // will pay (cen_abandon below): overlapping clusters go back to the three-product level at the price of the gate (~2 ms).
-    const int64_t cen_min_nq = []{ const char *e = getenv("CELLMAP_CEN_MIN"); return e ? atoll(e) : prune_min_nq(); }();
+    const int64_t cen_min_nq = prune_min_nq();
     const bool have_cen = rperm && !wide && !lowp && !cm_get_knobs().no_centre && (nq >= cen_min_nq || forced == 5);
     bool cen_abandon = false;
     int *qpack = nullptr, *blk_bucket = nullptr;
