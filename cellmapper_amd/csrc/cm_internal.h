@@ -66,7 +66,7 @@ struct cm_handle_s {
     // staged search: the filter level that certified most queries on the previous call with this (d, k, metric); lets
     // repeated calls on similar data skip the pilot (a stale hint only costs time: the ladder still escalates)
     int staged_hint_level = 0, staged_hint_d = 0, staged_hint_k = 0, staged_hint_metric = 0;
-    int64_t staged_long_nref = 0, staged_long_nq = 0;   // hint 6 (centred level, long lists) holds for the problem size it was learnt on
+    int64_t staged_long_nref = 0, staged_long_nq = 0;   // hints 3, 4, 6 and -5 hold for the problem size they were learnt on
     int staged_ivf_skip = 0;   // calls for which bucket pruning is not tried again after it did not pay ...
     int64_t staged_ivf_nref = 0, staged_ivf_nq = 0;   // ... on a problem of these sizes
     int32_t *d_nflag_pinned = nullptr;  // host-pinned mirror for the fallback counter (read lazily)

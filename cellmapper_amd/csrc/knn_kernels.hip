@@ -3199,9 +3199,12 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
                          !cm_get_knobs().no_hint;
     // (round 5: a set that STARTED on the three-product or the direct level and certified most of its queries there starts there
     //  again -- its pilot, two sample stages over the whole reference, was 30 of the 230 ms of the 40-cluster d = 128 shape)
-    const bool hinted = hint_ok && (h->staged_hint_level == 1 || h->staged_hint_level == 3 || (h->staged_hint_level == 4 && have_direct) ||
+    // (hints 3, 4 and 6 -- start levels that give up on cheaper ones -- hold for the problem size they were learnt on: another data set of
+    //  the same width gets its pilot again)
+    const bool same_size = h->staged_long_nref == n_ref && h->staged_long_nq == nq;
+    const bool hinted = hint_ok && (h->staged_hint_level == 1 || (h->staged_hint_level == 3 && same_size) || (h->staged_hint_level == 4 && have_direct && same_size) ||
                                     ((h->staged_hint_level == 5 || (h->staged_hint_level == 6 && cen_long)) && have_cen));
-    const bool cen_bad = hint_ok && h->staged_hint_level == -5;   // the centred level failed for most queries last time
+    const bool cen_bad = hint_ok && h->staged_hint_level == -5 && same_size;   // the centred level failed for most queries last time (on this problem size)
     if (lowp) {}   // grid or direct kernel: nothing to choose
     else if (forced) start = forced;
     else if (flags & CM_KNN_FORCE_FALLBACK) start = 3;
@@ -3235,6 +3238,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             cen_abandon = false;
             if (dbg & 16) fprintf(stderr, "[cellmap dbg] centred level abandoned (%lld queries, nothing to prune): three-product level\n", (long long)nq);
             h->staged_hint_level = -5; h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
+            h->staged_long_nref = n_ref; h->staged_long_nq = nq;
             level = start = 3; qmap = (const int *)qperm; nsub = nq;
             --stage;
             continue;
@@ -3284,7 +3288,7 @@ cm_status knn_run_staged(cm_handle_t h, const T *d_ref, int64_t n_ref, const T *
             else
                 h->staged_hint_level = good ? (level == 5 ? 6 : level) : (level == 5 ? -5 : 0);
             h->staged_hint_d = d; h->staged_hint_k = k; h->staged_hint_metric = metric;
-            if (h->staged_hint_level == 6) { h->staged_long_nref = n_ref; h->staged_long_nq = nq; }
+            if (h->staged_hint_level == 6 || h->staged_hint_level == 3 || h->staged_hint_level == 4 || h->staged_hint_level == -5) { h->staged_long_nref = n_ref; h->staged_long_nq = nq; }
         }
         if (dbg & 16) {
             unsigned gc[4] = {0, 0, 0, 0}, why[2] = {0, 0};
