@@ -847,21 +847,33 @@ cm_status cm_mapping_matrix(cm_handle_t h, const double *dist, const int64_t *id
     if (nq < 0 || k < 1) CM_FAIL(h, CM_E_INVALID, "mapping matrix: bad shape");
     if (kernel < 0 || kernel > CM_KERNEL_IDENTITY) CM_FAIL(h, CM_E_INVALID, "Unknown kernel id %d", kernel);
     size_t nk = (size_t)nq * k;
+    // (phase clock: a phase that takes more than a second is reported on stderr -- DESIGN.md section 8, "host-tier calls that stall")
+    double ph_t = wall_ms();
+    auto phase = [&](const char *what) {
+        const double now = wall_ms();
+        if (now - ph_t > 1000.0) fprintf(stderr, "[cellmap] cm_mapping_matrix: %.1f s in phase '%s' (nq=%lld, k=%d)\n", (now - ph_t) * 1e-3, what, (long long)nq, (int)k);
+        ph_t = now;
+    };
     CM_TRY(begin_call(h, 64 * 1024 + cm_scan_ws_bytes(nq)));
+    phase("begin_call");
     DevBuf dd, di, dcols, dvals, dconn, dcnt, dptr, ocols, ovals, oconn, dm;
     CM_TRY(dd.alloc(h, 8 * nk)); CM_TRY(di.alloc(h, 8 * nk));
     CM_TRY(dcols.alloc(h, 4 * nk)); CM_TRY(dvals.alloc(h, 4 * nk)); CM_TRY(dcnt.alloc(h, 4 * (size_t)nq));
     CM_TRY(dptr.alloc(h, 8 * ((size_t)nq + 1))); CM_TRY(ocols.alloc(h, 4 * nk)); CM_TRY(ovals.alloc(h, 4 * nk));
     CM_TRY(dm.alloc(h, 64));
     if (out_conn) { CM_TRY(dconn.alloc(h, 8 * nk)); CM_TRY(oconn.alloc(h, 8 * nk)); }
+    phase("device buffers");
     CM_TRY(h2d(h, dd.p, dist, 8 * nk));
     CM_TRY(h2d(h, di.p, idx, 8 * nk));
+    phase("uploads (enqueue)");
     double *m3 = dm.as<double>(), *param = m3 + 5;
     CM_HIP(h, hipMemsetAsync(m3, 0, 64, h->stream));
     CM_TRY(cm_moments_run(h, dd.as<double>(), di.as<int64_t>(), (int64_t)nk, nullptr, m3));
     double hm[3] = {0, 0, 0};
     CM_TRY(d2h(h, hm, m3, 24));
+    phase("moments (enqueue) + read-back (enqueue)");
     CM_TRY(sync(h));
+    phase("first stream wait");
     if (!(hm[2] > 0.0)) CM_FAIL(h, CM_E_NOFINITE, "No finite distances found in the neighborhood graph");
     CM_TRY(kernel_param_dev(h, dd.as<double>(), di.as<int64_t>(), (int64_t)nk, kernel, m3, param));
     CM_TRY(cm_weights_run(h, dd.as<double>(), di.as<int64_t>(), nq, k, n_ref, kernel, param, epsilon, dcols.as<int32_t>(),
@@ -869,15 +881,18 @@ cm_status cm_mapping_matrix(cm_handle_t h, const double *dist, const int64_t *id
     CM_TRY(cm_ell_to_csr_run(h, dcols.as<int32_t>(), dvals.as<float>(), out_conn ? dconn.as<double>() : nullptr,
                              dcnt.as<int32_t>(), nq, k, dptr.as<int64_t>(), ocols.as<int32_t>(), ovals.as<float>(),
                              out_conn ? oconn.as<double>() : nullptr));
+    phase("weights + CSR kernels (enqueue)");
     CM_TRY(d2h(h, out_indptr, dptr.p, 8 * ((size_t)nq + 1)));
     double hp = 0.0;
     CM_TRY(d2h(h, &hp, param, 8));
     CM_TRY(sync(h));
+    phase("second stream wait");
     int64_t nnz = out_indptr[nq];
     CM_TRY(d2h(h, out_cols, ocols.p, 4 * (size_t)nnz));
     CM_TRY(d2h(h, out_vals, ovals.p, 4 * (size_t)nnz));
     if (out_conn) CM_TRY(d2h(h, out_conn, oconn.p, 8 * (size_t)nnz));
     CM_TRY(sync(h));
+    phase("downloads + last stream wait");
     if (out_nnz) *out_nnz = nnz;
     if (out_param) *out_param = (kernel == CM_KERNEL_GAUSSIAN || kernel == CM_KERNEL_SCARCHES) ? hp : 0.0;
     return CM_OK;
